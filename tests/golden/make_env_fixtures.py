@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/env_rollout_*.npz by running the REFERENCE env glue.
+
+What runs: the reference's unmodified `HectorFreeEnv` (humanoid/envs/custom/hector_env.py +
+humanoid/envs/base/legged_robot.py) imported from /root/reference over the stub isaacgym in
+tests/refstub/, whose `gym.simulate` is oracle/physics.py.  Every random draw the reference makes
+(torch.rand / torch.randn_like, reference hector_env.py:166-168,243, legged_robot.py:327-335,366,384,
+hector_env.py:58-63) is recorded and laid out as the per-step "random pack" the product's parity
+mode injects (include/hx_sim.h, HX_RP_* offsets).
+
+Outputs per step: actions in; newest obs frame (41) and privileged frame (70); reward; reset and
+time-out flags; post-step physics state (float64) and the tensors the glue read; selected full
+615/1050 stacks.  Only data is stored -- no reference source text.
+
+Run in this container only:  python tests/golden/make_env_fixtures.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from tests.refstub import loader  # noqa: E402
+
+# random-pack field offsets (floats per env); mirrored in include/hx_sim.h
+RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34)
+RP_SIZE = 75
+
+
+def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_counter_init=0, add_noise=True,
+             full_stack_steps=(0, 1, 14, 15, 16)):
+    env_mod, cfg_mod, helpers = loader.load_env()
+    from isaacgym import gymapi, torch_utils
+    import isaacgym.torch_utils  # noqa: F401
+
+    cfg = cfg_mod.HectorCfg()
+    cfg.terrain.mesh_type = "plane"          # first slice (heightfield is a next row)
+    cfg.env.num_envs = n_envs
+    cfg.noise.add_noise = add_noise
+    cfg.seed = seed
+    helpers.set_seed(seed)
+    sim_params = gymapi.SimParams()
+    sim_params.dt = cfg.sim.dt
+    sim_params.use_gpu_pipeline = False
+
+    log = []
+    real_rand, real_randn_like = torch.rand, torch.randn_like
+
+    def rand(*a, **k):
+        r = real_rand(*a, **k)
+        log.append(("rand", r.clone()))
+        return r
+
+    def randn_like(x, *a, **k):
+        r = real_randn_like(x, *a, **k)
+        log.append(("randn", r.clone()))
+        return r
+
+    torch.rand, torch.randn_like = rand, randn_like
+    try:
+        env = env_mod.HectorFreeEnv(cfg, sim_params, gymapi.SIM_PHYSX, "cpu", True)
+        gym = env.gym
+        gym.env = env
+        N = n_envs
+        # creation-time draws (start xy, friction buckets) are creation inputs, not step packs; the
+        # constructor's reset_idx(all)+compute_observations made exactly the last five draws
+        creation_draws = len(log) - (5 if add_noise else 4)
+
+        # wrap methods to leave markers with the env ids they act on
+        orig_resample, orig_reset_dofs = env._resample_commands, env._reset_dofs
+
+        def resample(ids):
+            log.append(("mark_resample", ids.clone()))
+            return orig_resample(ids)
+
+        def reset_dofs(ids):
+            log.append(("mark_reset", ids.clone()))
+            return orig_reset_dofs(ids)
+
+        env._resample_commands, env._reset_dofs = resample, reset_dofs
+
+        def build_pack(entries, is_init):
+            pack = np.zeros((RP_SIZE, N), np.float32)
+            it = iter(entries)
+            state = "start"
+            resample_count = 0
+            e = next(it, None)
+            if not is_init:
+                assert e[0] == "rand" and e[1].shape == (N, 1)
+                pack[RP["delay"]] = e[1][:, 0].numpy()
+                e = next(it)
+                assert e[0] == "randn" and e[1].shape == (N, 10)
+                pack[RP["act_noise"]:RP["act_noise"] + 10] = e[1].numpy().T
+                e = next(it, None)
+            while e is not None:
+                if e[0] == "mark_resample":
+                    ids = e[1].numpy()
+                    field = RP["cmd_b"] if (state == "reset" or is_init) else RP["cmd_a"]
+                    for k in range(3):
+                        r = next(it)
+                        assert r[0] == "rand" and r[1].shape == (len(ids), 1), (r[0], r[1].shape, len(ids))
+                        pack[field + k, ids] = r[1][:, 0].numpy()
+                    resample_count += 1
+                elif e[0] == "mark_reset":
+                    ids = e[1].numpy()
+                    r = next(it)
+                    assert r[0] == "rand" and r[1].shape == (len(ids), 10)
+                    pack[RP["reset_q"]:RP["reset_q"] + 10, ids] = r[1].numpy().T
+                    state = "reset"
+                elif e[0] == "rand" and e[1].shape == (N, 2):
+                    pack[RP["push"]:RP["push"] + 2] = e[1].numpy().T
+                    r = next(it)
+                    assert r[0] == "rand" and r[1].shape == (N, 3)
+                    pack[RP["push"] + 2:RP["push"] + 5] = r[1].numpy().T
+                elif e[0] == "randn" and e[1].shape == (N, 41):
+                    pack[RP["obs_noise"]:RP["obs_noise"] + 41] = e[1].numpy().T
+                else:
+                    raise AssertionError(("unexpected draw", e[0], getattr(e[1], "shape", None)))
+                e = next(it, None)
+            return pack
+
+        # the constructor already did reset_idx(all) + compute_observations (reference hector_env.py:50-51),
+        # but before the markers were installed: re-derive the init pack from the raw log by position
+        init_entries = log[creation_draws:]
+        # order: rand(N,10) reset dofs ; 3x rand(N,1) resample ; randn(N,41)
+        ie = [("mark_reset", torch.arange(N)), init_entries[0], ("mark_resample", torch.arange(N))] + init_entries[1:]
+        packs = [build_pack(ie, True)]
+        log.clear()
+
+        out = {k: [] for k in ("actions", "obs41", "priv70", "rew", "reset", "timeout", "root", "q", "qd",
+                               "contact", "bodies", "torques", "commands", "ep_len", "feet_air_time",
+                               "feet_height", "episode_sums", "timeouts_visible")}
+        full = {}
+        init = dict(obs_full=env.obs_buf.numpy().copy(), priv_full=env.privileged_obs_buf.numpy().copy(),
+                    root=gym.root_t.numpy().copy(), q=gym.state.q.copy(), commands=env.commands.numpy().copy(),
+                    shape_friction=np.array(gym.shape_friction), base_mass=np.array(gym.base_mass),
+                    env_origins=env.env_origins.numpy().copy(), env_frictions=env.env_frictions.numpy().copy(),
+                    body_mass=env.body_mass.numpy().copy())
+        if ep_len_init is not None:
+            env.episode_length_buf[:] = torch.as_tensor(ep_len_init, dtype=torch.long)
+        env.common_step_counter = step_counter_init
+        arng = np.random.default_rng(seed + 1000)
+        reward_names = list(env.reward_names)
+        for t in range(n_steps):
+            a = (arng.standard_normal((N, 10)) * action_std).astype(np.float32)
+            obs, priv, rew, reset, extras = env.step(torch.from_numpy(a.copy()))
+            packs.append(build_pack(list(log), False))
+            log.clear()
+            out["actions"].append(a)
+            out["obs41"].append(obs[:, -41:].numpy().copy())
+            out["priv70"].append(priv[:, -70:].numpy().copy())
+            out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8))
+            out["timeout"].append(env.time_out_buf.numpy().astype(np.uint8))
+            tv = extras.get("time_outs")
+            out["timeouts_visible"].append(tv.numpy().astype(np.uint8) if tv is not None else np.zeros(N, np.uint8))
+            s = gym.state
+            out["root"].append(np.concatenate([s.root_pos, s.root_quat, s.root_linvel, s.root_angvel], 1))
+            out["q"].append(s.q.copy())
+            out["qd"].append(s.qd.copy())
+            out["contact"].append(env.contact_forces.numpy().copy())
+            out["bodies"].append(env.rigid_state.numpy()[:, [4, 5, 9, 10]].copy())
+            out["torques"].append(env.torques.numpy().copy())
+            out["commands"].append(env.commands.numpy().copy())
+            out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["feet_air_time"].append(env.feet_air_time.numpy().copy())
+            out["feet_height"].append(env.feet_height.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[k].numpy() for k in reward_names], 0))
+            if (t + 1) in full_stack_steps or t == n_steps - 1:
+                full[t + 1] = (obs.numpy().copy(), priv.numpy().copy())
+        res = {k: np.stack(v) for k, v in out.items()}
+        res["packs"] = np.stack(packs)
+        for k, v in init.items():
+            res["init_" + k] = v
+        res["full_steps"] = np.array(sorted(full))
+        res["full_obs"] = np.stack([full[k][0] for k in sorted(full)])
+        res["full_priv"] = np.stack([full[k][1] for k in sorted(full)])
+        res["reward_names"] = np.array(reward_names)
+        res["reward_scales"] = np.array([env.reward_scales[k] for k in reward_names], np.float64)
+        res["meta"] = np.array([n_envs, n_steps, seed, step_counter_init, int(add_noise)])
+        res["ep_len_init"] = np.zeros(N, np.int64) if ep_len_init is None else np.asarray(ep_len_init, np.int64)
+        res["noise_scale_vec"] = env.noise_scale_vec.numpy().copy()
+        res["torque_limits"] = env.torque_limits.numpy().copy()
+        res["p_gains"] = env.p_gains[0].numpy().copy()
+        res["d_gains"] = env.d_gains[0].numpy().copy()
+        res["default_dof_pos"] = env.default_dof_pos[0].numpy().copy()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **res)
+        print(name, "steps", n_steps, "resets", int(res["reset"].sum()), "timeouts", int(res["timeout"].sum()),
+              "torque checks", gym.torque_checks, "size %.0f KB" % (os.path.getsize(path) / 1024),
+              "mean rew %.4f" % res["rew"].mean())
+    finally:
+        torch.rand, torch.randn_like = real_rand, real_randn_like
+
+
+if __name__ == "__main__":
+    assert loader.available(), "needs /root/reference"
+    N = 8
+    # A: ordinary rollout from the initial reset; falls (contact terminations) happen on their own
+    generate("env_rollout_a", N, 120, seed=5, action_std=1.0)
+    # B: exercises the calendar events: command resampling (ep_len % 800 == 0), time-outs (> 2400),
+    #    the global push (counter % 400 == 0); observation noise off so stacks are exact
+    generate("env_rollout_b", N, 40, seed=7, action_std=0.3,
+             ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390, add_noise=False)

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Model compiler: URDF -> collapsed rigid-body tree constants for the HIP simulator.
+
+Reads the robot description that the reference loads through
+`gym.load_asset(..., collapse_fixed_joints=True)` (reference
+humanoid/envs/base/legged_robot.py:596-615, humanoid/envs/custom/hector_config.py:28-40)
+and emits
+  * isaac_amd/assets/hector_model.json   (data consumed by the numpy oracle and host code)
+  * isaac_amd/csrc/hx_model_data.h       (the same numbers as C constants for the kernels)
+
+This is a build-time tool.  It runs only where the reference checkout is present; its two outputs
+are committed, so nothing at run time (tests on the GPU box, bench.py, smoke) reads /root/reference.
+
+What "collapse" means here (PhysX does the same on import): every link reached through a `fixed`
+joint is merged into its nearest movable ancestor: masses add, centres of mass combine, inertia
+tensors are rotated into the ancestor frame and shifted with the parallel-axis theorem.
+
+Collision geometry: the reference's collision meshes for trunk / hips / thighs are absent from the
+checkout (.MISSING_LARGE_BLOBS); they fall back to the primitive boxes of const.xacro:17-19,128-133.
+The toe meshes foot_L2.stl / foot_R2.stl are present; their axis-aligned bounding box is used
+(PhysX would use the convex hull; for a flat ground both touch at the sole corners).
+"""
+import json
+import os
+import struct
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+REF = os.environ.get("HX_REFERENCE_ROOT", "/root/reference")
+URDF = os.path.join(REF, "resources/robots/hector_v2/xacro/robot.urdf")
+MESH_DIR = os.path.join(REF, "resources/robots/hector_v2/meshes")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def rpy_to_mat(rpy):
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def vec(s, n=3):
+    v = [float(x) for x in s.split()]
+    assert len(v) == n
+    return np.array(v)
+
+
+def parse_origin(el):
+    if el is None:
+        return np.zeros(3), np.eye(3)
+    xyz = vec(el.get("xyz", "0 0 0"))
+    R = rpy_to_mat(vec(el.get("rpy", "0 0 0")))
+    return xyz, R
+
+
+def stl_bbox(path):
+    """Axis-aligned bounding box of a binary or ASCII STL."""
+    with open(path, "rb") as f:
+        data = f.read()
+    pts = []
+    ntri = struct.unpack_from("<I", data, 80)[0] if len(data) >= 84 else 0
+    if len(data) == 84 + 50 * ntri:
+        for i in range(ntri):
+            off = 84 + 50 * i + 12
+            pts.append(struct.unpack_from("<9f", data, off))
+        pts = np.array(pts).reshape(-1, 3)
+    else:
+        for line in data.decode("ascii", "ignore").splitlines():
+            t = line.split()
+            if len(t) == 4 and t[0] == "vertex":
+                pts.append([float(t[1]), float(t[2]), float(t[3])])
+        pts = np.array(pts)
+    return pts.min(0), pts.max(0)
+
+
+def main():
+    root = ET.parse(URDF).getroot()
+    links = {l.get("name"): l for l in root.findall("link")}
+    joints = root.findall("joint")
+    children = {}
+    for j in joints:
+        children.setdefault(j.find("parent").get("link"), []).append(j)
+    child_names = {j.find("child").get("link") for j in joints}
+    root_link = [n for n in links if n not in child_names]
+    assert len(root_link) == 1
+    root_link = root_link[0]
+
+    bodies = []  # collapsed bodies, URDF depth-first order
+
+    def link_inertial(name):
+        el = links[name].find("inertial")
+        if el is None:
+            return 0.0, np.zeros(3), np.zeros((3, 3))
+        m = float(el.find("mass").get("value"))
+        c, R = parse_origin(el.find("origin"))
+        i = el.find("inertia")
+        I = np.array([[float(i.get("ixx")), float(i.get("ixy")), float(i.get("ixz"))],
+                      [float(i.get("ixy")), float(i.get("iyy")), float(i.get("iyz"))],
+                      [float(i.get("ixz")), float(i.get("iyz")), float(i.get("izz"))]])
+        return m, c, R @ I @ R.T
+
+    def collect(name, p, R, acc):
+        """Accumulate link `name` (pose p,R in the collapsed body's frame) and its fixed subtree."""
+        m, c, I = link_inertial(name)
+        if m > 0:
+            acc.append((m, p + R @ c, R @ I @ R.T))
+        movable = []
+        for j in children.get(name, []):
+            jp, jR = parse_origin(j.find("origin"))
+            cp, cR = p + R @ jp, R @ jR
+            if j.get("type") == "fixed":
+                movable += collect(j.find("child").get("link"), cp, cR, acc)
+            else:
+                movable.append((j, cp, cR))
+        return movable
+
+    def build(name, parent_idx, joint, jpos, jrot):
+        acc = []
+        movable = collect(name, np.zeros(3), np.eye(3), acc)
+        m = sum(a[0] for a in acc)
+        com = sum(a[0] * a[1] for a in acc) / m
+        I = np.zeros((3, 3))
+        for mi, ci, Ii in acc:
+            d = ci - com
+            I += Ii + mi * (d @ d * np.eye(3) - np.outer(d, d))
+        body = {"name": name, "parent": parent_idx, "mass": m, "com": com.tolist(),
+                "inertia_com": I.tolist()}
+        if joint is not None:
+            assert np.allclose(jrot, np.eye(3)), "rotated joint frames are not supported"
+            axis = vec(joint.find("axis").get("xyz"))
+            k = int(np.argmax(np.abs(axis)))
+            assert np.allclose(axis, np.eye(3)[k]), "joint axes must be +x/+y/+z"
+            lim = joint.find("limit")
+            body.update({"joint": joint.get("name"), "offset": jpos.tolist(), "axis": k,
+                         "lower": float(lim.get("lower")), "upper": float(lim.get("upper")),
+                         "velocity": float(lim.get("velocity")), "effort": float(lim.get("effort"))})
+        idx = len(bodies)
+        bodies.append(body)
+        for j, cp, cR in movable:
+            build(j.find("child").get("link"), idx, j, cp, cR)
+
+    build(root_link, -1, None, None, None)
+    assert len(bodies) == 11, len(bodies)
+    total = sum(b["mass"] for b in bodies)
+
+    # collision primitives: list of (body index, [points in body frame])
+    def box_corners(center, size):
+        c, h = np.array(center), np.array(size) / 2
+        return [(c + h * np.array([sx, sy, sz])).tolist()
+                for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+
+    name_to_idx = {b["name"]: i for i, b in enumerate(bodies)}
+    contacts = []
+    contacts.append({"body": name_to_idx["base"], "points": box_corners((0, 0, 0), (0.125, 0.19, 0.248)),
+                     "source": "const.xacro:17-19 trunk box (body.stl absent)"})
+    for side, sgn in (("L", 1.0), ("R", -1.0)):
+        contacts.append({"body": name_to_idx[f"{side}_thigh"],
+                         "points": box_corners((0, sgn * 0.0175, -0.09), (0.06, 0.035, 0.18)),
+                         "source": "const.xacro:128-133 thigh box (thigh_combined_*2.stl absent)"})
+        lo, hi = stl_bbox(os.path.join(MESH_DIR, f"foot_{side}2.stl"))
+        ctr, size = (lo + hi) / 2, hi - lo
+        contacts.append({"body": name_to_idx[f"{side}_toe"], "points": box_corners(ctr, size),
+                         "source": f"foot_{side}2.stl axis-aligned bounding box",
+                         "bbox": [lo.tolist(), hi.tolist()]})
+
+    model = {"source": "resources/robots/hector_v2/xacro/robot.urdf (collapse_fixed_joints)",
+             "total_mass": total, "bodies": bodies, "contacts": contacts}
+    os.makedirs(os.path.join(ROOT, "isaac_amd/assets"), exist_ok=True)
+    with open(os.path.join(ROOT, "isaac_amd/assets/hector_model.json"), "w") as f:
+        json.dump(model, f, indent=1)
+
+    # ---- C header ----
+    L = []
+    L.append("// GENERATED by tools/compile_urdf.py from the reference's robot.urdf -- do not edit.")
+    L.append("// 11 collapsed bodies / 10 revolute joints; body i>0 is driven by joint i-1.")
+    L.append("#pragma once")
+    L.append("#define HX_NB 11")
+    L.append("#define HX_NJ 10")
+
+    def arr(name, vals, fmt="%.9gf"):
+        L.append("static const float %s[%d] = {%s};" % (name, len(vals), ", ".join(fmt % v for v in vals)))
+
+    def iarr(name, vals):
+        L.append("static const int %s[%d] = {%s};" % (name, len(vals), ", ".join(str(v) for v in vals)))
+
+    iarr("HXM_PARENT", [b["parent"] for b in bodies])
+    iarr("HXM_AXIS", [b.get("axis", -1) for b in bodies])
+    arr("HXM_MASS", [b["mass"] for b in bodies])
+    arr("HXM_COM", [x for b in bodies for x in b["com"]])
+    arr("HXM_ICOM", [np.array(b["inertia_com"])[i, j] for b in bodies
+                     for (i, j) in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
+    arr("HXM_OFFSET", [x for b in bodies for x in b.get("offset", [0, 0, 0])])
+    arr("HXM_QLO", [b["lower"] for b in bodies[1:]])
+    arr("HXM_QHI", [b["upper"] for b in bodies[1:]])
+    arr("HXM_VMAX", [b["velocity"] for b in bodies[1:]])
+    arr("HXM_EFFORT", [b["effort"] for b in bodies[1:]])
+    iarr("HXM_CONTACT_BODY", [c["body"] for c in contacts])
+    arr("HXM_CONTACT_PTS", [x for c in contacts for p in c["points"] for x in p])
+    L.append("#define HX_NCSHAPE %d" % len(contacts))
+    with open(os.path.join(ROOT, "isaac_amd/csrc/hx_model_data.h"), "w") as f:
+        f.write("\n".join(L) + "\n")
+
+    print("bodies:")
+    for i, b in enumerate(bodies):
+        print(i, b["name"], "parent", b["parent"], "m=%.5f" % b["mass"], "com", np.round(b["com"], 4),
+              b.get("joint"), b.get("offset"), b.get("axis"))
+    print("total mass %.5f" % total)
+    for c in contacts:
+        print("contact", bodies[c["body"]]["name"], c.get("bbox"))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
