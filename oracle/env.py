@@ -1,0 +1,399 @@
+"""ORACLE (test infrastructure, never shipped) -- CPU restatement of the hector env step.
+
+Follows, function by function, the reference's
+  humanoid/envs/custom/hector_env.py   (step :158-169, compute_observations :172-254, _push_robots :53-68,
+                                        _get_gait_phase :75-88, reset_idx :256-261, rewards :277-539)
+  humanoid/envs/base/legged_robot.py   (step :84-108, post_physics_step :118-153, check_termination :155-160,
+                                        reset_idx :162-214, compute_reward :216-234, _resample_commands :321-335,
+                                        _compute_torques :339-355, _reset_dofs :358-372, _reset_root_states :373-396,
+                                        _post_physics_step_callback :303-319)
+in float32 numpy.  The rigid-body step underneath is oracle/physics.py (float64) -- see that file's
+header for why the dynamics are "parity unpinned".
+
+Pinning: tests/test_oracle_env.py replays tests/golden/env_rollout_*.npz, which were produced by the
+reference's own code (tests/golden/make_env_fixtures.py), and requires this restatement to reproduce
+the reference's observations / rewards / resets / time-outs step for step.
+
+Random numbers are injected ("random pack", include/hx_sim.h HX_RP_*): pack[field, env].
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import numpy as np
+
+from . import physics as P
+
+F = np.float32
+RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34)
+RP_SIZE = 75
+
+# constants of HectorCfg (reference hector_config.py); the product reads them from its own config classes
+DEFAULT_Q = np.array([0, 0, .785, -1.578, .785] * 2, F)
+KP = np.array([40, 40, 60, 120, 20] * 2, F)
+KD = np.array([3, 3, 5, 4, 1] * 2, F)
+EFFORT = np.array([33.5, 33.5, 33.5, 67, 33.5] * 2, F)
+TORQUE_LIMIT = (EFFORT * F(0.85)).astype(F)          # legged_robot.py:292, hector_config.py:26
+FEET = [5, 10]
+KNEES = [4, 9]
+TERM = [0, 3, 8]
+REWARD_ORDER = ["action_smoothness", "base_acc", "base_height", "collision", "default_joint_pos", "dof_acc",
+                "dof_vel", "feet_air_time", "feet_clearance", "feet_contact_forces", "feet_contact_number",
+                "feet_distance", "foot_slip", "knee_distance", "orientation", "torques", "tracking_ang_vel",
+                "tracking_lin_vel"]
+REWARD_SCALE = dict(action_smoothness=-0.008, base_acc=0.3, base_height=1.0, collision=-0.5,
+                    default_joint_pos=1.7, dof_acc=-1e-6, dof_vel=-1e-4, feet_air_time=2.0, feet_clearance=1.5,
+                    feet_contact_forces=-0.05, feet_contact_number=2.5, feet_distance=0.2, foot_slip=-0.05,
+                    knee_distance=0.2, orientation=2.0, torques=-1e-5, tracking_ang_vel=1.5, tracking_lin_vel=2.5)
+NOISE_VEC = np.zeros(41, F)
+NOISE_VEC[5:15] = 0.05 * 1.0
+NOISE_VEC[15:25] = 0.5 * 0.05
+NOISE_VEC[35:38] = 0.1 * 1.0
+NOISE_VEC[38:41] = 0.03 * 1.0      # reference writes [38:42] on a 41-vector (hector_env.py:154)
+
+
+def quat_rotate_inverse(q, v):
+    qw = q[:, 3:4]
+    qv = q[:, :3]
+    a = v * (F(2.0) * qw * qw - F(1.0))
+    b = np.cross(qv, v) * qw * F(2.0)
+    c = qv * np.sum(qv * v, 1, keepdims=True) * F(2.0)
+    return (a - b + c).astype(F)
+
+
+def quat_apply(q, v):
+    xyz = q[:, :3]
+    t = np.cross(xyz, v) * F(2)
+    return (v + q[:, 3:4] * t + np.cross(xyz, t)).astype(F)
+
+
+def euler_xyz_wrapped(q):
+    """get_euler_xyz (isaacgym.torch_utils) then the (-pi,pi] wrap of legged_robot.py:50-55."""
+    qx, qy, qz, qw = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    roll = np.arctan2(F(2) * (qw * qx + qy * qz), qw * qw - qx * qx - qy * qy + qz * qz)
+    sinp = F(2) * (qw * qy - qz * qx)
+    pitch = np.where(np.abs(sinp) >= 1, np.sign(sinp) * F(np.pi / 2), np.arcsin(np.clip(sinp, -1, 1)))
+    yaw = np.arctan2(F(2) * (qw * qz + qx * qy), qw * qw + qx * qx - qy * qy - qz * qz)
+    e = np.stack([roll, pitch, yaw], 1).astype(F) % F(2 * np.pi)
+    e = np.where(e > F(np.pi), e - F(2 * np.pi), e)
+    return e.astype(F)
+
+
+def wrap_to_pi(a):
+    a = a % F(2 * np.pi)
+    return (a - F(2 * np.pi) * (a > F(np.pi))).astype(F)
+
+
+def unif(lo, hi, u):
+    return (F(hi - lo) * u + F(lo)).astype(F)
+
+
+class HectorEnvOracle:
+    def __init__(self, n, shape_friction, base_mass, env_origins, init_pack, add_noise=True,
+                 start_xy=None, phys_dtype=np.float64):
+        self.n = n
+        m0 = P.load_model()["bodies"][0]["mass"]
+        self.phys = P.HectorPhysics(n, base_mass_added=np.asarray(base_mass, np.float64) - m0,
+                                    shape_friction=shape_friction, dtype=phys_dtype)
+        self.state = P.State(n, phys_dtype)
+        if start_xy is not None:
+            # actor creation pose (legged_robot.py:653-655): origin + U[-1,1]^2, z of the origin; the first
+            # privileged frames read body poses from this pose because reset does not refresh them
+            self.state.root_pos[:] = np.asarray(start_xy, phys_dtype)
+        self.env_origins = np.asarray(env_origins, F)
+        self.env_frictions = np.asarray(shape_friction, F).reshape(n, 1)
+        self.body_mass = np.asarray(base_mass, F).reshape(n, 1)
+        self.add_noise = add_noise
+        self.dt = 0.01
+        self.max_episode_length = 2400.0
+        z = lambda *s: np.zeros(s, F)
+        self.actions, self.last_actions, self.last_last_actions = z(n, 10), z(n, 10), z(n, 10)
+        self.last_dof_vel, self.last_root_vel = z(n, 10), z(n, 6)
+        self.commands = z(n, 4)
+        self.feet_air_time = z(n, 2)
+        self.last_contacts = np.zeros((n, 2), bool)
+        self.feet_height = z(n, 2)
+        self.last_feet_z = F(0.05) * np.ones((n, 2), F)      # scalar 0.05 in the reference (hector_env.py:48)
+        self.rand_push_force, self.rand_push_torque = z(n, 3), z(n, 3)
+        self.episode_length_buf = np.zeros(n, np.int64)
+        self.common_step_counter = 0
+        self.reset_buf = np.ones(n, bool)
+        self.time_out_buf = np.zeros(n, bool)
+        self.time_outs_visible = np.zeros(n, bool)      # extras["time_outs"], stale unless some env reset
+        self.episode_sums = {k: z(n) for k in REWARD_ORDER}
+        self.rew_buf = z(n)
+        self.torques = z(n, 10)
+        self.obs_hist = z(15, n, 41)       # oldest .. newest
+        self.priv_hist = z(15, n, 70)
+        self.extras_episode = {}
+        # tensors the glue reads from the simulator
+        self._refresh(full=True)
+        self.base_lin_vel = quat_rotate_inverse(self.root[:, 3:7], self.root[:, 7:10])
+        self.base_ang_vel = quat_rotate_inverse(self.root[:, 3:7], self.root[:, 10:13])
+        self.projected_gravity = quat_rotate_inverse(self.root[:, 3:7], np.tile(np.array([[0, 0, -1]], F), (n, 1)))
+        self.base_euler = euler_xyz_wrapped(self.root[:, 3:7])
+        # constructor: reset all, then first observation (hector_env.py:50-51)
+        self.reset_idx(np.arange(n), init_pack)
+        self.compute_observations(init_pack)
+
+    # ---- simulator <-> glue views
+    def _refresh(self, full):
+        s = self.state
+        self.root = np.concatenate([s.root_pos, s.root_quat, s.root_linvel, s.root_angvel], 1).astype(F)
+        self.dof_pos = s.q.astype(F)
+        self.dof_vel = s.qd.astype(F)
+        if full:
+            self.rigid_state = self.phys.body_states(s).astype(F)
+            self.contact_forces = self.phys.contact_force.astype(F)
+
+    def _push_root(self, ids):
+        s = self.state
+        r = self.root.astype(s.q.dtype)
+        s.root_pos[ids], s.root_quat[ids] = r[ids, 0:3], r[ids, 3:7]
+        s.root_linvel[ids], s.root_angvel[ids] = r[ids, 7:10], r[ids, 10:13]
+
+    def _push_dofs(self, ids):
+        self.state.q[ids] = self.dof_pos[ids].astype(self.state.q.dtype)
+        self.state.qd[ids] = self.dof_vel[ids].astype(self.state.q.dtype)
+
+    # ---- gait clock (hector_env.py:70-88)
+    def _phase(self):
+        return (self.episode_length_buf.astype(F) * F(self.dt) / F(0.64)).astype(F)
+
+    def _stance_mask(self):
+        sin_pos = np.sin(F(2 * np.pi) * self._phase()).astype(F)
+        m = np.zeros((self.n, 2), F)
+        m[:, 0] = sin_pos >= 0
+        m[:, 1] = sin_pos < 0
+        m[np.abs(sin_pos) < 0.1] = 1
+        return m
+
+    # ---- step (hector_env.py:158-169 -> legged_robot.py:84-108)
+    def step(self, actions, pack):
+        a = np.clip(np.asarray(actions, F), -100, 100)
+        delay = pack[RP["delay"]][:, None] * F(0.0)
+        a = (F(1) - delay) * a + delay * self.actions
+        a = a + F(0.02) * pack[RP["act_noise"]:RP["act_noise"] + 10].T * a
+        self.actions = np.clip(a, -100, 100).astype(F)
+        target = (self.actions * F(0.25) + DEFAULT_Q).astype(F)
+        for _ in range(10):
+            self.phys.substep(self.state, target.astype(np.float64), KP.astype(np.float64),
+                              KD.astype(np.float64), TORQUE_LIMIT.astype(np.float64))
+        # torque the reference reports = _compute_torques at the start of the last substep
+        self.torques = self.phys.tau.astype(F)
+        self._refresh(full=True)
+        self.post_physics_step(pack)
+        obs = np.clip(self.obs_buf, -100, 100)
+        priv = np.clip(self.priv_buf, -100, 100)
+        return obs, priv, self.rew_buf.copy(), self.reset_buf.copy()
+
+    def post_physics_step(self, pack):
+        n = self.n
+        self.episode_length_buf += 1
+        self.common_step_counter += 1
+        q = self.root[:, 3:7]
+        self.base_lin_vel = quat_rotate_inverse(q, self.root[:, 7:10])
+        self.base_ang_vel = quat_rotate_inverse(q, self.root[:, 10:13])
+        self.projected_gravity = quat_rotate_inverse(q, np.tile(np.array([[0, 0, -1]], F), (n, 1)))
+        self.base_euler = euler_xyz_wrapped(q)
+        # callback (legged_robot.py:303-319)
+        ids = np.nonzero(self.episode_length_buf % 800 == 0)[0]
+        self._resample_commands(ids, pack, "cmd_a")
+        fwd = quat_apply(q, np.tile(np.array([[1, 0, 0]], F), (n, 1)))
+        heading = np.arctan2(fwd[:, 1], fwd[:, 0]).astype(F)
+        self.commands[:, 2] = np.clip(F(0.5) * wrap_to_pi(self.commands[:, 3] - heading), -1, 1)
+        if self.common_step_counter % 400 == 0:
+            self._push_robots(pack)
+        # termination (legged_robot.py:155-160)
+        fn = np.sqrt(np.sum(self.contact_forces[:, TERM] ** 2, -1))
+        self.reset_buf = np.any(fn > 1.0, 1)
+        self.time_out_buf = self.episode_length_buf > self.max_episode_length
+        self.reset_buf |= self.time_out_buf
+        self.compute_reward()
+        ids = np.nonzero(self.reset_buf)[0]
+        self.reset_idx(ids, pack)
+        self.compute_observations(pack)
+        self.last_last_actions = self.last_actions.copy()
+        self.last_actions = self.actions.copy()
+        self.last_dof_vel = self.dof_vel.copy()
+        self.last_root_vel = self.root[:, 7:13].copy()
+
+    def _resample_commands(self, ids, pack, field):
+        if len(ids) == 0:
+            return
+        o = RP[field]
+        self.commands[ids, 0] = unif(-0.6, 0.6, pack[o][ids])
+        self.commands[ids, 1] = unif(-0.3, 0.3, pack[o + 1][ids])
+        self.commands[ids, 3] = unif(-3.14, 3.14, pack[o + 2][ids])
+        nrm = np.sqrt(np.sum(self.commands[ids, :2] ** 2, 1))
+        self.commands[ids, :2] *= (nrm > 0.2)[:, None]
+
+    def _push_robots(self, pack):
+        o = RP["push"]
+        self.rand_push_force[:, :2] = unif(-0.3, 0.3, pack[o:o + 2].T)
+        self.root[:, 7:9] = self.rand_push_force[:, :2]
+        self.rand_push_torque = unif(-0.4, 0.4, pack[o + 2:o + 5].T)
+        self.root[:, 10:13] = self.rand_push_torque
+        self._push_root(np.arange(self.n))
+
+    # ---- reset (legged_robot.py:162-214, hector_env.py:256-261)
+    def reset_idx(self, ids, pack):
+        if len(ids) == 0:
+            return
+        o = RP["reset_q"]
+        self.dof_pos[ids] = DEFAULT_Q + unif(-0.15, 0.15, pack[o:o + 10].T[ids])
+        self.dof_vel[ids] = 0
+        self._push_dofs(ids)
+        base_init = np.array([0, 0, 0.55, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], F)
+        self.root[ids] = base_init
+        self.root[ids, :3] += self.env_origins[ids]
+        self._push_root(ids)
+        self._resample_commands(ids, pack, "cmd_b")
+        self.last_last_actions[ids] = 0
+        self.actions[ids] = 0
+        self.last_actions[ids] = 0
+        self.last_dof_vel[ids] = 0
+        self.feet_air_time[ids] = 0
+        self.episode_length_buf[ids] = 0
+        self.reset_buf[ids] = True
+        self.extras_episode = {}
+        for k in REWARD_ORDER:
+            self.extras_episode["rew_" + k] = np.mean(self.episode_sums[k][ids]) / F(24.0)
+            self.episode_sums[k][ids] = 0
+        self.time_outs_visible = self.time_out_buf.copy()
+        self.base_euler = euler_xyz_wrapped(self.root[:, 3:7])
+        self.projected_gravity[ids] = quat_rotate_inverse(self.root[ids, 3:7], np.tile(np.array([[0, 0, -1]], F), (len(ids), 1)))
+        self.obs_hist[:, ids] = 0
+        self.priv_hist[:, ids] = 0
+
+    # ---- rewards (hector_env.py:277-539), alphabetical evaluation order (helpers.py:47 dir())
+    def compute_reward(self):
+        self.rew_buf = np.zeros(self.n, F)
+        for name in REWARD_ORDER:
+            scale = F(REWARD_SCALE[name] * self.dt)
+            rew = (getattr(self, "_reward_" + name)().astype(F) * scale).astype(F)
+            self.rew_buf = (self.rew_buf + rew).astype(F)
+            self.episode_sums[name] = (self.episode_sums[name] + rew).astype(F)
+        self.rew_buf = np.maximum(self.rew_buf, F(0))
+
+    def _contact(self):
+        return self.contact_forces[:, FEET, 2] > 5.0
+
+    def _reward_action_smoothness(self):
+        t1 = np.sum((self.last_actions - self.actions) ** 2, 1)
+        t2 = np.sum((self.actions + self.last_last_actions - F(2) * self.last_actions) ** 2, 1)
+        t3 = F(0.05) * np.sum(np.abs(self.actions), 1)
+        return t1 + t2 + t3
+
+    def _reward_base_acc(self):
+        d = self.last_root_vel - self.root[:, 7:13]
+        return np.exp(-np.sqrt(np.sum(d * d, 1)) * F(3))
+
+    def _reward_base_height(self):
+        sm = self._stance_mask()
+        mh = np.sum(self.rigid_state[:, FEET, 2] * sm, 1) / np.sum(sm, 1)
+        bh = self.root[:, 2] - (mh - F(0.05))
+        return np.exp(-np.abs(bh - F(0.55)) * F(100))
+
+    def _reward_collision(self):
+        fn = np.sqrt(np.sum(self.contact_forces[:, TERM] ** 2, -1))
+        return np.sum(F(1.0) * (fn > 0.1), 1)
+
+    def _reward_default_joint_pos(self):
+        jd = self.dof_pos - DEFAULT_Q
+        yr = np.sqrt(np.sum(jd[:, 0:2] ** 2, 1)) + np.sqrt(np.sum(jd[:, 5:7] ** 2, 1))
+        yr = np.clip(yr - F(0.1), 0, 50)
+        return np.exp(-yr * F(100)) - F(0.01) * np.sqrt(np.sum(jd * jd, 1))
+
+    def _reward_dof_acc(self):
+        return np.sum(((self.last_dof_vel - self.dof_vel) / F(self.dt)) ** 2, 1)
+
+    def _reward_dof_vel(self):
+        return np.sum(self.dof_vel ** 2, 1)
+
+    def _reward_feet_air_time(self):
+        contact = self._contact()
+        sm = self._stance_mask()
+        filt = contact | (sm > 0) | self.last_contacts
+        self.last_contacts = contact
+        first = (self.feet_air_time > 0) * filt
+        self.feet_air_time = (self.feet_air_time + F(self.dt)).astype(F)
+        air = np.clip(self.feet_air_time, 0, 0.5) * first
+        self.feet_air_time = (self.feet_air_time * ~filt).astype(F)
+        return np.sum(air, 1)
+
+    def _reward_feet_clearance(self):
+        contact = self._contact()
+        feet_z = self.rigid_state[:, FEET, 2] - F(0.05)
+        dz = feet_z - self.last_feet_z
+        self.feet_height = (self.feet_height + dz).astype(F)
+        self.last_feet_z = feet_z
+        swing = F(1) - self._stance_mask()
+        pos = np.abs(self.feet_height - F(0.06)) < 0.01
+        r = np.sum(pos * swing, 1)
+        self.feet_height = (self.feet_height * ~contact).astype(F)
+        return r
+
+    def _reward_feet_contact_forces(self):
+        fn = np.sqrt(np.sum(self.contact_forces[:, FEET] ** 2, -1))
+        return np.sum(np.clip(fn - F(180), 0, 400), 1)
+
+    def _reward_feet_contact_number(self):
+        contact = self._contact()
+        sm = self._stance_mask()
+        return np.mean(np.where(contact == sm, F(1), F(-0.3)), 1)
+
+    def _dist_reward(self, idx, max_df):
+        pos = self.rigid_state[:, idx, :2]
+        d = np.sqrt(np.sum((pos[:, 0] - pos[:, 1]) ** 2, 1))
+        dmin = np.clip(d - F(0.1), -0.5, 0.0)
+        dmax = np.clip(d - F(max_df), 0, 0.5)
+        return (np.exp(-np.abs(dmin) * F(100)) + np.exp(-np.abs(dmax) * F(100))) / F(2)
+
+    def _reward_feet_distance(self):
+        return self._dist_reward(FEET, 0.5)
+
+    def _reward_foot_slip(self):
+        contact = self._contact()
+        sp = np.sqrt(np.sum(self.rigid_state[:, FEET, 7:9] ** 2, 2))
+        return np.sum(np.sqrt(sp) * contact, 1)
+
+    def _reward_knee_distance(self):
+        return self._dist_reward(KNEES, 0.25)
+
+    def _reward_orientation(self):
+        a = np.exp(-np.sum(np.abs(self.base_euler[:, :2]), 1) * F(10))
+        b = np.exp(-np.sqrt(np.sum(self.projected_gravity[:, :2] ** 2, 1)) * F(20))
+        return (a + b) / F(2)
+
+    def _reward_torques(self):
+        return np.sum(self.torques ** 2, 1)
+
+    def _reward_tracking_ang_vel(self):
+        e = (self.commands[:, 2] - self.base_ang_vel[:, 2]) ** 2
+        return np.exp(-e * F(5))
+
+    def _reward_tracking_lin_vel(self):
+        e = np.sum((self.commands[:, :2] - self.base_lin_vel[:, :2]) ** 2, 1)
+        return np.exp(-e * F(5))
+
+    # ---- observations (hector_env.py:172-254)
+    def compute_observations(self, pack):
+        ph = self._phase()
+        sin_pos = np.sin(F(2 * np.pi) * ph).astype(F)[:, None]
+        cos_pos = np.cos(F(2 * np.pi) * ph).astype(F)[:, None]
+        sm = self._stance_mask()
+        cm = self._contact().astype(F)
+        cmd = np.concatenate([sin_pos, cos_pos, self.commands[:, :3] * np.array([2, 2, 1], F)], 1)
+        qd = (self.dof_pos - DEFAULT_Q).astype(F)
+        dq = self.dof_vel * F(0.05)
+        priv = np.concatenate([cmd, qd, dq, self.actions, self.base_lin_vel * F(2), self.base_ang_vel,
+                               self.base_euler, self.rigid_state[:, FEET, :3].reshape(self.n, 6),
+                               self.rigid_state[:, FEET, 7:10].reshape(self.n, 6), self.root[:, :3],
+                               self.rand_push_force[:, :2], self.rand_push_torque, self.env_frictions,
+                               self.body_mass / F(30.0), sm, cm], 1).astype(F)
+        obs = np.concatenate([cmd, qd, dq, self.actions, self.base_ang_vel, self.base_euler], 1).astype(F)
+        if self.add_noise:
+            o = RP["obs_noise"]
+            obs = (obs + pack[o:o + 41].T * NOISE_VEC * F(0.6)).astype(F)
+        self.obs_hist = np.concatenate([self.obs_hist[1:], obs[None]], 0)
+        self.priv_hist = np.concatenate([self.priv_hist[1:], priv[None]], 0)
+        self.obs_buf = self.obs_hist.transpose(1, 0, 2).reshape(self.n, 615)
+        self.priv_buf = self.priv_hist.transpose(1, 0, 2).reshape(self.n, 1050)

@@ -137,6 +137,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         init = dict(obs_full=env.obs_buf.numpy().copy(), priv_full=env.privileged_obs_buf.numpy().copy(),
                     root=gym.root_t.numpy().copy(), q=gym.state.q.copy(), commands=env.commands.numpy().copy(),
                     shape_friction=np.array(gym.shape_friction), base_mass=np.array(gym.base_mass),
+                    start_pos=np.array(gym.start_pos),
                     env_origins=env.env_origins.numpy().copy(), env_frictions=env.env_frictions.numpy().copy(),
                     body_mass=env.body_mass.numpy().copy())
         if ep_len_init is not None:
