@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the hector PPO hot path on MI355X (BASELINE.json metric).
+
+One "step" = one full training iteration of the reference loop (on_policy_runner.py:124-170) on one batch of
+synthetic-but-real work: 60 x {actor/critic forward + sample, env step with 10 physics substeps, transition
+store} for `--envs` (default 4096) robots per GPU, then GAE and the PPO update (2 epochs x 4 minibatches of
+61 440 rows, fwd + loss + bwd + clip + Adam).  Nothing is skipped or cached; weights are random-init
+(no checkpoints exist offline), robots are the real hector model, all inputs already live in HBM.
+
+value = num_steps_per_env * num_envs * n_gpus * K / max-over-ranks(elapsed)      [env-steps / s, whole job]
+       = the reference's own `Perf/total_fps` (on_policy_runner.py:199-203).
+
+Launch: `python bench.py` (1 GPU) or
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+         bench.py --gpus N --steps K --warmup W`   (one rank per GPU, weak scaling: 4096 envs on every rank,
+         one RCCL all-reduce of the flat gradient per optimiser step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_ENV_STEP = 16_772_066            # dense MLP flops, rollout 3 066 338 + update 13 705 728
+PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+GEMM_KERNELS = ["fwd_128x128", "fwd_64x128", "dgrad_128x128", "dgrad_64x128", "wgrad_128x128_splitk"]
+
+
+def cpu_baseline(sample_envs=256, sample_steps=2):
+    """The numpy oracle (oracle/env.py + oracle/physics.py + oracle/ppo.py: the CPU restatement, kind="port")
+    timed on this box's host cores for a bounded sample of the same iteration: `sample_steps` rollout steps of
+    `sample_envs` robots (policy forward, env step with 10 substeps, store), GAE and the 2x4-minibatch update."""
+    from oracle.env import HectorEnvOracle, RP_SIZE
+    from oracle.ppo import ActorCriticOracle, PPOOracle
+    rng = np.random.default_rng(0)
+    n, T = sample_envs, sample_steps
+    pack = lambda: np.concatenate([rng.uniform(size=(34, n)), rng.standard_normal((41, n))]).astype(np.float32)
+    env = HectorEnvOracle(n, rng.uniform(0.1, 1.0, n), 8.15528 + rng.uniform(-2, 4, n), np.zeros((n, 3)), pack())
+    alg = PPOOracle(ActorCriticOracle.default_init(rng), n, T)
+    t0 = time.perf_counter()
+    obs, priv = env.obs_buf, env.priv_buf
+    for _ in range(T):
+        a = alg.act(obs, priv, rng.standard_normal((n, 10)).astype(np.float32))
+        obs, priv, rew, done = env.step(a, pack())
+        alg.process_env_step(rew, done, env.time_outs_visible)
+    alg.compute_returns(priv)
+    alg.update(rng.permutation(n * T))
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": n * T / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{T} rollout steps x {n} envs + GAE + full 2x4-minibatch update, numpy float32/64 oracle, "
+                      f"{dt:.1f} s wall; host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    args = ap.parse_args()
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from isaac_amd import capi
+    from isaac_amd.parallel import init_comm
+    from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO
+    from isaac_amd.envs.hector_env import HectorFreeEnv, class_to_dict
+    from isaac_amd.algo.on_policy_runner import OnPolicyRunner
+    from isaac_amd.utils.helpers import set_seed
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    comm = init_comm()
+    local = comm.local_rank
+    capi.check(capi.lib().hx_set_device(local), "hx_set_device")
+
+    env_cfg, train_cfg = HectorCfg(), HectorCfgPPO()
+    env_cfg.env.num_envs = args.envs
+    env_cfg.seed = set_seed(train_cfg.seed + comm.rank)
+    env = HectorFreeEnv(env_cfg, sim_device=f"cuda:{local}", headless=True)
+    runner = OnPolicyRunner(env, class_to_dict(train_cfg), log_dir=None, device=f"cuda:{local}", comm=comm)
+    T = runner.num_steps_per_env
+
+    runner.learn(args.warmup, init_at_random_ep_len=True)          # untimed warm-up iterations
+    env.sync()
+    comm.barrier()
+    if not args.no_prof:
+        runner.alg.prof_begin()
+    t0 = time.perf_counter()
+    runner.learn(args.steps, init_at_random_ep_len=False)
+    env.sync()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None if args.no_prof else runner.alg.prof_end()
+    elapsed = comm.max_over_ranks(elapsed)
+
+    if comm.rank == 0:
+        env_steps = T * args.envs * world * args.steps
+        value = env_steps / elapsed
+        out = {"metric": "env-steps/sec (whole node), hector 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"hector {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
+                                      "update 2 epochs x 4 minibatches, fp32 HIP sim + MLP actor [512,256,128] / critic [768,256,128]",
+                          "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
+                          "terrain": "plane", "collection_s": runner.last_perf.get("collection_time"),
+                          "learn_s": runner.last_perf.get("learn_time")}}
+        if prof is not None and prof["kernels"]:
+            k = max(prof["kernels"], key=lambda r: r["ms"])
+            achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": k["name"], "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches": k["launches"], "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
+                               "flop_per_launch": k["flops"] / max(1, k["launches"]),
+                               "all_gemm_kernels": prof["kernels"],
+                               "whole_iteration_mfma_frac": value / world * FLOP_PER_ENV_STEP / (PEAK_F32_MFMA_TFLOPS * 1e12)}
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                        # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out))
+    comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+/* hx_ppo.h -- C ABI of the MI355X-native PPO learner (rsl_rl-style ActorCritic + PPO + RolloutStorage).
+ *
+ * Reference interfaces replaced (all under humanoid/algo/ppo/):
+ *   hx_ppo_create            ActorCritic.__init__ (actor_critic.py:37-83) + PPO.__init__ (ppo.py:41-80)
+ *                            + PPO.init_storage / RolloutStorage.__init__ (ppo.py:82-83, rollout_storage.py:52-85)
+ *   hx_ppo_set/get_params_h  ActorCritic.state_dict()/load_state_dict(): tensors in `parameters()` order
+ *                            std, actor.{0,2,4,6}.{weight,bias}, critic.{0,2,4,6}.{weight,bias}
+ *                            (checkpoint format of on_policy_runner.py:278-295)
+ *   hx_ppo_set/get_opt_state_h  torch.optim.Adam state (exp_avg, exp_avg_sq, step) in the same order
+ *   hx_ppo_act               PPO.act (ppo.py:91-101): actor forward, sample, log-prob, critic forward, stash transition
+ *   hx_ppo_process_step      PPO.process_env_step (ppo.py:103-113) + RolloutStorage.add_transitions (:87-100)
+ *   hx_ppo_compute_returns   PPO.compute_returns (ppo.py:115-117) + RolloutStorage.compute_returns GAE loop (:122-132)
+ *   hx_ppo_adv_normalize     RolloutStorage.compute_returns advantage normalisation (:135-136)
+ *   hx_ppo_update            PPO.update (ppo.py:119-184) + RolloutStorage.mini_batch_generator (:146-182)
+ *   hx_ppo_update_begin / _minibatch_backward / _minibatch_step / _update_end
+ *                            the same loop split at the point where data-parallel ranks exchange gradients
+ *                            (absent in the reference): backward fills one flat buffer
+ *                            [grads..., kl_sum, value_loss_sum, surrogate_loss_sum, rows] that the host
+ *                            all-reduces (RCCL) before _minibatch_step applies LR schedule, clip and Adam
+ *   hx_ppo_inference         ActorCritic.act_inference (actor_critic.py:122-124)
+ *
+ * Conventions as in hx_sim.h: DEVICE pointers unless suffixed _h; one stream; 0 = ok; no CPU path.
+ */
+#ifndef HX_PPO_H
+#define HX_PPO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hx_ppo_cfg {
+  int32_t num_envs, num_steps;            /* N, T (num_steps_per_env) */
+  int32_t num_obs, num_priv, num_actions; /* 615, 1050, 10 */
+  int32_t actor_hidden[3], critic_hidden[3];
+  int32_t num_learning_epochs, num_mini_batches;
+  float clip_param, gamma, lam, value_loss_coef, entropy_coef, learning_rate, max_grad_norm;
+  int32_t use_clipped_value_loss;
+  int32_t adaptive_schedule;              /* schedule == 'adaptive' */
+  float desired_kl;
+  float init_noise_std;
+  int32_t obs_ld, priv_ld;                /* row strides of the obs / privileged-obs buffers given to hx_ppo_act */
+} hx_ppo_cfg;
+
+typedef struct hx_ppo hx_ppo;
+
+enum hx_ppo_buffer_id {
+  HX_PPO_BUF_ACTIONS = 0,   /* float [T][N][A] */
+  HX_PPO_BUF_VALUES,        /* float [T][N] */
+  HX_PPO_BUF_LOGP,          /* float [T][N] */
+  HX_PPO_BUF_MU,            /* float [T][N][A] */
+  HX_PPO_BUF_REWARDS,       /* float [T][N] (after the time-out bootstrap) */
+  HX_PPO_BUF_RETURNS,       /* float [T][N] */
+  HX_PPO_BUF_ADVANTAGES,    /* float [T][N] */
+  HX_PPO_BUF_GRADS,         /* float [padded params + 4] flat gradient + statistics buffer */
+  HX_PPO_BUF_PERM           /* int32 [T*N] minibatch permutation in use */
+};
+
+int hx_ppo_create(const hx_ppo_cfg* cfg, void* hip_stream, void* ext_grad_buffer /*nullable*/, hx_ppo** out);
+void hx_ppo_destroy(hx_ppo* p);
+void* hx_ppo_stream(hx_ppo* p);
+int64_t hx_ppo_num_params(hx_ppo* p);                 /* torch element count, 1 517 973 for hector */
+int hx_ppo_set_params_h(hx_ppo* p, const float* flat_h);
+int hx_ppo_get_params_h(hx_ppo* p, float* flat_h);
+int hx_ppo_set_opt_state_h(hx_ppo* p, const float* exp_avg_h, const float* exp_avg_sq_h, int64_t step);
+int hx_ppo_get_opt_state_h(hx_ppo* p, float* exp_avg_h, float* exp_avg_sq_h, int64_t* step);
+
+int hx_ppo_act(hx_ppo* p, const float* obs, const float* priv, const float* eps /*[N][A], nullable*/, float** actions_out);
+int hx_ppo_process_step(hx_ppo* p, const float* rewards, const uint8_t* dones, const uint8_t* time_outs /*nullable*/);
+int hx_ppo_compute_returns(hx_ppo* p, const float* last_priv);
+int hx_ppo_adv_moments(hx_ppo* p, void** moments /* double[3] on device: sum, sum of squares, count */);
+int hx_ppo_adv_normalize(hx_ppo* p);
+
+int hx_ppo_update_begin(hx_ppo* p, const int32_t* perm /*[T*N], nullable: drawn on device*/);
+int hx_ppo_minibatch_backward(hx_ppo* p, int mb_index, void** grad_buffer, int64_t* count);
+int hx_ppo_minibatch_step(hx_ppo* p, float inv_world_size);
+int hx_ppo_update_end(hx_ppo* p, float* stats_h /*[4]: mean value loss, mean surrogate loss, lr, last kl*/);
+int hx_ppo_update(hx_ppo* p, const int32_t* perm, float* stats_h);
+
+int hx_ppo_buffer(hx_ppo* p, int which, void** dptr);
+int hx_ppo_get_lr(hx_ppo* p, float* lr_h);
+int hx_ppo_set_lr(hx_ppo* p, float lr);
+int hx_ppo_inference(hx_ppo* p, const float* obs, int rows, float* actions_out);
+/* HIP-event timing of the dense kernels on the learner's stream: which=1 starts/clears, which=0 stops and
+ * returns accumulated {milliseconds, launches, flops} */
+int hx_ppo_prof(hx_ppo* p, int which, double* out_h /*[3]*/, void* reserved);
+/* unit-test hook: one GEMM of the given mode (0 fwd bias+ELU, 1 dgrad * elu', 2 wgrad split-K) */
+int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     const float* bias, float* C, int ldc, const float* H, void* hip_stream);
+
+/* device memory helpers for hosts without a tensor library */
+int hx_malloc(size_t bytes, void** out);
+int hx_free(void* ptr);
+int hx_memcpy_h2d(void* dst, const void* src_h, size_t bytes, void* hip_stream);
+int hx_memcpy_d2h(void* dst_h, const void* src, size_t bytes, void* hip_stream);
+int hx_memcpy_d2d(void* dst, const void* src, size_t bytes, void* hip_stream);
+int hx_device_count(void);
+int hx_set_device(int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

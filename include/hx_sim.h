@@ -1,0 +1,156 @@
+/* hx_sim.h -- C ABI of the MI355X-native hector environment step.
+ *
+ * The reference has no FFI for this path: its seams are two Python protocols.  This
+ * header is the C boundary a maintainer binds instead of them.  Each entry point names the reference
+ * interface it replaces:
+ *
+ *   hx_sim_create        LeggedRobot.__init__ / _create_envs / _init_buffers
+ *                        (humanoid/envs/base/legged_robot.py:58-82,433-515,587-681) and the
+ *                        gym.create_sim / load_asset / create_actor / prepare_sim calls underneath
+ *   hx_sim_reset_all     HectorFreeEnv.__init__ tail: reset_idx(all) + compute_observations()
+ *                        (humanoid/envs/custom/hector_env.py:50-51)
+ *   hx_sim_step          HectorFreeEnv.step -> LeggedRobot.step -> post_physics_step
+ *                        (hector_env.py:158-169, legged_robot.py:84-153), including the 10 x
+ *                        {_compute_torques, gym.set_dof_actuation_force_tensor, gym.simulate,
+ *                        gym.refresh_dof_state_tensor} substeps (legged_robot.py:93-100)
+ *   hx_sim_buffer        VecEnv attributes obs_buf / privileged_obs_buf / rew_buf / reset_buf /
+ *                        episode_length_buf / extras["time_outs"] (humanoid/algo/vec_env.py:37-61)
+ *   hx_sim_get_state /   gym.acquire_actor_root_state_tensor / acquire_dof_state_tensor and
+ *   hx_sim_set_state     gym.set_actor_root_state_tensor[_indexed] / set_dof_state_tensor_indexed
+ *                        (legged_robot.py:437-456,370,394)
+ *   hx_sim_set_episode_length   `env.episode_length_buf = randint_like(...)`
+ *                        (humanoid/algo/ppo/on_policy_runner.py:103-106)
+ *   hx_sim_episode_stats extras["episode"]["rew_*"] (legged_robot.py:198-201)
+ *
+ * Conventions: single-threaded caller; every call enqueues on the one hipStream_t given at creation
+ * and returns without synchronising unless it copies to host; pointers are DEVICE pointers unless
+ * the name ends in _h; the library owns all device buffers.  Return value 0 = ok, negative = error,
+ * message from hx_last_error().  No CPU fallback exists: without a HIP device every call fails.
+ */
+#ifndef HX_SIM_H
+#define HX_SIM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HX_NUM_DOF 10
+#define HX_NUM_BODIES 11
+#define HX_OBS_FRAME 41        /* num_single_obs, hector_config.py:12 */
+#define HX_PRIV_FRAME 70       /* single_num_privileged_obs, hector_config.py:14 */
+#define HX_FRAME_STACK 15      /* frame_stack = c_frame_stack, hector_config.py:10-11 */
+#define HX_NUM_OBS 615
+#define HX_NUM_PRIV 1050
+#define HX_OBS_LD 616          /* row stride of the obs buffer (16-byte aligned rows) */
+#define HX_PRIV_LD 1052        /* row stride of the privileged obs buffer */
+#define HX_NUM_REWARDS 22      /* every _reward_* of hector_env.py, alphabetical (helpers.py:47 dir() order) */
+
+/* Random pack: one step's injected random numbers, laid out [HX_RP_SIZE][num_envs] (field-major).
+ * Uniform fields hold torch.rand-style values in [0,1); normal fields hold N(0,1) draws.
+ * Passing NULL makes the kernel draw the same fields from Philox4x32-10 keyed by (seed, env, step). */
+#define HX_RP_DELAY 0          /* hector_env.py:166    U   x1  */
+#define HX_RP_ACT_NOISE 1      /* hector_env.py:168    N   x10 */
+#define HX_RP_CMD_A 11         /* legged_robot.py:308-309 resample at ep_len % 800 == 0   U x3 (x, y, heading) */
+#define HX_RP_PUSH 14          /* hector_env.py:58-63  U   x5 (lin xy, ang xyz) */
+#define HX_RP_RESET_Q 19       /* legged_robot.py:366  U   x10 */
+#define HX_RP_RESET_XY 29      /* legged_robot.py:384  U   x2 (custom origins only) */
+#define HX_RP_CMD_B 31         /* legged_robot.py:186 resample inside reset_idx        U x3 */
+#define HX_RP_OBS_NOISE 34     /* hector_env.py:243    N   x41 */
+#define HX_RP_SIZE 75
+
+/* indices into hx_sim_cfg.reward_scale (already multiplied by dt, legged_robot.py:527) */
+enum {
+  HX_R_ACTION_SMOOTHNESS = 0, HX_R_BASE_ACC, HX_R_BASE_HEIGHT, HX_R_COLLISION, HX_R_DEFAULT_JOINT_POS,
+  HX_R_DOF_ACC, HX_R_DOF_VEL, HX_R_FEET_AIR_TIME, HX_R_FEET_CLEARANCE, HX_R_FEET_CONTACT_FORCES,
+  HX_R_FEET_CONTACT_NUMBER, HX_R_FEET_DISTANCE, HX_R_FOOT_SLIP, HX_R_JOINT_POS, HX_R_KNEE_DISTANCE,
+  HX_R_LOW_SPEED, HX_R_ORIENTATION, HX_R_TORQUES, HX_R_TRACK_VEL_HARD, HX_R_TRACKING_ANG_VEL,
+  HX_R_TRACKING_LIN_VEL, HX_R_VEL_MISMATCH_EXP
+};
+
+typedef struct hx_sim_cfg {
+  int32_t num_envs;
+  int32_t decimation;            /* control.decimation = 10 */
+  float sim_dt;                  /* sim.dt = 1e-3 */
+  float gravity_z;               /* sim.gravity[2] = -9.81 */
+  /* control */
+  float action_scale;            /* 0.25 */
+  float clip_actions;            /* 100 */
+  float clip_observations;       /* 100 */
+  float default_dof_pos[HX_NUM_DOF];
+  float p_gains[HX_NUM_DOF];
+  float d_gains[HX_NUM_DOF];
+  float torque_limits[HX_NUM_DOF];   /* effort * safety.torque_limit */
+  /* domain randomisation / noise */
+  float action_delay;            /* 0.0 */
+  float action_noise;            /* 0.02 */
+  int32_t add_noise;
+  float noise_level;             /* 0.6 */
+  float noise_scale_vec[HX_OBS_FRAME];
+  int32_t push_robots;
+  int32_t push_interval;         /* ceil(push_interval_s / dt) = 400 */
+  float max_push_vel_xy;         /* 0.3 */
+  float max_push_ang_vel;        /* 0.4 */
+  /* commands */
+  int32_t resample_interval;     /* int(resampling_time / dt) = 800 */
+  int32_t heading_command;
+  float cmd_range[4][2];         /* lin_vel_x, lin_vel_y, ang_vel_yaw, heading */
+  /* observation scales */
+  float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_quat;
+  /* episode */
+  float max_episode_length;      /* ceil(episode_length_s / dt) = 2400 */
+  float max_episode_length_s;    /* 24 */
+  float env_dt;                  /* decimation * sim_dt = 0.01 */
+  float base_init_state[13];     /* pos, quat xyzw, lin vel, ang vel */
+  int32_t custom_origins;        /* 1 for heightfield/trimesh (adds U[-1,1] xy on reset) */
+  /* rewards */
+  float reward_scale[HX_NUM_REWARDS];
+  int32_t only_positive_rewards;
+  float base_height_target, min_dist, max_dist, target_joint_pos_scale, target_feet_height;
+  float cycle_time, tracking_sigma, max_contact_force;
+  /* physics model (DESIGN.md "Physics model"; no counterpart in the reference, PhysX is opaque) */
+  float contact_kn, contact_dn, friction_veps, limit_k, limit_d, terrain_mu;
+} hx_sim_cfg;
+
+typedef struct hx_sim hx_sim;
+
+enum hx_sim_buffer_id {
+  HX_BUF_OBS = 0,          /* float [N][HX_OBS_LD], clipped, current step */
+  HX_BUF_PRIV,             /* float [N][HX_PRIV_LD] */
+  HX_BUF_REW,              /* float [N] */
+  HX_BUF_RESET,            /* uint8 [N]  reset_buf */
+  HX_BUF_TIMEOUT,          /* uint8 [N]  time_out_buf of this step */
+  HX_BUF_TIMEOUT_VISIBLE,  /* uint8 [N]  extras["time_outs"]: refreshed only on steps where some env reset */
+  HX_BUF_EP_LEN,           /* int32 [N]  episode_length_buf */
+  HX_BUF_COMMANDS,         /* float [4][N] */
+  HX_BUF_TORQUES,          /* float [10][N] torques of the last substep */
+  HX_BUF_CONTACT,          /* float [11*3][N] net contact force per body, world frame */
+  HX_BUF_BODY_STATE,       /* float [4*13][N] rigid_body_state of L_calf, L_toe, R_calf, R_toe */
+  HX_BUF_EPISODE_SUMS,     /* float [HX_NUM_REWARDS][N] */
+  HX_BUF_FEET_AIR_TIME,    /* float [2][N] */
+  HX_BUF_FEET_HEIGHT,      /* float [2][N] */
+  HX_BUF_NUM_RESET         /* int32 [1] number of envs that reset in the last step */
+};
+
+const char* hx_last_error(void);
+int hx_version(void);
+
+int hx_sim_create(const hx_sim_cfg* cfg, const float* shape_friction_h, const float* base_mass_h,
+                  const float* env_origins_h /*[N][3]*/, const float* start_pos_h /*[N][3]*/,
+                  uint64_t seed, void* hip_stream /*NULL: library creates one*/, hx_sim** out);
+void hx_sim_destroy(hx_sim* s);
+int hx_sim_reset_all(hx_sim* s, const float* pack /*nullable*/);
+int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const float* pack /*nullable*/);
+int hx_sim_buffer(hx_sim* s, int which, void** dptr);
+int hx_sim_get_state(hx_sim* s, float* root13_h /*[N][13]*/, float* q_h /*[N][10]*/, float* qd_h /*[N][10]*/);
+int hx_sim_set_state(hx_sim* s, const float* root13_h, const float* q_h, const float* qd_h);
+int hx_sim_set_episode_length(hx_sim* s, const int32_t* ep_len_h);
+int hx_sim_set_step_counter(hx_sim* s, int64_t common_step_counter);
+/* mean over the envs that reset since the last call of episode_sum / max_episode_length_s, and the count */
+int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS]*/, int32_t* count_h);
+void* hx_sim_stream(hx_sim* s);
+int hx_sync(void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

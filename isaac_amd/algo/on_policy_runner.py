@@ -1,0 +1,176 @@
+"""OnPolicyRunner: the reference's training loop over the HIP env + learner.
+
+Surface follows humanoid/algo/ppo/on_policy_runner.py: __init__(env, train_cfg, log_dir, device) :47-91,
+learn(num_learning_iterations, init_at_random_ep_len) :93-177, log :179-276, save :278-287, load :289-295,
+get_inference_policy :297-301; attributes .alg, .current_learning_iteration, .tot_timesteps.
+
+Differences that are deliberate:
+  * tensorboard / wandb sinks (absent here, and wandb.init is a network call) are replaced by a JSONL file
+    with the SAME scalar names (Episode/rew_*, Loss/*, Policy/mean_noise_std, Perf/*, Train/*), so curves can
+    be overlaid on a reference run's export.
+  * rewards/dones never leave the device inside the rollout; episode statistics are accumulated by the env
+    kernel and read once per iteration, so the loop has no per-step host synchronisation.
+  * with a `comm` (isaac_amd.parallel) the gradient of every optimiser step is all-reduced over RCCL.
+Checkpoints keep the reference's torch.save dict layout (model_state_dict / optimizer_state_dict / iter / infos).
+"""
+import json
+import os
+import statistics
+import time
+from collections import deque
+from datetime import datetime
+
+import numpy as np
+
+from .. import capi
+from .ppo import PPO, ActorCritic
+
+_CLASSES = {"ActorCritic": ActorCritic, "PPO": PPO}
+
+
+class OnPolicyRunner:
+    def __init__(self, env, train_cfg, log_dir=None, device="cuda:0", comm=None):
+        self.cfg = train_cfg["runner"]
+        self.alg_cfg = train_cfg["algorithm"]
+        self.policy_cfg = train_cfg["policy"]
+        self.all_cfg = train_cfg
+        self.wandb_run_name = (datetime.now().strftime("%b%d_%H-%M-%S") + "_" + train_cfg["runner"]["experiment_name"]
+                               + "_" + train_cfg["runner"]["run_name"])
+        self.device = device
+        self.env = env
+        self.comm = comm
+        num_critic_obs = env.num_privileged_obs if env.num_privileged_obs is not None else env.num_obs
+        actor_critic = _CLASSES[self.cfg["policy_class_name"]](env.num_obs, num_critic_obs, env.num_actions, **self.policy_cfg)
+        if comm is not None and comm.world_size > 1:
+            actor_critic.load_state_dict(comm.broadcast_state(actor_critic.state_dict()))
+        self.alg = _CLASSES[self.cfg["algorithm_class_name"]](actor_critic, device=device, stream=getattr(env, "stream", None),
+                                                              comm=comm, **self.alg_cfg)
+        self.num_steps_per_env = self.cfg["num_steps_per_env"]
+        self.save_interval = self.cfg["save_interval"]
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions],
+                              obs_ld=capi.OBS_LD, priv_ld=capi.PRIV_LD)
+        self.log_dir = log_dir
+        self.writer = None
+        self.tot_timesteps = 0
+        self.tot_time = 0
+        self.current_learning_iteration = 0
+        self.last_perf = {}
+        _, _ = self.env.reset()
+
+    # ------------------------------------------------------------------ training loop
+    def learn(self, num_learning_iterations, init_at_random_ep_len=False):
+        if self.log_dir is not None and self.writer is None:
+            os.makedirs(self.log_dir, exist_ok=True)
+            self.writer = open(os.path.join(self.log_dir, "scalars.jsonl"), "a")
+        env, alg = self.env, self.alg
+        if init_at_random_ep_len:
+            try:
+                import torch
+                r = torch.randint(0, int(env.max_episode_length), (env.num_envs,)).numpy()
+            except ImportError:                          # pragma: no cover
+                r = np.random.randint(0, int(env.max_episode_length), env.num_envs)
+            env.episode_length_buf = r.astype(np.int32)
+        obs = env.get_observations()
+        privileged_obs = env.get_privileged_observations()
+        critic_obs = privileged_obs if privileged_obs is not None else obs
+        alg.actor_critic.train()
+        rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            start = time.time()
+            for _ in range(self.num_steps_per_env):
+                actions = alg.act(obs, critic_obs)
+                obs, privileged_obs, rewards, dones, infos = env.step(actions)
+                critic_obs = privileged_obs if privileged_obs is not None else obs
+                alg.process_env_step(rewards, dones, infos)
+            env.sync()
+            stop = time.time()
+            collection_time = stop - start
+            start = stop
+            alg.compute_returns(critic_obs)
+            mean_value_loss, mean_surrogate_loss = alg.update()      # synchronises once (loss scalars)
+            stop = time.time()
+            learn_time = stop - start
+            self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
+                                  fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
+            if self.log_dir is not None:
+                ep_info, n_ep = env.episode_stats()
+                self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,
+                              mean_value_loss=mean_value_loss, mean_surrogate_loss=mean_surrogate_loss,
+                              ep_info=ep_info, n_ep=n_ep, rewbuffer=rewbuffer, lenbuffer=lenbuffer))
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None:
+            self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
+
+    def log(self, locs, width=80, pad=35):
+        world = 1 if self.comm is None else self.comm.world_size
+        self.tot_timesteps += self.num_steps_per_env * self.env.num_envs * world
+        self.tot_time += locs["collection_time"] + locs["learn_time"]
+        iteration_time = locs["collection_time"] + locs["learn_time"]
+        fps = int(self.num_steps_per_env * self.env.num_envs * world / iteration_time)
+        scalars = {}
+        for k, v in locs["ep_info"].items():
+            scalars["Episode/" + k] = v
+        mean_std = float(np.mean(self.alg.actor_critic.std))
+        scalars.update({"Loss/value_function": locs["mean_value_loss"], "Loss/surrogate": locs["mean_surrogate_loss"],
+                        "Loss/learning_rate": self.alg.learning_rate, "Policy/mean_noise_std": mean_std,
+                        "Perf/total_fps": fps, "Perf/collection time": locs["collection_time"],
+                        "Perf/learning_time": locs["learn_time"]})
+        if self.writer is not None and (self.comm is None or self.comm.rank == 0):
+            self.writer.write(json.dumps({"it": locs["it"], "tot_timesteps": self.tot_timesteps, "tot_time": self.tot_time, **scalars}) + "\n")
+            self.writer.flush()
+        if self.comm is not None and self.comm.rank != 0:
+            return
+        head = f" \033[1m Learning iteration {locs['it']}/{self.current_learning_iteration + locs['tot_iter'] - self.current_learning_iteration} \033[0m "
+        lines = [f"{'#' * width}", f"{head.center(width, ' ')}", "",
+                 f"{'Computation:':>{pad}} {fps:.0f} steps/s (collection: {locs['collection_time']:.3f}s, learning {locs['learn_time']:.3f}s)",
+                 f"{'Value function loss:':>{pad}} {locs['mean_value_loss']:.4f}",
+                 f"{'Surrogate loss:':>{pad}} {locs['mean_surrogate_loss']:.4f}",
+                 f"{'Mean action noise std:':>{pad}} {mean_std:.2f}"]
+        for k, v in locs["ep_info"].items():
+            lines.append(f"{'Mean episode ' + k + ':':>{pad}} {v:.4f}")
+        lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}",
+                  f"{'Iteration time:':>{pad}} {iteration_time:.2f}s", f"{'Total time:':>{pad}} {self.tot_time:.2f}s"]
+        print("\n".join(lines))
+
+    # ------------------------------------------------------------------ checkpoints (torch is used ONLY here)
+    def _opt_state_dict(self):
+        m, v, step = self.alg.optimizer_state()
+        shapes = self.alg.actor_critic.tensor_shapes()
+        state, o = {}, 0
+        import torch
+        for i, (name, shape) in enumerate(shapes.items()):
+            n = int(np.prod(shape))
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": torch.from_numpy(m[o:o + n].reshape(shape).copy()),
+                        "exp_avg_sq": torch.from_numpy(v[o:o + n].reshape(shape).copy())}
+            o += n
+        groups = [{"lr": self.alg.learning_rate, "betas": (0.9, 0.999), "eps": 1e-08, "weight_decay": 0, "amsgrad": False,
+                   "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                   "params": list(range(len(shapes)))}]
+        return {"state": state, "param_groups": groups}
+
+    def save(self, path, infos=None):
+        import torch
+        sd = {k: torch.from_numpy(v) for k, v in self.alg.actor_critic.state_dict().items()}
+        torch.save({"model_state_dict": sd, "optimizer_state_dict": self._opt_state_dict(),
+                    "iter": self.current_learning_iteration, "infos": infos}, path)
+
+    def load(self, path, load_optimizer=True):
+        import torch
+        loaded = torch.load(path, map_location="cpu", weights_only=False)
+        self.alg.actor_critic.load_state_dict(loaded["model_state_dict"])
+        if load_optimizer and loaded.get("optimizer_state_dict"):
+            st = loaded["optimizer_state_dict"]["state"]
+            if st:
+                m = np.concatenate([st[i]["exp_avg"].numpy().reshape(-1) for i in sorted(st)])
+                v = np.concatenate([st[i]["exp_avg_sq"].numpy().reshape(-1) for i in sorted(st)])
+                self.alg.load_optimizer_state(m, v, int(float(st[0]["step"])))
+            self.alg.learning_rate = loaded["optimizer_state_dict"]["param_groups"][0]["lr"]
+        self.current_learning_iteration = loaded["iter"]
+        return loaded["infos"]
+
+    def get_inference_policy(self, device=None):
+        self.alg.actor_critic.eval()
+        return self.alg.actor_critic.act_inference

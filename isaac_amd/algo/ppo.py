@@ -1,0 +1,314 @@
+"""ActorCritic / PPO host objects with the reference's (rsl_rl-style) surface, served by libhx.so.
+
+  ActorCritic   humanoid/algo/ppo/actor_critic.py:36-128   (state_dict keys: std, actor.{0,2,4,6}.*, critic.*)
+  PPO           humanoid/algo/ppo/ppo.py:38-184            (init_storage / act / process_env_step /
+                                                            compute_returns / update, .learning_rate, .storage)
+The two reference objects share one device object here (parameters, rollout storage and workspace live in
+one hx_ppo handle), because the learner's kernels need them resident together; `ActorCritic` only records
+the architecture until `PPO.init_storage` binds it.  No arithmetic happens in this file.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+from .. import capi
+from ..devarray import DeviceArray, device_pointer
+
+
+class ActorCritic:
+    is_recurrent = False
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256),
+                 critic_hidden_dims=(256, 256, 256), init_noise_std=1.0, activation="elu", **kwargs):
+        if kwargs:
+            print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs)))
+        if len(actor_hidden_dims) != 3 or len(critic_hidden_dims) != 3:
+            raise ValueError("the HIP learner is built for three hidden layers per network (hector: [512,256,128] / [768,256,128])")
+        self.num_actor_obs, self.num_critic_obs, self.num_actions = num_actor_obs, num_critic_obs, num_actions
+        self.actor_hidden_dims, self.critic_hidden_dims = list(actor_hidden_dims), list(critic_hidden_dims)
+        self.init_noise_std = init_noise_std
+        self._alg = None
+        self._pending_state = self._default_init()
+
+    # ---- parameter bookkeeping (torch `parameters()` order)
+    def tensor_shapes(self):
+        shapes = OrderedDict(std=(self.num_actions,))
+        for name, dims in (("actor", [self.num_actor_obs, *self.actor_hidden_dims, self.num_actions]),
+                           ("critic", [self.num_critic_obs, *self.critic_hidden_dims, 1])):
+            for i in range(4):
+                shapes[f"{name}.{2 * i}.weight"] = (dims[i + 1], dims[i])
+                shapes[f"{name}.{2 * i}.bias"] = (dims[i + 1],)
+        return shapes
+
+    def num_params(self):
+        return int(sum(int(np.prod(s)) for s in self.tensor_shapes().values()))
+
+    def _default_init(self):
+        """nn.Linear default init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias
+        (reference uses the torch defaults: `init_weights` is unused, actor_critic.py:86-90).
+        Drawn from torch's generator when available so `torch.manual_seed(s)` gives the reference's stream order;
+        the values differ from torch's own kaiming call sequence only in draw order."""
+        out = OrderedDict()
+        try:
+            import torch
+            uni = lambda shape, k: ((torch.rand(*shape) * 2 - 1) * k).numpy().astype(np.float32)
+        except ImportError:                              # pragma: no cover
+            uni = lambda shape, k: np.random.uniform(-k, k, shape).astype(np.float32)
+        for name, shape in self.tensor_shapes().items():
+            if name == "std":
+                out[name] = np.full(shape, self.init_noise_std, np.float32)
+            else:
+                fan_in = shape[1] if len(shape) == 2 else self._fan_in_of_bias(name)
+                out[name] = uni(shape, 1.0 / np.sqrt(fan_in))
+        return out
+
+    def _fan_in_of_bias(self, name):
+        return self.tensor_shapes()[name.replace("bias", "weight")][1]
+
+    def _flatten(self, sd):
+        parts = []
+        for name, shape in self.tensor_shapes().items():
+            t = sd[name]
+            t = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"state_dict[{name!r}] has shape {tuple(t.shape)}, expected {shape}")
+            parts.append(np.ascontiguousarray(t, np.float32).reshape(-1))
+        return np.concatenate(parts)
+
+    def _unflatten(self, flat):
+        out, o = OrderedDict(), 0
+        for name, shape in self.tensor_shapes().items():
+            n = int(np.prod(shape))
+            out[name] = flat[o:o + n].reshape(shape).copy()
+            o += n
+        return out
+
+    def state_dict(self):
+        if self._alg is None:
+            return OrderedDict((k, v.copy()) for k, v in self._pending_state.items())
+        flat = np.empty(self.num_params(), np.float32)
+        capi.check(capi.lib().hx_ppo_get_params_h(self._alg._h, capi.ptr(flat)), "get_params")
+        return self._unflatten(flat)
+
+    def load_state_dict(self, sd, strict=True):
+        if self._alg is None:
+            self._pending_state = self._unflatten(self._flatten(sd))
+        else:
+            flat = self._flatten(sd)
+            capi.check(capi.lib().hx_ppo_set_params_h(self._alg._h, capi.ptr(flat)), "set_params")
+
+    @property
+    def std(self):
+        return self.state_dict()["std"]
+
+    # ---- modes / no-ops kept for API compatibility
+    def train(self):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def reset(self, dones=None):
+        pass
+
+    def act_inference(self, observations):
+        if self._alg is None:
+            raise RuntimeError("ActorCritic is not bound to a learner yet (PPO.init_storage)")
+        return self._alg.inference(observations)
+
+
+class PPO:
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
+                 use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cuda:0", stream=None,
+                 comm=None):
+        self.device = device
+        self.actor_critic = actor_critic
+        self.desired_kl, self.schedule = desired_kl, schedule
+        self._lr0 = learning_rate
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.gamma, self.lam, self.max_grad_norm = gamma, lam, max_grad_norm
+        self.use_clipped_value_loss = use_clipped_value_loss
+        self.storage = None
+        self._h = None
+        self._stream = stream
+        self.comm = comm                  # isaac_amd.parallel.Comm or None (single process)
+        self._L = capi.lib()
+        self._keep = []
+
+    # ------------------------------------------------------------------ construction
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape,
+                     obs_ld=None, priv_ld=None):
+        ac = self.actor_critic
+        c = capi.PpoCfg()
+        c.num_envs, c.num_steps = num_envs, num_transitions_per_env
+        c.num_obs, c.num_priv, c.num_actions = actor_obs_shape[0], critic_obs_shape[0], action_shape[0]
+        for i in range(3):
+            c.actor_hidden[i], c.critic_hidden[i] = ac.actor_hidden_dims[i], ac.critic_hidden_dims[i]
+        c.num_learning_epochs, c.num_mini_batches = self.num_learning_epochs, self.num_mini_batches
+        c.clip_param, c.gamma, c.lam = self.clip_param, self.gamma, self.lam
+        c.value_loss_coef, c.entropy_coef = self.value_loss_coef, self.entropy_coef
+        c.learning_rate, c.max_grad_norm = self._lr0, self.max_grad_norm
+        c.use_clipped_value_loss = int(self.use_clipped_value_loss)
+        c.adaptive_schedule = int(self.desired_kl is not None and self.schedule == "adaptive")
+        c.desired_kl = self.desired_kl if self.desired_kl is not None else 0.0
+        c.init_noise_std = ac.init_noise_std
+        c.obs_ld = obs_ld if obs_ld is not None else (c.num_obs + 3) // 4 * 4
+        c.priv_ld = priv_ld if priv_ld is not None else (c.num_priv + 3) // 4 * 4
+        if (num_envs * num_transitions_per_env) % self.num_mini_batches:
+            raise ValueError("num_envs * num_steps_per_env must be divisible by num_mini_batches")
+        self._cfg = c
+        ext = None
+        if self.comm is not None and self.comm.world_size > 1:
+            ext = self.comm.alloc_grad_buffer(self._padded_count(c) + 4)
+        h = capi.C.c_void_p()
+        capi.check(self._L.hx_ppo_create(capi.C.byref(c), self._stream, ext, capi.C.byref(h)), "hx_ppo_create")
+        self._h = h
+        self._stream = self._L.hx_ppo_stream(h)
+        self.N, self.T, self.A = num_envs, num_transitions_per_env, action_shape[0]
+        self.obs_ld, self.priv_ld = c.obs_ld, c.priv_ld
+        ac._alg = self
+        ac.load_state_dict(ac._pending_state)
+        self.storage = self          # `alg.storage.clear()` style calls land here
+        self.step = 0
+
+    @staticmethod
+    def _padded_count(c):
+        r4 = lambda x: (x + 3) // 4 * 4
+        tot = 0
+        for dims in ([c.num_obs, *c.actor_hidden, c.num_actions], [c.num_priv, *c.critic_hidden, 1]):
+            for i in range(4):
+                tot = r4(tot + dims[i + 1] * r4(dims[i]))
+                tot = r4(tot + dims[i + 1])
+        return tot + r4(c.num_actions)
+
+    # ------------------------------------------------------------------ rollout side
+    def _padded_ptr(self, x, width, ld):
+        """Device pointer of an [N, ld]-strided buffer.  Host arrays of logical width are padded and uploaded."""
+        if isinstance(x, DeviceArray) or hasattr(x, "__cuda_array_interface__"):
+            p, keep = device_pointer(x)
+            return p, keep
+        arr = x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+        arr = np.asarray(arr, np.float32)
+        if arr.shape[1] != ld:
+            pad = np.zeros((arr.shape[0], ld), np.float32)
+            pad[:, :arr.shape[1]] = arr
+            arr = pad
+        return device_pointer(arr)
+
+    def act(self, obs, critic_obs, eps=None):
+        po, k1 = self._padded_ptr(obs, self._cfg.num_obs, self.obs_ld)
+        pp, k2 = self._padded_ptr(critic_obs, self._cfg.num_priv, self.priv_ld)
+        pe, k3 = (None, None) if eps is None else device_pointer(np.ascontiguousarray(eps, np.float32))
+        out = capi.C.c_void_p()
+        capi.check(self._L.hx_ppo_act(self._h, po, pp, pe, capi.C.byref(out)), "hx_ppo_act")
+        self._keep = [k1, k2, k3]
+        return DeviceArray(out.value, (self.N, self.A), np.float32, None, self.stream)
+
+    def process_env_step(self, rewards, dones, infos):
+        pr, k1 = device_pointer(rewards)
+        pd, k2 = device_pointer(dones if not isinstance(dones, np.ndarray) else dones.astype(np.uint8))
+        pt, k3 = (None, None)
+        if "time_outs" in infos:
+            t = infos["time_outs"]
+            pt, k3 = device_pointer(t if not isinstance(t, np.ndarray) else t.astype(np.uint8))
+        capi.check(self._L.hx_ppo_process_step(self._h, pr, pd, pt), "hx_ppo_process_step")
+        self._keep += [k1, k2, k3]
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        pp, k = self._padded_ptr(last_critic_obs, self._cfg.num_priv, self.priv_ld)
+        capi.check(self._L.hx_ppo_compute_returns(self._h, pp), "hx_ppo_compute_returns")
+        if self.comm is not None and self.comm.world_size > 1:
+            m = capi.C.c_void_p()
+            capi.check(self._L.hx_ppo_adv_moments(self._h, capi.C.byref(m)), "adv_moments")
+            self.comm.all_reduce_moments(m.value, self.stream)
+        capi.check(self._L.hx_ppo_adv_normalize(self._h), "hx_ppo_adv_normalize")
+        self._keep.append(k)
+
+    # ------------------------------------------------------------------ learner side
+    def update(self, perm=None):
+        pp, k = (None, None) if perm is None else device_pointer(np.ascontiguousarray(perm, np.int32))
+        stats = np.zeros(4, np.float32)
+        world = 1 if self.comm is None else self.comm.world_size
+        if world == 1:
+            capi.check(self._L.hx_ppo_update(self._h, pp, capi.ptr(stats)), "hx_ppo_update")
+        else:
+            capi.check(self._L.hx_ppo_update_begin(self._h, pp), "update_begin")
+            g, cnt = capi.C.c_void_p(), capi.C.c_int64()
+            for i in range(self.num_learning_epochs * self.num_mini_batches):
+                capi.check(self._L.hx_ppo_minibatch_backward(self._h, i, capi.C.byref(g), capi.C.byref(cnt)), "mb_backward")
+                self.comm.all_reduce_grads(g.value, cnt.value, self.stream)      # ONE collective per optimiser step
+                capi.check(self._L.hx_ppo_minibatch_step(self._h, 1.0 / world), "mb_step")
+            capi.check(self._L.hx_ppo_update_end(self._h, capi.ptr(stats)), "update_end")
+        self._last_lr, self.last_kl = float(stats[2]), float(stats[3])
+        self._keep = []
+        return float(stats[0]), float(stats[1])
+
+    @property
+    def learning_rate(self):
+        lr = capi.C.c_float()
+        capi.check(self._L.hx_ppo_get_lr(self._h, capi.C.byref(lr)), "get_lr")
+        return float(lr.value)
+
+    @learning_rate.setter
+    def learning_rate(self, v):
+        capi.check(self._L.hx_ppo_set_lr(self._h, float(v)), "set_lr")
+
+    @property
+    def stream(self):
+        return self._stream
+
+    def clear(self):
+        pass
+
+    def inference(self, obs):
+        po, k = self._padded_ptr(obs, self._cfg.num_obs, self.obs_ld)
+        rows = obs.shape[0]
+        out = capi.DeviceBuffer(rows * self.A * 4)
+        capi.check(self._L.hx_ppo_inference(self._h, po, rows, out.ptr), "inference")
+        return DeviceArray(out.ptr, (rows, self.A), np.float32, None, self.stream, owner=out)
+
+    def buffer(self, which, shape, dtype=np.float32):
+        p = capi.C.c_void_p()
+        capi.check(self._L.hx_ppo_buffer(self._h, which, capi.C.byref(p)), "hx_ppo_buffer")
+        return DeviceArray(p.value, shape, dtype, None, self.stream)
+
+    def test_mode(self):
+        pass
+
+    def train_mode(self):
+        pass
+
+    # ---- optimizer state (checkpoint format of on_policy_runner.py:278-295)
+    def optimizer_state(self):
+        n = self.actor_critic.num_params()
+        m, v, step = np.empty(n, np.float32), np.empty(n, np.float32), capi.C.c_int64()
+        capi.check(self._L.hx_ppo_get_opt_state_h(self._h, capi.ptr(m), capi.ptr(v), capi.C.byref(step)), "get_opt_state")
+        return m, v, int(step.value)
+
+    def load_optimizer_state(self, m, v, step):
+        capi.check(self._L.hx_ppo_set_opt_state_h(self._h, capi.ptr(capi.farr(m)), capi.ptr(capi.farr(v)), int(step)), "set_opt_state")
+
+    def prof_begin(self):
+        capi.check(self._L.hx_ppo_prof(self._h, 1, None, None), "prof")
+
+    def prof_end(self):
+        out = np.zeros(3, np.float64)
+        capi.check(self._L.hx_ppo_prof(self._h, 0, capi.ptr(out), None), "prof")
+        return dict(ms=float(out[0]), launches=int(out[1]), flops=float(out[2]))
+
+    def close(self):
+        if self._h:
+            self._L.hx_ppo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,220 @@
+// hx_gemm.h -- fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, 64-wide waves.
+//
+// One kernel template covers the three dense products of an MLP layer (reference: nn.Linear + nn.ELU in
+// humanoid/algo/ppo/actor_critic.py:57-80 and their autograd):
+//   FWD    Y[M,N]  = elu(X[M,K] W[N,K]^T + b)         A K-major, B K-major,  epilogue bias+ELU
+//   DGRAD  dX[M,N] = (dZ[M,K] W[K,N]) * elu'(H[M,N])  A K-major, B N-major,  epilogue * elu'(H)
+//   WGRAD  dW[M,N] = dZ[K,M]^T X[K,N]   (split-K)     A M-major, B N-major,  epilogue -> partial slab
+// (M,N,K are always the GEMM's own output rows / output cols / reduction length.)
+//
+// Tile: BM x BN x 16 per 256-thread workgroup (4 waves as 2x2), each wave (BM/2)x(BN/2) as 32x32 MFMA
+// tiles.  fp32 MFMA is exact fp32 (k-ordered fma chain) and runs at the fp32 vector rate, so LDS and
+// global bandwidth are never the limiter; the layout work here is about keeping every LDS access
+// conflict-free and every global access a whole 64-byte segment:
+//   K-major operand: global float4 along K -> ds_write_b128 into [row][16+4]; fragment = one ds_read_b128
+//                    per lane holding k = 4h..4h+3 of an 8-deep block (h = lane>>5), feeding 4 MFMAs;
+//   M/N-major operand: global float4 along the row index -> ds_write_b128 into [k][rows]; fragment =
+//                    4 ds_read_b32 at k = 4h+j.
+// Both use the same k <-> (lane half, MFMA j) assignment (MFMA j consumes k = j and k = 4+j of the block),
+// which is legal because a dot product does not care in which order its k terms are visited.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { EPI_BIAS_ELU = 0, EPI_ELU_GRAD = 1, EPI_SLAB = 2, EPI_BIAS = 3 };
+
+struct GemmArgs {
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int M, N, K;
+  const float* bias;        // EPI_BIAS_ELU / EPI_BIAS: [N]
+  const float* H; int ldh;  // EPI_ELU_GRAD: activations of the layer whose pre-activation gradient is produced
+  int splits, kchunk;       // EPI_SLAB: reduction split; C is [splits][M][ldc]
+  float* dbias;             // EPI_SLAB: [splits][M] column sums of A (bias gradient), nullable
+  int tiles_m, tiles_n;
+};
+
+#define HX_BK 16
+#define HX_KPAD 4
+
+__device__ __forceinline__ float hx_elu(float x) { return x > 0.f ? x : expm1f(x); }
+
+template <int BM, int BN, bool A_KM, bool B_KM, int EPI>
+__global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
+  constexpr int A_ELEMS = A_KM ? BM * (HX_BK + HX_KPAD) : HX_BK * BM;
+  constexpr int B_ELEMS = B_KM ? BN * (HX_BK + HX_KPAD) : HX_BK * BN;
+  constexpr int A_LOADS = BM * HX_BK / 4 / 256;   // float4 per thread per tile
+  constexpr int B_LOADS = BN * HX_BK / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
+
+  // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
+  // contiguous run of logical tiles so neighbours re-use the same A rows out of L2.
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  int logical;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+  const int split = logical / tiles_mn;
+  const int t = logical % tiles_mn;
+  const int tile_m = t / g.tiles_n, tile_n = t % g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int k_begin = 0, k_end = g.K;
+  if (EPI == EPI_SLAB) { k_begin = split * g.kchunk; k_end = min(g.K, k_begin + g.kchunk); }
+  const int nk = (k_end - k_begin + HX_BK - 1) / HX_BK;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, r32 = lane & 31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[A_LOADS], rb[B_LOADS];
+  float dbacc = 0.f;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = k_begin + kt * HX_BK;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (A_KM) {
+        const int row = idx >> 2, k4 = idx & 3;
+        const int gm = m0 + row, gk = k0 + k4 * 4;
+        if (gm < g.M && gk < k_end) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gm * g.lda + gk);
+      } else {
+        const int k = idx / (BM / 4), m4 = idx % (BM / 4);
+        const int gk = k0 + k, gm = m0 + m4 * 4;
+        if (gk < k_end && gm < g.M) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gk * g.lda + gm);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (B_KM) {
+        const int row = idx >> 2, k4 = idx & 3;
+        const int gn = n0 + row, gk = k0 + k4 * 4;
+        if (gn < g.N && gk < k_end) v = *reinterpret_cast<const f32x4*>(g.B + (size_t)gn * g.ldb + gk);
+      } else {
+        const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+        const int gk = k0 + k, gn = n0 + n4 * 4;
+        if (gk < k_end && gn < g.N) v = *reinterpret_cast<const f32x4*>(g.B + (size_t)gk * g.ldb + gn);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = lds + buf * (A_ELEMS + B_ELEMS);
+    float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (A_KM) { const int row = idx >> 2, k4 = idx & 3; *reinterpret_cast<f32x4*>(As + row * (HX_BK + HX_KPAD) + k4 * 4) = ra[i]; }
+      else { const int k = idx / (BM / 4), m4 = idx % (BM / 4); *reinterpret_cast<f32x4*>(As + k * BM + m4 * 4) = ra[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      const int idx = tid + i * 256;
+      if (B_KM) { const int row = idx >> 2, k4 = idx & 3; *reinterpret_cast<f32x4*>(Bs + row * (HX_BK + HX_KPAD) + k4 * 4) = rb[i]; }
+      else { const int k = idx / (BN / 4), n4 = idx % (BN / 4); *reinterpret_cast<f32x4*>(Bs + k * BN + n4 * 4) = rb[i]; }
+    }
+  };
+  auto compute = [&](int buf) {
+    const float* As = lds + buf * (A_ELEMS + B_ELEMS);
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int kb = 0; kb < HX_BK / 8; ++kb) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + r32;
+        if (A_KM) fa[i] = *reinterpret_cast<const f32x4*>(As + row * (HX_BK + HX_KPAD) + kb * 8 + 4 * h);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[i][j] = As[(kb * 8 + 4 * h + j) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * WTN + i * 32 + r32;
+        if (B_KM) fb[i] = *reinterpret_cast<const f32x4*>(Bs + row * (HX_BK + HX_KPAD) + kb * 8 + 4 * h);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[i][j] = Bs[(kb * 8 + 4 * h + j) * BN + row];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    }
+    if (EPI == EPI_SLAB && !A_KM) {
+      // bias gradient = column sums of dZ = row sums over k of the A tile; done once per tile row
+      if (g.dbias != nullptr && tile_n == 0 && tid < BM) {
+#pragma unroll
+        for (int k = 0; k < HX_BK; ++k) dbacc += As[k * BM + tid];
+      }
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 1 < nk);
+      if (more) load_tile(kt + 1);
+      compute(kt & 1);
+      if (more) store_tile((kt + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* Cb = g.C;
+  if (EPI == EPI_SLAB) Cb += (size_t)split * g.M * g.ldc;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn * WTN + b * 32 + r32;
+      if (col >= g.N) continue;
+      float bv = 0.f;
+      if (EPI == EPI_BIAS_ELU || EPI == EPI_BIAS) bv = g.bias[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        float v = acc[a][b][e];
+        if (EPI == EPI_BIAS_ELU) v = hx_elu(v + bv);
+        if (EPI == EPI_BIAS) v = v + bv;
+        if (EPI == EPI_ELU_GRAD) {
+          const float hh = g.H[(size_t)row * g.ldh + col];
+          v = v * (hh > 0.f ? 1.f : hh + 1.f);
+        }
+        Cb[(size_t)row * g.ldc + col] = v;
+      }
+    }
+  if (EPI == EPI_SLAB && !A_KM) {
+    if (g.dbias != nullptr && tile_n == 0 && tid < BM && m0 + tid < g.M) g.dbias[(size_t)split * g.M + m0 + tid] = dbacc;
+  }
+}

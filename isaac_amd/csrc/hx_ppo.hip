@@ -1,0 +1,896 @@
+// hx_ppo.hip -- PPO learner kernels + C ABI (include/hx_ppo.h).
+//
+// Restates the reference's humanoid/algo/ppo/{actor_critic,rollout_storage,ppo}.py (see hx_ppo.h for the
+// function-by-function map).  The autograd graph is written out by hand; oracle/ppo.py is the CPU
+// statement of the same formulas, pinned to the reference by tests/golden/ppo_*.npz.
+//
+// Data layout in HBM (fp32 unless noted):
+//   params / grads / Adam m,v : one flat buffer each, per layer W[out][in_ld] (in_ld = in rounded up to 4,
+//                               zero padded so every row is 16-byte aligned), then b[out]; std last.
+//   rollout storage           : [T][N][ld] for obs / privileged obs, [T][N][A] actions / mu, [T][N] scalars.
+//   minibatch workspace       : gathered rows + one activation buffer per hidden layer, [M][width].
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/hx_ppo.h"
+#include "hx_common.h"
+#include "hx_gemm.h"
+
+#define MAX_A 16
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// ================================================================= small kernels
+__device__ __forceinline__ void philox4p(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+#define LOG_SQRT_2PI 0.9189385332046727f
+
+// Rollout head (ppo.py:91-101): mu = W4 h3a + b4, a = mu + std*eps, logp, V = w4c.h3c + b4c.  One thread per env.
+__global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restrict__ h3a, const float* __restrict__ h3c, int hw,
+                                                          const float* __restrict__ W4, const float* __restrict__ b4,
+                                                          const float* __restrict__ W4c, const float* __restrict__ b4c,
+                                                          const float* __restrict__ stdp, const float* __restrict__ eps,
+                                                          int n, int A, uint32_t k0, uint32_t k1, uint32_t step,
+                                                          float* actions, float* mu_out, float* values, float* logp) {
+  extern __shared__ float sm[];
+  float* sW = sm;                 // [A][hw]
+  float* sWc = sm + A * hw;       // [hw]
+  for (int i = threadIdx.x; i < A * hw; i += blockDim.x) sW[i] = W4[i];
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) sWc[i] = W4c[i];
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float mu[MAX_A];
+  for (int j = 0; j < A; ++j) mu[j] = 0.f;
+  float v = 0.f;
+  const float* ha = h3a + (size_t)e * hw;
+  const float* hc = h3c + (size_t)e * hw;
+  for (int k = 0; k < hw; k += 4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(ha + k);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(hc + k);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      for (int j = 0; j < A; ++j) mu[j] = fmaf(x[q], sW[j * hw + k + q], mu[j]);
+      v = fmaf(y[q], sWc[k + q], v);
+    }
+  }
+  float lp = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float m = mu[j] + b4[j];
+    const float sg = m * 0.f + stdp[j];
+    float z;
+    if (eps) z = eps[(size_t)e * A + j];
+    else {
+      uint32_t o[4];
+      philox4p(k0, k1, (uint32_t)e, step, (uint32_t)j, 7u, o);
+      const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+      const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+      z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    const float a = m + sg * z;
+    actions[(size_t)e * A + j] = a;
+    mu_out[(size_t)e * A + j] = m;
+    const float d = a - m;
+    lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - LOG_SQRT_2PI;
+  }
+  values[e] = v + b4c[0];
+  logp[e] = lp;
+}
+
+// critic head only (bootstrap value of compute_returns, ppo.py:116)
+__global__ void __launch_bounds__(256) hx_value_head_kernel(const float* __restrict__ h3c, int hw, const float* __restrict__ W4c,
+                                                            const float* __restrict__ b4c, int n, float* values) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float v = 0.f;
+  const float* hc = h3c + (size_t)e * hw;
+  for (int k = 0; k < hw; ++k) v = fmaf(hc[k], W4c[k], v);
+  values[e] = v + b4c[0];
+}
+
+// actor head only (act_inference, actor_critic.py:122-124)
+__global__ void __launch_bounds__(256) hx_mean_head_kernel(const float* __restrict__ h3a, int hw, const float* __restrict__ W4,
+                                                           const float* __restrict__ b4, int n, int A, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * A) return;
+  const int e = i / A, j = i % A;
+  float m = 0.f;
+  for (int k = 0; k < hw; ++k) m = fmaf(h3a[(size_t)e * hw + k], W4[j * hw + k], m);
+  out[i] = m + b4[j];
+}
+
+// process_env_step (ppo.py:103-113): time-out bootstrap, store reward / done
+__global__ void hx_process_step_kernel(const float* __restrict__ rew, const unsigned char* __restrict__ dones,
+                                       const unsigned char* __restrict__ timeouts, const float* __restrict__ values, float gamma,
+                                       int n, float* rew_out, unsigned char* done_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float r = rew[e];
+  if (timeouts) r += gamma * (values[e] * (timeouts[e] ? 1.f : 0.f));
+  rew_out[e] = r;
+  done_out[e] = dones[e] ? 1 : 0;
+}
+
+// GAE (rollout_storage.py:122-132) + first pass of the advantage moments
+__global__ void __launch_bounds__(256) hx_gae_kernel(const float* __restrict__ rewards, const unsigned char* __restrict__ dones,
+                                                     const float* __restrict__ values, const float* __restrict__ last_values,
+                                                     int T, int n, float gamma, float lam, float* returns, float* adv_raw,
+                                                     double* moments) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  double s = 0.0, s2 = 0.0;
+  if (e < n) {
+    float adv = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+      const float nv = (t == T - 1) ? last_values[e] : values[(size_t)(t + 1) * n + e];
+      const float nt = 1.0f - (float)dones[(size_t)t * n + e];
+      const float v = values[(size_t)t * n + e];
+      const float delta = rewards[(size_t)t * n + e] + nt * gamma * nv - v;
+      adv = delta + nt * gamma * lam * adv;
+      const float ret = adv + v;
+      returns[(size_t)t * n + e] = ret;
+      const float a = ret - v;
+      adv_raw[(size_t)t * n + e] = a;
+      s += (double)a; s2 += (double)a * (double)a;
+    }
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&moments[0], sh[0][0]);
+    atomicAdd(&moments[1], sh[1][0]);
+    if (blockIdx.x == 0) atomicAdd(&moments[2], (double)T * (double)n);
+  }
+}
+
+// (A - mean) / (std_unbiased + 1e-8)   (rollout_storage.py:135-136)
+__global__ void hx_adv_normalize_kernel(const float* __restrict__ adv_raw, const double* __restrict__ moments, size_t count, float* adv) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const double nn = moments[2];
+  const double mean = moments[0] / nn;
+  double var = (moments[1] - nn * mean * mean) / (nn - 1.0);
+  if (var < 0.0) var = 0.0;
+  const float m = (float)mean, sd = (float)sqrt(var);
+  adv[i] = (adv_raw[i] - m) / (sd + 1e-8f);
+}
+
+// keyed bijection on [0, B): 4-round Feistel on the enclosing power of four, cycle-walking
+__global__ void hx_perm_kernel(int* perm, int B, uint32_t key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  int bits = 2;
+  while ((1 << bits) < B) bits += 2;
+  const int half = bits / 2;
+  const uint32_t mask = (1u << half) - 1u;
+  uint32_t x = (uint32_t)i;
+  do {
+    uint32_t l = x >> half, r = x & mask;
+    for (int round = 0; round < 4; ++round) {
+      uint32_t f = (r * 0x9E3779B1u) ^ (key + 0x85EBCA6Bu * (uint32_t)(round + 1));
+      f ^= f >> 15; f *= 0x2C1B3C6Du; f ^= f >> 12;
+      const uint32_t nl = r, nr = (l ^ f) & mask;
+      l = nl; r = nr;
+    }
+    x = (l << half) | r;
+  } while (x >= (uint32_t)B);
+  perm[i] = (int)x;
+}
+
+// minibatch gather (rollout_storage.py:167-180): rows of obs / priv and the per-row scalars
+struct GatherArgs {
+  const int* idx; int M;
+  const float* obs; int obs_ld; float* obs_mb;
+  const float* priv; int priv_ld; float* priv_mb;
+  const float* actions; const float* mu; const float* values; const float* returns; const float* logp; const float* adv;
+  int A;
+  float* row_mb;   // [M][2A+4]: actions A, mu_old A, value_old, return, logp_old, advantage
+};
+__global__ void __launch_bounds__(256) hx_gather_kernel(GatherArgs g) {
+  const int m = blockIdx.x;
+  const int src = g.idx[m];
+  const f32x4* so = reinterpret_cast<const f32x4*>(g.obs + (size_t)src * g.obs_ld);
+  f32x4* dobs = reinterpret_cast<f32x4*>(g.obs_mb + (size_t)m * g.obs_ld);
+  for (int k = threadIdx.x; k < g.obs_ld / 4; k += blockDim.x) dobs[k] = so[k];
+  const f32x4* sp = reinterpret_cast<const f32x4*>(g.priv + (size_t)src * g.priv_ld);
+  f32x4* dp = reinterpret_cast<f32x4*>(g.priv_mb + (size_t)m * g.priv_ld);
+  for (int k = threadIdx.x; k < g.priv_ld / 4; k += blockDim.x) dp[k] = sp[k];
+  const int W = 2 * g.A + 4;
+  float* r = g.row_mb + (size_t)m * W;
+  if (threadIdx.x < g.A) { r[threadIdx.x] = g.actions[(size_t)src * g.A + threadIdx.x]; r[g.A + threadIdx.x] = g.mu[(size_t)src * g.A + threadIdx.x]; }
+  if (threadIdx.x == 32) { r[2 * g.A] = g.values[src]; r[2 * g.A + 1] = g.returns[src]; r[2 * g.A + 2] = g.logp[src]; r[2 * g.A + 3] = g.adv[src]; }
+}
+
+// Loss head (ppo.py:128-166 forward of the last layers, all loss terms, and their backward down to the
+// pre-activation gradient of the third hidden layer).  64 rows per workgroup.
+// Outputs: dZ3a[M][hw], dZ3c[M][hw] and one partial slab per workgroup:
+//   [A*hw dW4 | A db4 | hw dW4c | 1 db4c | A dstd | kl_sum, value_loss_sum, surrogate_sum, entropy_sum]
+#define HEAD_ROWS 32
+struct HeadArgs {
+  const float* h3a; const float* h3c; int hw;
+  const float* W4; const float* b4; const float* W4c; const float* b4c; const float* stdp; const float* sigma_old;
+  const float* row_mb; int M, A;
+  float clip, vcoef, ecoef; int use_clipped_value_loss;
+  float* dz3a; float* dz3c; float* slab; int slab_w;
+};
+__global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
+  extern __shared__ float sm[];
+  const int hw = g.hw, A = g.A, hp = hw + 1;
+  float* sHa = sm;                       // [64][hw+1]
+  float* sHc = sHa + HEAD_ROWS * hp;     // [64][hw+1]
+  float* sW = sHc + HEAD_ROWS * hp;      // [A][hw]
+  float* sWc = sW + A * hw;              // [hw]
+  float* sD = sWc + hw;                  // [64][A+1]  dmu, dv
+  float* sL = sD + HEAD_ROWS * (A + 1);  // [64][4+A]  kl, vloss, sloss, entropy, dsigma[A]
+  const int r0 = blockIdx.x * HEAD_ROWS;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < HEAD_ROWS * hw; i += 256) {
+    const int r = i / hw, k = i % hw;
+    const bool ok = (r0 + r) < g.M;
+    sHa[r * hp + k] = ok ? g.h3a[(size_t)(r0 + r) * hw + k] : 0.f;
+    sHc[r * hp + k] = ok ? g.h3c[(size_t)(r0 + r) * hw + k] : 0.f;
+  }
+  for (int i = tid; i < A * hw; i += 256) sW[i] = g.W4[i];
+  for (int i = tid; i < hw; i += 256) sWc[i] = g.W4c[i];
+  __syncthreads();
+  if (tid < HEAD_ROWS) {
+    const int r = tid, m = r0 + r;
+    float* L = sL + r * (4 + A);
+    float* D = sD + r * (A + 1);
+    if (m < g.M) {
+      const float invM = 1.0f / (float)g.M;
+      const float* row = g.row_mb + (size_t)m * (2 * A + 4);
+      float mu[MAX_A];
+      for (int j = 0; j < A; ++j) mu[j] = 0.f;
+      float v = 0.f;
+      for (int k = 0; k < hw; ++k) {
+        const float x = sHa[r * hp + k];
+        for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
+        v = fmaf(sHc[r * hp + k], sWc[k], v);
+      }
+      v += g.b4c[0];
+      float logp = 0.f, ent = 0.f, kl = 0.f;
+      float sg[MAX_A];
+      for (int j = 0; j < A; ++j) {
+        mu[j] += g.b4[j];
+        sg[j] = mu[j] * 0.f + g.stdp[j];
+        const float d = row[j] - mu[j];
+        const float ls = logf(sg[j]);
+        logp += -(d * d) / (2.0f * sg[j] * sg[j]) - ls - LOG_SQRT_2PI;
+        ent += 0.5f + LOG_SQRT_2PI + ls;
+        const float so = g.sigma_old[j], dm = row[A + j] - mu[j];
+        kl += logf(sg[j] / so + 1.e-5f) + (so * so + dm * dm) / (2.0f * sg[j] * sg[j]) - 0.5f;
+      }
+      const float v_old = row[2 * A], ret = row[2 * A + 1], logp_old = row[2 * A + 2], adv = row[2 * A + 3];
+      const float ratio = expf(logp - logp_old);
+      const float lo = 1.0f - g.clip, hi = 1.0f + g.clip;
+      const float s = -adv * ratio, sc = -adv * fminf(fmaxf(ratio, lo), hi);
+      const float inr = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+      const float w = (s > sc) ? 1.f : ((s == sc) ? 0.5f + 0.5f * inr : inr);
+      const float dlogp = -adv * w * ratio * invM;
+      float vl, dv;
+      if (g.use_clipped_value_loss) {
+        const float vc = v_old + fminf(fmaxf(v - v_old, -g.clip), g.clip);
+        const float la = (v - ret) * (v - ret), lb = (vc - ret) * (vc - ret);
+        vl = fmaxf(la, lb);
+        const float inv = (fabsf(v - v_old) <= g.clip) ? 1.f : 0.f;
+        const float ga = 2.0f * (v - ret), gb = 2.0f * (vc - ret) * inv;
+        dv = (la > lb) ? ga : ((la == lb) ? 0.5f * ga + 0.5f * gb : gb);
+      } else {
+        vl = (ret - v) * (ret - v);
+        dv = 2.0f * (v - ret);
+      }
+      D[A] = g.vcoef * dv * invM;
+      for (int j = 0; j < A; ++j) {
+        const float d = row[j] - mu[j];
+        D[j] = dlogp * d / (sg[j] * sg[j]);
+        L[4 + j] = dlogp * (d * d / (sg[j] * sg[j] * sg[j]) - 1.0f / sg[j]) - g.ecoef * invM / sg[j];
+      }
+      L[0] = kl; L[1] = vl; L[2] = fmaxf(s, sc); L[3] = ent;
+    } else {
+      for (int j = 0; j <= A; ++j) D[j] = 0.f;
+      for (int j = 0; j < 4 + A; ++j) L[j] = 0.f;
+    }
+  }
+  __syncthreads();
+  // dZ3 = (W4^T dmu) * elu'(h3)   and   dZ3c = dv w4c * elu'(h3c)
+  for (int i = tid; i < HEAD_ROWS * hw; i += 256) {
+    const int r = i / hw, k = i % hw;
+    if (r0 + r >= g.M) continue;
+    float s = 0.f;
+    for (int j = 0; j < A; ++j) s = fmaf(sD[r * (A + 1) + j], sW[j * hw + k], s);
+    const float ha = sHa[r * hp + k], hc = sHc[r * hp + k];
+    g.dz3a[(size_t)(r0 + r) * hw + k] = s * (ha > 0.f ? 1.f : ha + 1.f);
+    g.dz3c[(size_t)(r0 + r) * hw + k] = sD[r * (A + 1) + A] * sWc[k] * (hc > 0.f ? 1.f : hc + 1.f);
+  }
+  // partial parameter gradients of the two heads, summed over this workgroup's rows
+  float* slab = g.slab + (size_t)blockIdx.x * g.slab_w;
+  for (int i = tid; i < A * hw; i += 256) {
+    const int j = i / hw, k = i % hw;
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + j], sHa[r * hp + k], s);
+    slab[i] = s;
+  }
+  for (int k = tid; k < hw; k += 256) {
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + A], sHc[r * hp + k], s);
+    slab[A * hw + A + k] = s;
+  }
+  if (tid < A) {
+    float s = 0.f, d = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) { s += sD[r * (A + 1) + tid]; d += sL[r * (4 + A) + 4 + tid]; }
+    slab[A * hw + tid] = s;                      // db4
+    slab[A * hw + A + hw + 1 + tid] = d;         // dstd
+  }
+  if (tid == 32) {
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s += sD[r * (A + 1) + A];
+    slab[A * hw + A + hw] = s;                   // db4c
+  }
+  if (tid >= 64 && tid < 68) {
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s += sL[r * (4 + A) + (tid - 64)];
+    slab[A * hw + A + hw + 1 + A + (tid - 64)] = s;
+  }
+}
+
+// dst[i] (+)= sum_s src[s][i]
+__global__ void hx_reduce_slabs_kernel(const float* __restrict__ src, int S, size_t count, size_t stride, float* dst, int accumulate) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += src[(size_t)k * stride + i];
+  dst[i] = accumulate ? dst[i] + s : s;
+}
+
+// scatter the head slab sums into the flat gradient buffer + statistics
+struct HeadScatter { size_t w4, b4, w4c, b4c, stdo, stats; int A, hw; };
+__global__ void hx_head_scatter_kernel(const float* __restrict__ slab, int S, int slab_w, float* grads, HeadScatter o, float rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slab_w) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += slab[(size_t)k * slab_w + i];
+  const int A = o.A, hw = o.hw;
+  size_t dst;
+  if (i < A * hw) dst = o.w4 + i;
+  else if (i < A * hw + A) dst = o.b4 + (i - A * hw);
+  else if (i < A * hw + A + hw) dst = o.w4c + (i - A * hw - A);
+  else if (i < A * hw + A + hw + 1) dst = o.b4c;
+  else if (i < A * hw + A + hw + 1 + A) dst = o.stdo + (i - (A * hw + A + hw + 1));
+  else {
+    const int q = i - (A * hw + A + hw + 1 + A);   // 0 kl, 1 vloss, 2 sloss, 3 entropy
+    if (q == 3) return;
+    dst = o.stats + q;
+  }
+  grads[dst] = s;
+  if (i == 0) grads[o.stats + 3] = rows;
+}
+
+// sum of squares of the gradient (clip_grad_norm_, ppo.py:173)
+__global__ void __launch_bounds__(256) hx_sumsq_kernel(const float* __restrict__ g, size_t count, float scale, double* out) {
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const double x = (double)(g[i] * scale);
+    s += x * x;
+  }
+  __shared__ double sh[256];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+}
+
+// adaptive-KL learning-rate schedule (ppo.py:136-148) + running loss sums, on device so no host sync is needed
+struct SchedState { float lr; float last_kl; float vloss_sum; float sloss_sum; };
+__global__ void hx_schedule_kernel(const float* __restrict__ stats, int adaptive, float desired_kl, SchedState* st) {
+  const float rows = stats[3];
+  const float kl = stats[0] / rows;
+  float lr = st->lr;
+  if (adaptive) {
+    if (kl > desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+    else if (kl < desired_kl / 2.0f && kl > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+  }
+  st->lr = lr;
+  st->last_kl = kl;
+  st->vloss_sum += stats[1] / rows;
+  st->sloss_sum += stats[2] / rows;
+}
+
+// clip_grad_norm_ + Adam (ppo.py:171-174 ; torch.optim.Adam defaults betas (0.9,0.999) eps 1e-8)
+__global__ void __launch_bounds__(256) hx_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, size_t count, float gscale, const double* sumsq,
+                                                      float max_norm, const SchedState* st, float bc1, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float total = (float)sqrt(*sumsq);
+  const float coef = fminf(1.0f, max_norm / (total + 1e-6f));
+  const float gi = g[i] * gscale * coef;
+  const float mi = 0.9f * m[i] + (1.0f - 0.9f) * gi;
+  const float vi = 0.999f * v[i] + (1.0f - 0.999f) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + 1e-8f;
+  p[i] = p[i] - (st->lr / bc1) * (mi / denom);
+}
+
+// ================================================================= host side
+struct Layer { int out, in, in_ld; size_t w, b; };
+
+struct hx_ppo {
+  hx_ppo_cfg cfg;
+  hipStream_t stream; bool own_stream;
+  Layer L[8];                  // actor 0..3, critic 4..7
+  size_t std_off, padded, stats_off;
+  int64_t torch_count;
+  float *params, *grads, *m, *v; bool ext_grads;
+  // storage
+  float *s_obs, *s_priv, *s_actions, *s_mu, *s_values, *s_logp, *s_rewards, *s_returns, *s_adv_raw, *s_adv, *sigma_old;
+  unsigned char* s_dones;
+  float* last_values; double* moments;
+  int step;
+  // workspace
+  int Mmax;
+  float *obs_mb, *priv_mb, *row_mb;
+  float *act_a[3], *act_c[3], *dz_a[3], *dz_c[3];
+  float *slab, *bias_slab, *head_slab; size_t slab_floats; int head_blocks_max, head_slab_w;
+  int* perm; int perm_external;
+  double* sumsq; SchedState* sched;
+  int64_t adam_t;
+  int mb_done, mb_total;
+  uint32_t seed_lo, seed_hi, act_counter, perm_counter;
+  // profiling
+  bool prof; std::vector<hipEvent_t> ev; size_t ev_used; double prof_flops; long prof_launches;
+  std::vector<void*> allocs;
+};
+
+template <typename T> static int palloc(hx_ppo* s, T** ptr, size_t count) {
+  HX_CHECK(hipMalloc((void**)ptr, count * sizeof(T)));
+  HX_CHECK(hipMemsetAsync(*ptr, 0, count * sizeof(T), s->stream));
+  s->allocs.push_back(*ptr);
+  return 0;
+}
+
+// ---- GEMM dispatch
+template <int BM, int BN, bool AK, bool BK_, int EPI> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
+  if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
+    hipEventRecord(s->ev[s->ev_used], st);
+    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
+    hipEventRecord(s->ev[s->ev_used + 1], st);
+    s->ev_used += 2;
+    s->prof_flops += 2.0 * g.M * g.N * g.K;
+    s->prof_launches += 1;
+  } else {
+    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
+  }
+}
+
+static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K) {
+  GemmArgs g{};
+  g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
+  if (M >= 16384) launch_gemm<128, 128, true, true, EPI_BIAS_ELU>(s, g, st);
+  else launch_gemm<64, 128, true, true, EPI_BIAS_ELU>(s, g, st);
+}
+static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
+  GemmArgs g{};
+  g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = N; g.M = M; g.N = N; g.K = K; g.H = H; g.ldh = N;
+  if (M >= 16384) launch_gemm<128, 128, true, false, EPI_ELU_GRAD>(s, g, st);
+  else launch_gemm<64, 128, true, false, EPI_ELU_GRAD>(s, g, st);
+}
+// dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab / bias_slab
+static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab) {
+  GemmArgs g{};
+  g.A = dZ; g.lda = out; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = Mrows;
+  const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
+  int splits = (1024 + tiles - 1) / tiles;
+  int max_splits = Mrows / 256; if (max_splits < 1) max_splits = 1;
+  if (splits > max_splits) splits = max_splits;
+  int kchunk = rup((Mrows + splits - 1) / splits, HX_BK);
+  splits = (Mrows + kchunk - 1) / kchunk;
+  g.splits = splits; g.kchunk = kchunk; g.dbias = bias_slab;
+  launch_gemm<128, 128, false, false, EPI_SLAB>(s, g, st);
+  return splits;
+}
+
+extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
+                                float* C, int ldc, const float* H, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.H = H; g.ldh = ldc;
+  if (mode == 0) launch_gemm<128, 128, true, true, EPI_BIAS_ELU>(nullptr, g, st);
+  else if (mode == 3) launch_gemm<64, 128, true, true, EPI_BIAS_ELU>(nullptr, g, st);
+  else if (mode == 1) launch_gemm<128, 128, true, false, EPI_ELU_GRAD>(nullptr, g, st);
+  else if (mode == 4) launch_gemm<64, 128, true, false, EPI_ELU_GRAD>(nullptr, g, st);
+  else if (mode == 2) {
+    // single split, direct output (C must hold [M][ldc]); bias -> column sums written to `bias` (cast away const for the test)
+    g.splits = 1; g.kchunk = rup(K, HX_BK); g.dbias = const_cast<float*>(bias);
+    launch_gemm<128, 128, false, false, EPI_SLAB>(nullptr, g, st);
+  } else { hx_set_error("hx_ppo_gemm_test: bad mode"); return -2; }
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo** out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
+  if (cfg->num_actions > MAX_A) { hx_set_error("hx_ppo_create: num_actions > 16"); return -2; }
+  if (cfg->actor_hidden[2] != cfg->critic_hidden[2] || cfg->actor_hidden[2] % 4) { hx_set_error("hx_ppo_create: last hidden widths must match and be a multiple of 4"); return -2; }
+  hx_ppo* s = new hx_ppo();
+  s->cfg = *cfg;
+  if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
+  else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
+  const int A = cfg->num_actions, N = cfg->num_envs, T = cfg->num_steps;
+  // ---- parameter layout
+  int dims_a[5] = {cfg->num_obs, cfg->actor_hidden[0], cfg->actor_hidden[1], cfg->actor_hidden[2], A};
+  int dims_c[5] = {cfg->num_priv, cfg->critic_hidden[0], cfg->critic_hidden[1], cfg->critic_hidden[2], 1};
+  size_t off = 0; int64_t tc = A;
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < 4; ++l) {
+      const int* d = net ? dims_c : dims_a;
+      Layer& Ly = s->L[net * 4 + l];
+      Ly.in = d[l]; Ly.out = d[l + 1]; Ly.in_ld = rup(d[l], 4);
+      Ly.w = off; off += (size_t)Ly.out * Ly.in_ld; off = rup((int)off, 4);
+      Ly.b = off; off += Ly.out; off = rup((int)off, 4);
+      tc += (int64_t)Ly.out * Ly.in + Ly.out;
+    }
+  s->std_off = off; off += rup(A, 4);
+  s->padded = off; s->stats_off = off;
+  s->torch_count = tc;
+  if (cfg->obs_ld < s->L[0].in_ld || cfg->priv_ld < s->L[4].in_ld || cfg->obs_ld % 4 || cfg->priv_ld % 4) { hx_set_error("hx_ppo_create: obs_ld/priv_ld must be >= padded input width and multiples of 4"); return -2; }
+  int rc = 0;
+  rc |= palloc(s, &s->params, s->padded);
+  if (ext_grad) { s->grads = (float*)ext_grad; s->ext_grads = true; }
+  else { rc |= palloc(s, &s->grads, s->padded + 4); s->ext_grads = false; }
+  rc |= palloc(s, &s->m, s->padded);
+  rc |= palloc(s, &s->v, s->padded);
+  // ---- storage
+  const size_t TN = (size_t)T * N;
+  rc |= palloc(s, &s->s_obs, TN * cfg->obs_ld);
+  rc |= palloc(s, &s->s_priv, TN * cfg->priv_ld);
+  rc |= palloc(s, &s->s_actions, TN * A); rc |= palloc(s, &s->s_mu, TN * A);
+  rc |= palloc(s, &s->s_values, TN); rc |= palloc(s, &s->s_logp, TN); rc |= palloc(s, &s->s_rewards, TN);
+  rc |= palloc(s, &s->s_returns, TN); rc |= palloc(s, &s->s_adv_raw, TN); rc |= palloc(s, &s->s_adv, TN);
+  rc |= palloc(s, &s->s_dones, TN); rc |= palloc(s, &s->sigma_old, MAX_A);
+  rc |= palloc(s, &s->last_values, (size_t)N); rc |= palloc(s, &s->moments, 3);
+  // ---- workspace
+  const int mbs = (int)(TN / cfg->num_mini_batches);
+  s->Mmax = mbs > N ? mbs : N;
+  const size_t Mm = s->Mmax;
+  rc |= palloc(s, &s->obs_mb, Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb, Mm * cfg->priv_ld);
+  rc |= palloc(s, &s->row_mb, Mm * (2 * A + 4));
+  for (int l = 0; l < 3; ++l) {
+    rc |= palloc(s, &s->act_a[l], Mm * cfg->actor_hidden[l]); rc |= palloc(s, &s->dz_a[l], Mm * cfg->actor_hidden[l]);
+    rc |= palloc(s, &s->act_c[l], Mm * cfg->critic_hidden[l]); rc |= palloc(s, &s->dz_c[l], Mm * cfg->critic_hidden[l]);
+  }
+  size_t slab_max = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (i % 4 == 3) continue;
+    const Layer& Ly = s->L[i];
+    const int tiles = ((Ly.out + 127) / 128) * ((Ly.in_ld + 127) / 128);
+    int splits = (1024 + tiles - 1) / tiles + 1;
+    const size_t need = (size_t)splits * Ly.out * Ly.in_ld;
+    if (need > slab_max) slab_max = need;
+  }
+  s->slab_floats = slab_max;
+  rc |= palloc(s, &s->slab, slab_max);
+  rc |= palloc(s, &s->bias_slab, (size_t)1100 * 1024);
+  s->head_slab_w = A * cfg->actor_hidden[2] + A + cfg->actor_hidden[2] + 1 + A + 4;
+  s->head_blocks_max = (s->Mmax + HEAD_ROWS - 1) / HEAD_ROWS;
+  rc |= palloc(s, &s->head_slab, (size_t)s->head_blocks_max * s->head_slab_w);
+  rc |= palloc(s, &s->perm, TN);
+  rc |= palloc(s, &s->sumsq, 1); rc |= palloc(s, &s->sched, 1);
+  if (rc) return -3;
+  SchedState st0{cfg->learning_rate, 0.f, 0.f, 0.f};
+  HX_CHECK(hipMemcpyAsync(s->sched, &st0, sizeof(st0), hipMemcpyHostToDevice, s->stream));
+  // std = init_noise_std (actor_critic.py:80); weights stay zero until hx_ppo_set_params_h
+  std::vector<float> sd(rup(A, 4), 0.f);
+  for (int j = 0; j < A; ++j) sd[j] = cfg->init_noise_std;
+  HX_CHECK(hipMemcpyAsync(s->params + s->std_off, sd.data(), sd.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
+  s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
+  s->prof = false; s->ev_used = 0; s->prof_flops = 0; s->prof_launches = 0;
+  *out = s;
+  return 0;
+}
+
+extern "C" void hx_ppo_destroy(hx_ppo* s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s->stream);
+  for (void* a : s->allocs) (void)hipFree(a);
+  for (auto e : s->ev) (void)hipEventDestroy(e);
+  if (s->own_stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+extern "C" int64_t hx_ppo_num_params(hx_ppo* s) { return s->torch_count; }
+extern "C" void* hx_ppo_stream(hx_ppo* s) { return (void*)s->stream; }
+
+// torch parameters() order <-> padded device layout
+template <typename F> static void for_each_tensor(hx_ppo* s, F f) {
+  size_t t = 0;
+  f(t, s->std_off, 1, s->cfg.num_actions, s->cfg.num_actions); t += s->cfg.num_actions;
+  for (int i = 0; i < 8; ++i) {
+    const Layer& Ly = s->L[i];
+    f(t, Ly.w, Ly.out, Ly.in, Ly.in_ld); t += (size_t)Ly.out * Ly.in;
+    f(t, Ly.b, 1, Ly.out, Ly.out); t += Ly.out;
+  }
+}
+static void pack_padded(hx_ppo* s, const float* flat, std::vector<float>& pad) {
+  pad.assign(s->padded, 0.f);
+  for_each_tensor(s, [&](size_t t, size_t off, int rows, int cols, int ld) {
+    for (int r = 0; r < rows; ++r) memcpy(&pad[off + (size_t)r * ld], flat + t + (size_t)r * cols, cols * sizeof(float));
+  });
+}
+static void unpack_padded(hx_ppo* s, const std::vector<float>& pad, float* flat) {
+  for_each_tensor(s, [&](size_t t, size_t off, int rows, int cols, int ld) {
+    for (int r = 0; r < rows; ++r) memcpy(flat + t + (size_t)r * cols, &pad[off + (size_t)r * ld], cols * sizeof(float));
+  });
+}
+static int upload_flat(hx_ppo* s, float* dst, const float* flat) {
+  std::vector<float> pad; pack_padded(s, flat, pad);
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(dst, pad.data(), s->padded * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+static int download_flat(hx_ppo* s, const float* src, float* flat) {
+  std::vector<float> pad(s->padded);
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(pad.data(), src, s->padded * sizeof(float), hipMemcpyDeviceToHost));
+  unpack_padded(s, pad, flat);
+  return 0;
+}
+extern "C" int hx_ppo_set_params_h(hx_ppo* s, const float* flat) { return upload_flat(s, s->params, flat); }
+extern "C" int hx_ppo_get_params_h(hx_ppo* s, float* flat) { return download_flat(s, s->params, flat); }
+extern "C" int hx_ppo_set_opt_state_h(hx_ppo* s, const float* m, const float* v, int64_t step) {
+  int rc = upload_flat(s, s->m, m); if (rc) return rc;
+  rc = upload_flat(s, s->v, v); if (rc) return rc;
+  s->adam_t = step; return 0;
+}
+extern "C" int hx_ppo_get_opt_state_h(hx_ppo* s, float* m, float* v, int64_t* step) {
+  int rc = download_flat(s, s->m, m); if (rc) return rc;
+  rc = download_flat(s, s->v, v); if (rc) return rc;
+  *step = s->adam_t; return 0;
+}
+
+// hidden layers of one network: X[M][ld] -> act[0..2]
+static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act) {
+  const Layer* L = s->L + net * 4;
+  gemm_fwd(s, s->stream, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld);
+  gemm_fwd(s, s->stream, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld);
+  gemm_fwd(s, s->stream, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld);
+}
+
+extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const float* eps, float** actions_out) {
+  const int N = s->cfg.num_envs, A = s->cfg.num_actions, t = s->step;
+  if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }   // rollout_storage.py:88-89
+  float* so = s->s_obs + (size_t)t * N * s->cfg.obs_ld;
+  float* sp = s->s_priv + (size_t)t * N * s->cfg.priv_ld;
+  HX_CHECK(hipMemcpyAsync(so, obs, (size_t)N * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+  HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)N * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+  mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, N, s->act_a);
+  mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, N, s->act_c);
+  const int hw = s->cfg.actor_hidden[2];
+  if (t == 0) HX_CHECK(hipMemcpyAsync(s->sigma_old, s->params + s->std_off, A * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+  float* acts = s->s_actions + (size_t)t * N * A;
+  hipLaunchKernelGGL(hx_act_head_kernel, dim3((N + 255) / 256), dim3(256), (A + 1) * hw * sizeof(float), s->stream,
+                     s->act_a[2], s->act_c[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
+                     s->params + s->std_off, eps, N, A, s->seed_lo, s->seed_hi, s->act_counter++, acts, s->s_mu + (size_t)t * N * A,
+                     s->s_values + (size_t)t * N, s->s_logp + (size_t)t * N);
+  HX_CHECK(hipGetLastError());
+  if (actions_out) *actions_out = acts;
+  return 0;
+}
+
+extern "C" int hx_ppo_process_step(hx_ppo* s, const float* rew, const uint8_t* dones, const uint8_t* timeouts) {
+  const int N = s->cfg.num_envs, t = s->step;
+  if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }
+  hipLaunchKernelGGL(hx_process_step_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, rew, dones, timeouts,
+                     s->s_values + (size_t)t * N, s->cfg.gamma, N, s->s_rewards + (size_t)t * N, s->s_dones + (size_t)t * N);
+  HX_CHECK(hipGetLastError());
+  s->step += 1;
+  return 0;
+}
+
+extern "C" int hx_ppo_compute_returns(hx_ppo* s, const float* last_priv) {
+  const int N = s->cfg.num_envs, T = s->cfg.num_steps;
+  mlp_hidden_fwd(s, 1, last_priv, s->cfg.priv_ld, N, s->act_c);
+  hipLaunchKernelGGL(hx_value_head_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, s->act_c[2], s->cfg.critic_hidden[2],
+                     s->params + s->L[7].w, s->params + s->L[7].b, N, s->last_values);
+  HX_CHECK(hipMemsetAsync(s->moments, 0, 3 * sizeof(double), s->stream));
+  hipLaunchKernelGGL(hx_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, s->s_rewards, s->s_dones, s->s_values, s->last_values,
+                     T, N, s->cfg.gamma, s->cfg.lam, s->s_returns, s->s_adv_raw, s->moments);
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int hx_ppo_adv_moments(hx_ppo* s, void** m) { *m = s->moments; return 0; }
+extern "C" int hx_ppo_adv_normalize(hx_ppo* s) {
+  const size_t TN = (size_t)s->cfg.num_steps * s->cfg.num_envs;
+  hipLaunchKernelGGL(hx_adv_normalize_kernel, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, s->stream, s->s_adv_raw, s->moments, TN, s->s_adv);
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hx_ppo_update_begin(hx_ppo* s, const int32_t* perm) {
+  const int TN = s->cfg.num_steps * s->cfg.num_envs;
+  if (perm) HX_CHECK(hipMemcpyAsync(s->perm, perm, (size_t)TN * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
+  else hipLaunchKernelGGL(hx_perm_kernel, dim3((TN + 255) / 256), dim3(256), 0, s->stream, s->perm, TN, 0xA511E9B3u + 0x9E3779B9u * (s->perm_counter++));
+  SchedState z{};
+  // keep lr, clear the loss accumulators
+  HX_CHECK(hipMemsetAsync(&s->sched->vloss_sum, 0, 2 * sizeof(float), s->stream));
+  s->mb_done = 0;
+  s->mb_total = s->cfg.num_learning_epochs * s->cfg.num_mini_batches;
+  (void)z;
+  return 0;
+}
+
+extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_buffer, int64_t* count) {
+  const hx_ppo_cfg& c = s->cfg;
+  const int A = c.num_actions;
+  const int TN = c.num_steps * c.num_envs;
+  const int M = TN / c.num_mini_batches;
+  const int mb = mb_index % c.num_mini_batches;       // the permutation is reused by every epoch (rollout_storage.py:149,165)
+  hipStream_t st = s->stream;
+  GatherArgs ga{};
+  ga.idx = s->perm + (size_t)mb * M; ga.M = M;
+  ga.obs = s->s_obs; ga.obs_ld = c.obs_ld; ga.obs_mb = s->obs_mb;
+  ga.priv = s->s_priv; ga.priv_ld = c.priv_ld; ga.priv_mb = s->priv_mb;
+  ga.actions = s->s_actions; ga.mu = s->s_mu; ga.values = s->s_values; ga.returns = s->s_returns; ga.logp = s->s_logp; ga.adv = s->s_adv;
+  ga.A = A; ga.row_mb = s->row_mb;
+  hipLaunchKernelGGL(hx_gather_kernel, dim3(M), dim3(256), 0, st, ga);
+  // forward
+  mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a);
+  mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c);
+  // heads: losses + gradient into the third hidden layer
+  const int hw = c.actor_hidden[2];
+  const int hblocks = (M + HEAD_ROWS - 1) / HEAD_ROWS;
+  HeadArgs h{};
+  h.h3a = s->act_a[2]; h.h3c = s->act_c[2]; h.hw = hw;
+  h.W4 = s->params + s->L[3].w; h.b4 = s->params + s->L[3].b; h.W4c = s->params + s->L[7].w; h.b4c = s->params + s->L[7].b;
+  h.stdp = s->params + s->std_off; h.sigma_old = s->sigma_old; h.row_mb = s->row_mb; h.M = M; h.A = A;
+  h.clip = c.clip_param; h.vcoef = c.value_loss_coef; h.ecoef = c.entropy_coef; h.use_clipped_value_loss = c.use_clipped_value_loss;
+  h.dz3a = s->dz_a[2]; h.dz3c = s->dz_c[2]; h.slab = s->head_slab; h.slab_w = s->head_slab_w;
+  const size_t shm = (size_t)(2 * HEAD_ROWS * (hw + 1) + A * hw + hw + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
+  hipLaunchKernelGGL(hx_loss_head_kernel, dim3(hblocks), dim3(256), shm, st, h);
+  HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw};
+  hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab, hblocks, s->head_slab_w, s->grads, hs, (float)M);
+  // backward through the hidden layers of both networks
+  for (int net = 0; net < 2; ++net) {
+    const Layer* L = s->L + net * 4;
+    float** act = net ? s->act_c : s->act_a;
+    float** dz = net ? s->dz_c : s->dz_a;
+    const float* X = net ? s->priv_mb : s->obs_mb;
+    const int ldx = net ? c.priv_ld : c.obs_ld;
+    for (int l = 2; l >= 0; --l) {
+      const float* in = (l == 0) ? X : act[l - 1];
+      const int ld_in = (l == 0) ? ldx : L[l].in_ld;
+      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, s->slab, s->bias_slab);
+      const size_t cnt = (size_t)L[l].out * L[l].in_ld;
+      hipLaunchKernelGGL(hx_reduce_slabs_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, s->slab, splits, cnt, cnt, s->grads + L[l].w, 0);
+      hipLaunchKernelGGL(hx_reduce_slabs_kernel, dim3((L[l].out + 255) / 256), dim3(256), 0, st, s->bias_slab, splits, (size_t)L[l].out, (size_t)L[l].out, s->grads + L[l].b, 0);
+      if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out);
+    }
+  }
+  HX_CHECK(hipGetLastError());
+  if (grad_buffer) *grad_buffer = s->grads;
+  if (count) *count = (int64_t)s->padded + 4;
+  return 0;
+}
+
+extern "C" int hx_ppo_minibatch_step(hx_ppo* s, float inv_world) {
+  const hx_ppo_cfg& c = s->cfg;
+  hipStream_t st = s->stream;
+  // after an all-reduce(sum) the statistics are global sums, so kl_mean = kl_sum / rows is already world-wide
+  hipLaunchKernelGGL(hx_schedule_kernel, dim3(1), dim3(1), 0, st, s->grads + s->stats_off, c.adaptive_schedule, c.desired_kl, s->sched);
+  HX_CHECK(hipMemsetAsync(s->sumsq, 0, sizeof(double), st));
+  hipLaunchKernelGGL(hx_sumsq_kernel, dim3(256), dim3(256), 0, st, s->grads, s->padded, inv_world, s->sumsq);
+  s->adam_t += 1;
+  const float bc1 = 1.0f - (float)pow(0.9, (double)s->adam_t);
+  const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)s->adam_t));
+  hipLaunchKernelGGL(hx_adam_kernel, dim3((unsigned)((s->padded + 255) / 256)), dim3(256), 0, st, s->params, s->grads, s->m, s->v, s->padded,
+                     inv_world, s->sumsq, c.max_grad_norm, s->sched, bc1, bc2s);
+  HX_CHECK(hipGetLastError());
+  s->mb_done += 1;
+  return 0;
+}
+
+extern "C" int hx_ppo_update_end(hx_ppo* s, float* stats_h) {
+  SchedState st;
+  HX_CHECK(hipMemcpyAsync(&st, s->sched, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  const float n = (float)(s->mb_done > 0 ? s->mb_done : 1);
+  if (stats_h) { stats_h[0] = st.vloss_sum / n; stats_h[1] = st.sloss_sum / n; stats_h[2] = st.lr; stats_h[3] = st.last_kl; }
+  s->step = 0;       // storage.clear(), ppo.py:182
+  return 0;
+}
+
+extern "C" int hx_ppo_update(hx_ppo* s, const int32_t* perm, float* stats_h) {
+  int rc = hx_ppo_update_begin(s, perm); if (rc) return rc;
+  for (int i = 0; i < s->mb_total; ++i) {
+    rc = hx_ppo_minibatch_backward(s, i, nullptr, nullptr); if (rc) return rc;
+    rc = hx_ppo_minibatch_step(s, 1.0f); if (rc) return rc;
+  }
+  return hx_ppo_update_end(s, stats_h);
+}
+
+extern "C" int hx_ppo_buffer(hx_ppo* s, int which, void** d) {
+  switch (which) {
+    case HX_PPO_BUF_ACTIONS: *d = s->s_actions; break;
+    case HX_PPO_BUF_VALUES: *d = s->s_values; break;
+    case HX_PPO_BUF_LOGP: *d = s->s_logp; break;
+    case HX_PPO_BUF_MU: *d = s->s_mu; break;
+    case HX_PPO_BUF_REWARDS: *d = s->s_rewards; break;
+    case HX_PPO_BUF_RETURNS: *d = s->s_returns; break;
+    case HX_PPO_BUF_ADVANTAGES: *d = s->s_adv; break;
+    case HX_PPO_BUF_GRADS: *d = s->grads; break;
+    case HX_PPO_BUF_PERM: *d = s->perm; break;
+    default: hx_set_error("hx_ppo_buffer: unknown id"); return -2;
+  }
+  return 0;
+}
+extern "C" int hx_ppo_get_lr(hx_ppo* s, float* lr) {
+  SchedState st;
+  HX_CHECK(hipMemcpyAsync(&st, s->sched, sizeof(st), hipMemcpyDeviceToHost, s->stream));
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  *lr = st.lr; return 0;
+}
+extern "C" int hx_ppo_set_lr(hx_ppo* s, float lr) {
+  HX_CHECK(hipMemcpyAsync(&s->sched->lr, &lr, sizeof(float), hipMemcpyHostToDevice, s->stream));
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* out) {
+  if (rows > s->Mmax) { hx_set_error("hx_ppo_inference: rows > workspace"); return -2; }
+  mlp_hidden_fwd(s, 0, obs, s->cfg.obs_ld, rows, s->act_a);
+  const int A = s->cfg.num_actions;
+  hipLaunchKernelGGL(hx_mean_head_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, s->stream, s->act_a[2], s->cfg.actor_hidden[2],
+                     s->params + s->L[3].w, s->params + s->L[3].b, rows, A, out);
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
+  if (which == 1) {
+    if (s->ev.empty()) { s->ev.resize(8192); for (auto& e : s->ev) HX_CHECK(hipEventCreate(&e)); }
+    s->ev_used = 0; s->prof_flops = 0; s->prof_launches = 0; s->prof = true;
+    return 0;
+  }
+  s->prof = false;
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  double ms = 0;
+  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); ms += t; }
+  if (out) { out[0] = ms; out[1] = (double)s->prof_launches; out[2] = s->prof_flops; }
+  return 0;
+}
+
+// ---- device memory helpers
+extern "C" int hx_malloc(size_t bytes, void** out) { HX_CHECK(hipMalloc(out, bytes)); HX_CHECK(hipMemset(*out, 0, bytes)); return 0; }
+extern "C" int hx_free(void* p) { HX_CHECK(hipFree(p)); return 0; }
+extern "C" int hx_memcpy_h2d(void* d, const void* s, size_t b, void* st) {
+  if (st) HX_CHECK(hipStreamSynchronize((hipStream_t)st));
+  HX_CHECK(hipMemcpy(d, s, b, hipMemcpyHostToDevice)); return 0;
+}
+extern "C" int hx_memcpy_d2h(void* d, const void* s, size_t b, void* st) {
+  if (st) HX_CHECK(hipStreamSynchronize((hipStream_t)st));
+  HX_CHECK(hipMemcpy(d, s, b, hipMemcpyDeviceToHost)); return 0;
+}
+extern "C" int hx_memcpy_d2d(void* d, const void* s, size_t b, void* st) { HX_CHECK(hipMemcpyAsync(d, s, b, hipMemcpyDeviceToDevice, (hipStream_t)st)); return 0; }
+extern "C" int hx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+extern "C" int hx_set_device(int i) { HX_CHECK(hipSetDevice(i)); return 0; }

@@ -1,0 +1,708 @@
+// hx_sim.hip -- the hector environment step as ONE kernel launch per env step (+ one coalesced
+// frame-stack kernel), and its C ABI (include/hx_sim.h).
+//
+// Restates, per lane (= one environment), the arithmetic of the reference's
+//   HectorFreeEnv.step            humanoid/envs/custom/hector_env.py:158-169
+//   LeggedRobot.step              humanoid/envs/base/legged_robot.py:84-108
+//   LeggedRobot.post_physics_step legged_robot.py:118-153 (+ callback :303-335, termination :155-160,
+//                                 rewards hector_env.py:277-539 in dir() order, reset :162-214 / :256-261,
+//                                 observations hector_env.py:172-254)
+// with the ten `gym.simulate` substeps (legged_robot.py:93-100) replaced by hx_dyn.h.
+// State is SoA in HBM: field-major [field][env], so every load/store of a wave is one coalesced line.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/hx_sim.h"
+#include "hx_dyn.h"
+#include "hx_common.h"
+
+// ---------------------------------------------------------------- state layout (floats per env)
+enum {
+  S_ROOT_POS = 0, S_ROOT_QUAT = 3, S_LINVEL = 7, S_ANGVEL = 10, S_Q = 13, S_QD = 23,
+  S_ACT = 33, S_LAST_ACT = 43, S_LAST_LAST_ACT = 53, S_LAST_DOF_VEL = 63, S_LAST_ROOT_VEL = 73,
+  S_CMD = 79, S_AIR = 83, S_LAST_CONTACT = 85, S_FEET_H = 87, S_LAST_FEET_Z = 89, S_PUSH_F = 91,
+  S_PUSH_T = 93, S_FRICTION = 96, S_BASE_MASS = 97, S_ORIGIN = 98, S_BLV = 101, S_BAV = 104,
+  S_STATE_SIZE = 107
+};
+
+struct SimPtrs {
+  float* st;          // [S_STATE_SIZE][N]
+  int* ep_len;        // [N]
+  float* ep_sums;     // [HX_NUM_REWARDS][N]
+  float* torques;     // [10][N]
+  float* contact;     // [33][N]
+  float* bodies;      // [52][N]
+  float* obs_frame;   // [41][N]
+  float* priv_frame;  // [70][N]
+  float* rew;         // [N]
+  unsigned char* reset;    // [N]
+  unsigned char* timeout;  // [N]
+  int* num_reset;     // [1]
+  float* stat_sum;    // [HX_NUM_REWARDS] sums of episode sums of envs that reset
+  int* stat_cnt;      // [1]
+};
+
+// ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
+__device__ __forceinline__ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Rng {
+  const float* pack;   // injected [HX_RP_SIZE][N] or nullptr
+  int n, env;
+  uint32_t k0, k1, step;
+  __device__ __forceinline__ float uni(int field) const {
+    if (pack) return pack[(size_t)field * n + env];
+    uint32_t o[4];
+    philox4(k0, k1, (uint32_t)env, step, (uint32_t)field, 0u, o);
+    return (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+  }
+  __device__ __forceinline__ float nrm(int field) const {
+    if (pack) return pack[(size_t)field * n + env];
+    uint32_t o[4];
+    philox4(k0, k1, (uint32_t)env, step, (uint32_t)field, 1u, o);
+    const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);   // (0,1]
+    const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  }
+};
+
+// ---------------------------------------------------------------- small helpers (xyzw quaternions)
+__device__ __forceinline__ V3 quat_rotate_inverse(const float* q, V3 v) {
+  const float qw = q[3];
+  const V3 qv = mk(q[0], q[1], q[2]);
+  const V3 a = (2.0f * qw * qw - 1.0f) * v;
+  const V3 b = (2.0f * qw) * cross(qv, v);
+  const V3 c = (2.0f * dot(qv, v)) * qv;
+  return a - b + c;
+}
+__device__ __forceinline__ V3 quat_apply(const float* q, V3 v) {
+  const V3 xyz = mk(q[0], q[1], q[2]);
+  const V3 t = 2.0f * cross(xyz, v);
+  return v + q[3] * t + cross(xyz, t);
+}
+__device__ __forceinline__ float pymod(float a, float m) { float r = fmodf(a, m); return (r < 0.f) ? r + m : r; }
+__device__ __forceinline__ V3 euler_xyz_wrapped(const float* q) {
+  const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  const float TWO_PI = 6.283185307179586f, PI = 3.141592653589793f;
+  float roll = atan2f(2.0f * (qw * qx + qy * qz), qw * qw - qx * qx - qy * qy + qz * qz);
+  const float sinp = 2.0f * (qw * qy - qz * qx);
+  float pitch = (fabsf(sinp) >= 1.0f) ? copysignf(1.5707963267948966f, sinp) : asinf(sinp);
+  float yaw = atan2f(2.0f * (qw * qz + qx * qy), qw * qw + qx * qx - qy * qy - qz * qz);
+  V3 e = mk(pymod(roll, TWO_PI), pymod(pitch, TWO_PI), pymod(yaw, TWO_PI));
+  if (e.x > PI) e.x -= TWO_PI;
+  if (e.y > PI) e.y -= TWO_PI;
+  if (e.z > PI) e.z -= TWO_PI;
+  return e;
+}
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+struct StepArgs {
+  int mode;                  // 0: step, 1: constructor reset (reset all + first observation)
+  long long step_counter;    // common_step_counter AFTER the increment of this step
+  uint32_t k0, k1, rng_step;
+};
+
+#define LD(f) (p.st[(size_t)(f) * n + e])
+#define ST(f, val) (p.st[(size_t)(f) * n + e] = (val))
+
+__global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg cfg, const float* __restrict__ actions,
+                                                         const float* __restrict__ pack, StepArgs A) {
+  const int n = cfg.num_envs;
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= n) return;
+  Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
+
+  // ---- load state
+  DynState S;
+  S.pos = mk(LD(S_ROOT_POS), LD(S_ROOT_POS + 1), LD(S_ROOT_POS + 2));
+  for (int i = 0; i < 4; ++i) S.quat[i] = LD(S_ROOT_QUAT + i);
+  S.linvel = mk(LD(S_LINVEL), LD(S_LINVEL + 1), LD(S_LINVEL + 2));
+  S.angvel = mk(LD(S_ANGVEL), LD(S_ANGVEL + 1), LD(S_ANGVEL + 2));
+  for (int j = 0; j < 10; ++j) { S.q[j] = LD(S_Q + j); S.qd[j] = LD(S_QD + j); }
+  float act[10], last_act[10], last_last_act[10], last_dof_vel[10], last_root_vel[6], cmd[4];
+  for (int j = 0; j < 10; ++j) { act[j] = LD(S_ACT + j); last_act[j] = LD(S_LAST_ACT + j); last_last_act[j] = LD(S_LAST_LAST_ACT + j); last_dof_vel[j] = LD(S_LAST_DOF_VEL + j); }
+  for (int j = 0; j < 6; ++j) last_root_vel[j] = LD(S_LAST_ROOT_VEL + j);
+  for (int j = 0; j < 4; ++j) cmd[j] = LD(S_CMD + j);
+  float air[2] = {LD(S_AIR), LD(S_AIR + 1)};
+  float last_contact[2] = {LD(S_LAST_CONTACT), LD(S_LAST_CONTACT + 1)};
+  float feet_h[2] = {LD(S_FEET_H), LD(S_FEET_H + 1)};
+  float last_feet_z[2] = {LD(S_LAST_FEET_Z), LD(S_LAST_FEET_Z + 1)};
+  float push_f[2] = {LD(S_PUSH_F), LD(S_PUSH_F + 1)};
+  float push_t[3] = {LD(S_PUSH_T), LD(S_PUSH_T + 1), LD(S_PUSH_T + 2)};
+  const float friction = LD(S_FRICTION), base_mass = LD(S_BASE_MASS);
+  const V3 origin = mk(LD(S_ORIGIN), LD(S_ORIGIN + 1), LD(S_ORIGIN + 2));
+  V3 base_lin_vel = mk(LD(S_BLV), LD(S_BLV + 1), LD(S_BLV + 2));
+  V3 base_ang_vel = mk(LD(S_BAV), LD(S_BAV + 1), LD(S_BAV + 2));
+  int ep_len = p.ep_len[e];
+
+  float torques[10];
+  for (int j = 0; j < 10; ++j) torques[j] = 0.f;
+  V3 shape_force[5];
+  for (int i = 0; i < 5; ++i) shape_force[i] = mk(0, 0, 0);
+  BodyOut bo[4];
+  bool reset = false, time_out = false;
+  float rew_total = 0.f;
+
+  if (A.mode == 0) {
+    // ---- hector_env.py:158-169 : clip, delay blend, multiplicative noise ; legged_robot.py:90-91 clip
+    float a[10];
+    const float delay = rng.uni(HX_RP_DELAY) * cfg.action_delay;
+    for (int j = 0; j < 10; ++j) {
+      float x = clampf(actions[(size_t)e * 10 + j], -cfg.clip_actions, cfg.clip_actions);
+      x = (1.0f - delay) * x + delay * act[j];
+      x = x + cfg.action_noise * rng.nrm(HX_RP_ACT_NOISE + j) * x;
+      a[j] = clampf(x, -cfg.clip_actions, cfg.clip_actions);
+    }
+    for (int j = 0; j < 10; ++j) act[j] = a[j];
+    // ---- legged_robot.py:93-100 : decimation x {PD torque, simulate}
+    DynParams P;
+    P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
+    P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
+    float target[10];
+    for (int j = 0; j < 10; ++j) target[j] = act[j] * cfg.action_scale + cfg.default_dof_pos[j];
+    const float mass_scale = base_mass / HXM_MASS[0];
+#pragma unroll 1
+    for (int sub = 0; sub < cfg.decimation; ++sub)
+      dyn_substep(S, P, target, cfg.p_gains, cfg.d_gains, cfg.torque_limits, mass_scale, torques,
+                  sub == cfg.decimation - 1, shape_force);
+  }
+  // rigid_body_state of knees/feet (post-step pose; at construction: the actor creation pose)
+  dyn_body_states(S, bo);
+
+  const float TWO_PI = 6.283185307179586f;
+  V3 euler, pgrav;
+  if (A.mode == 0) {
+    // ---- post_physics_step (legged_robot.py:127-135)
+    ep_len += 1;
+    base_lin_vel = quat_rotate_inverse(S.quat, S.linvel);
+    base_ang_vel = quat_rotate_inverse(S.quat, S.angvel);
+    pgrav = quat_rotate_inverse(S.quat, mk(0.f, 0.f, -1.f));
+    euler = euler_xyz_wrapped(S.quat);
+    // ---- callback (legged_robot.py:303-319)
+    if (ep_len % cfg.resample_interval == 0) {
+      cmd[0] = (cfg.cmd_range[0][1] - cfg.cmd_range[0][0]) * rng.uni(HX_RP_CMD_A) + cfg.cmd_range[0][0];
+      cmd[1] = (cfg.cmd_range[1][1] - cfg.cmd_range[1][0]) * rng.uni(HX_RP_CMD_A + 1) + cfg.cmd_range[1][0];
+      if (cfg.heading_command) cmd[3] = (cfg.cmd_range[3][1] - cfg.cmd_range[3][0]) * rng.uni(HX_RP_CMD_A + 2) + cfg.cmd_range[3][0];
+      else cmd[2] = (cfg.cmd_range[2][1] - cfg.cmd_range[2][0]) * rng.uni(HX_RP_CMD_A + 2) + cfg.cmd_range[2][0];
+      const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.f : 0.f;
+      cmd[0] *= keep; cmd[1] *= keep;
+    }
+    if (cfg.heading_command) {
+      const V3 fwd = quat_apply(S.quat, mk(1.f, 0.f, 0.f));
+      const float heading = atan2f(fwd.y, fwd.x);
+      float w = pymod(cmd[3] - heading, TWO_PI);
+      if (w > 3.141592653589793f) w -= TWO_PI;
+      cmd[2] = clampf(0.5f * w, -1.f, 1.f);
+    }
+    if (cfg.push_robots && (A.step_counter % cfg.push_interval == 0)) {
+      // hector_env.py:53-68 : overwrite base velocities of every env
+      push_f[0] = 2.f * cfg.max_push_vel_xy * rng.uni(HX_RP_PUSH) - cfg.max_push_vel_xy;
+      push_f[1] = 2.f * cfg.max_push_vel_xy * rng.uni(HX_RP_PUSH + 1) - cfg.max_push_vel_xy;
+      S.linvel.x = push_f[0]; S.linvel.y = push_f[1];
+      for (int k = 0; k < 3; ++k) push_t[k] = 2.f * cfg.max_push_ang_vel * rng.uni(HX_RP_PUSH + 2 + k) - cfg.max_push_ang_vel;
+      S.angvel = mk(push_t[0], push_t[1], push_t[2]);
+    }
+  } else {
+    pgrav = mk(0, 0, -1); euler = mk(0, 0, 0);
+  }
+
+  // contact forces per body (world): only shape bodies can be non-zero
+  const V3 f_base = shape_force[0], f_lthigh = shape_force[1], f_ltoe = shape_force[2], f_rthigh = shape_force[3], f_rtoe = shape_force[4];
+  const V3 foot_f[2] = {f_ltoe, f_rtoe};
+  const V3 foot_pos[2] = {bo[1].pos, bo[3].pos}, foot_vel[2] = {bo[1].linvel, bo[3].linvel};
+  const V3 knee_pos[2] = {bo[0].pos, bo[2].pos};
+  bool contact[2] = {foot_f[0].z > 5.0f, foot_f[1].z > 5.0f};
+
+  auto stance_mask = [&](int len, float* sm) {
+    const float phase = (float)len * cfg.env_dt / cfg.cycle_time;
+    const float sp = sinf(TWO_PI * phase);
+    sm[0] = (sp >= 0.f) ? 1.f : 0.f;
+    sm[1] = (sp < 0.f) ? 1.f : 0.f;
+    if (fabsf(sp) < 0.1f) { sm[0] = 1.f; sm[1] = 1.f; }
+  };
+
+  if (A.mode == 0) {
+    // ---- termination (legged_robot.py:155-160)
+    const float nb = sqrtf(dot(f_base, f_base)), nl = sqrtf(dot(f_lthigh, f_lthigh)), nr = sqrtf(dot(f_rthigh, f_rthigh));
+    reset = (nb > 1.0f) || (nl > 1.0f) || (nr > 1.0f);
+    time_out = (float)ep_len > cfg.max_episode_length;
+    reset = reset || time_out;
+
+    // ---- rewards, alphabetical order (legged_robot.py:216-234 ; functions hector_env.py:264-539)
+    float sm[2];
+    stance_mask(ep_len, sm);
+    float dq0[10];
+    for (int j = 0; j < 10; ++j) dq0[j] = S.q[j] - cfg.default_dof_pos[j];
+    const float* sc = cfg.reward_scale;
+    float rsum = 0.f;
+    auto add = [&](int id, float r) {
+      const float x = r * sc[id];
+      rsum += x;
+      p.ep_sums[(size_t)id * n + e] += x;
+    };
+    if (sc[HX_R_ACTION_SMOOTHNESS] != 0.f) {
+      float t1 = 0, t2 = 0, t3 = 0;
+      for (int j = 0; j < 10; ++j) {
+        const float d1 = last_act[j] - act[j]; t1 += d1 * d1;
+        const float d2 = act[j] + last_last_act[j] - 2.f * last_act[j]; t2 += d2 * d2;
+        t3 += fabsf(act[j]);
+      }
+      add(HX_R_ACTION_SMOOTHNESS, t1 + t2 + 0.05f * t3);
+    }
+    if (sc[HX_R_BASE_ACC] != 0.f) {
+      const float d[6] = {last_root_vel[0] - S.linvel.x, last_root_vel[1] - S.linvel.y, last_root_vel[2] - S.linvel.z,
+                          last_root_vel[3] - S.angvel.x, last_root_vel[4] - S.angvel.y, last_root_vel[5] - S.angvel.z};
+      float s2 = 0; for (int k = 0; k < 6; ++k) s2 += d[k] * d[k];
+      add(HX_R_BASE_ACC, expf(-sqrtf(s2) * 3.f));
+    }
+    if (sc[HX_R_BASE_HEIGHT] != 0.f) {
+      const float mh = (foot_pos[0].z * sm[0] + foot_pos[1].z * sm[1]) / (sm[0] + sm[1]);
+      const float bh = S.pos.z - (mh - 0.05f);
+      add(HX_R_BASE_HEIGHT, expf(-fabsf(bh - cfg.base_height_target) * 100.f));
+    }
+    if (sc[HX_R_COLLISION] != 0.f)
+      add(HX_R_COLLISION, (nb > 0.1f ? 1.f : 0.f) + (nl > 0.1f ? 1.f : 0.f) + (nr > 0.1f ? 1.f : 0.f));
+    if (sc[HX_R_DEFAULT_JOINT_POS] != 0.f) {
+      float yr = sqrtf(dq0[0] * dq0[0] + dq0[1] * dq0[1]) + sqrtf(dq0[5] * dq0[5] + dq0[6] * dq0[6]);
+      yr = clampf(yr - 0.1f, 0.f, 50.f);
+      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += dq0[j] * dq0[j];
+      add(HX_R_DEFAULT_JOINT_POS, expf(-yr * 100.f) - 0.01f * sqrtf(s2));
+    }
+    if (sc[HX_R_DOF_ACC] != 0.f) {
+      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = (last_dof_vel[j] - S.qd[j]) / cfg.env_dt; s2 += d * d; }
+      add(HX_R_DOF_ACC, s2);
+    }
+    if (sc[HX_R_DOF_VEL] != 0.f) {
+      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += S.qd[j] * S.qd[j];
+      add(HX_R_DOF_VEL, s2);
+    }
+    if (sc[HX_R_FEET_AIR_TIME] != 0.f) {
+      float r = 0;
+      for (int k = 0; k < 2; ++k) {
+        const bool filt = contact[k] || (sm[k] > 0.f) || (last_contact[k] != 0.f);
+        last_contact[k] = contact[k] ? 1.f : 0.f;
+        const float first = ((air[k] > 0.f) && filt) ? 1.f : 0.f;
+        air[k] += cfg.env_dt;
+        r += clampf(air[k], 0.f, 0.5f) * first;
+        air[k] *= filt ? 0.f : 1.f;
+      }
+      add(HX_R_FEET_AIR_TIME, r);
+    }
+    if (sc[HX_R_FEET_CLEARANCE] != 0.f) {
+      float r = 0;
+      for (int k = 0; k < 2; ++k) {
+        const float fz = foot_pos[k].z - 0.05f;
+        feet_h[k] += fz - last_feet_z[k];
+        last_feet_z[k] = fz;
+        const float swing = 1.f - sm[k];
+        r += ((fabsf(feet_h[k] - cfg.target_feet_height) < 0.01f) ? 1.f : 0.f) * swing;
+        feet_h[k] *= contact[k] ? 0.f : 1.f;
+      }
+      add(HX_R_FEET_CLEARANCE, r);
+    }
+    if (sc[HX_R_FEET_CONTACT_FORCES] != 0.f) {
+      float r = 0;
+      for (int k = 0; k < 2; ++k) r += clampf(sqrtf(dot(foot_f[k], foot_f[k])) - cfg.max_contact_force, 0.f, 400.f);
+      add(HX_R_FEET_CONTACT_FORCES, r);
+    }
+    if (sc[HX_R_FEET_CONTACT_NUMBER] != 0.f) {
+      float r = 0;
+      for (int k = 0; k < 2; ++k) r += ((contact[k] ? 1.f : 0.f) == sm[k]) ? 1.f : -0.3f;
+      add(HX_R_FEET_CONTACT_NUMBER, r / 2.f);
+    }
+    auto dist_rew = [&](V3 a, V3 b, float maxd) {
+      const float dx = a.x - b.x, dy = a.y - b.y;
+      const float d = sqrtf(dx * dx + dy * dy);
+      const float dmin = clampf(d - cfg.min_dist, -0.5f, 0.f), dmax = clampf(d - maxd, 0.f, 0.5f);
+      return (expf(-fabsf(dmin) * 100.f) + expf(-fabsf(dmax) * 100.f)) / 2.f;
+    };
+    if (sc[HX_R_FEET_DISTANCE] != 0.f) add(HX_R_FEET_DISTANCE, dist_rew(foot_pos[0], foot_pos[1], cfg.max_dist));
+    if (sc[HX_R_FOOT_SLIP] != 0.f) {
+      float r = 0;
+      for (int k = 0; k < 2; ++k) r += sqrtf(sqrtf(foot_vel[k].x * foot_vel[k].x + foot_vel[k].y * foot_vel[k].y)) * (contact[k] ? 1.f : 0.f);
+      add(HX_R_FOOT_SLIP, r);
+    }
+    if (sc[HX_R_JOINT_POS] != 0.f) {
+      // hector_env.py:264-275 with compute_ref_state :90-111 (reference pose uses the phase of the PREVIOUS
+      // compute_observations call; this term is zero-scaled in HectorCfg)
+      const float phase = (float)(ep_len) * cfg.env_dt / cfg.cycle_time;
+      const float sp = sinf(TWO_PI * phase);
+      float ref[10]; for (int j = 0; j < 10; ++j) ref[j] = 0.f;
+      const float s1 = cfg.target_joint_pos_scale, s2c = 2.f * s1;
+      const float l = sp > 0.f ? 0.f : sp, r_ = sp < 0.f ? 0.f : sp;
+      ref[2] = l * s1; ref[3] = l * s2c; ref[4] = l * s1; ref[7] = r_ * s1; ref[8] = r_ * s2c; ref[9] = r_ * s1;
+      if (fabsf(sp) < 0.1f) for (int j = 0; j < 10; ++j) ref[j] = 0.f;
+      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = S.q[j] - ref[j]; s2 += d * d; }
+      const float nn = sqrtf(s2);
+      add(HX_R_JOINT_POS, expf(-2.f * nn) - 0.2f * clampf(nn, 0.f, 0.5f));
+    }
+    if (sc[HX_R_KNEE_DISTANCE] != 0.f) add(HX_R_KNEE_DISTANCE, dist_rew(knee_pos[0], knee_pos[1], cfg.max_dist / 2.f));
+    if (sc[HX_R_LOW_SPEED] != 0.f) {
+      const float as = fabsf(base_lin_vel.x), ac = fabsf(cmd[0]);
+      const bool low = as < 0.5f * ac, high = as > 1.2f * ac;
+      float r = 0.f;
+      if (low) r = -1.f;
+      if (high) r = 0.f;
+      if (!(low || high)) r = 1.2f;
+      const float sa = (base_lin_vel.x > 0.f) - (base_lin_vel.x < 0.f), sb = (cmd[0] > 0.f) - (cmd[0] < 0.f);
+      if (sa != sb) r = -2.f;
+      add(HX_R_LOW_SPEED, r * (fabsf(cmd[0]) > 0.1f ? 1.f : 0.f));
+    }
+    if (sc[HX_R_ORIENTATION] != 0.f) {
+      const float a1 = expf(-(fabsf(euler.x) + fabsf(euler.y)) * 10.f);
+      const float b1 = expf(-sqrtf(pgrav.x * pgrav.x + pgrav.y * pgrav.y) * 20.f);
+      add(HX_R_ORIENTATION, (a1 + b1) / 2.f);
+    }
+    if (sc[HX_R_TORQUES] != 0.f) {
+      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += torques[j] * torques[j];
+      add(HX_R_TORQUES, s2);
+    }
+    if (sc[HX_R_TRACK_VEL_HARD] != 0.f) {
+      const float dx = cmd[0] - base_lin_vel.x, dy = cmd[1] - base_lin_vel.y;
+      const float le = sqrtf(dx * dx + dy * dy), ae = fabsf(cmd[2] - base_ang_vel.z);
+      add(HX_R_TRACK_VEL_HARD, (expf(-le * 10.f) + expf(-ae * 10.f)) / 2.f - 0.2f * (le + ae));
+    }
+    if (sc[HX_R_TRACKING_ANG_VEL] != 0.f) {
+      const float d = cmd[2] - base_ang_vel.z;
+      add(HX_R_TRACKING_ANG_VEL, expf(-(d * d) * cfg.tracking_sigma));
+    }
+    if (sc[HX_R_TRACKING_LIN_VEL] != 0.f) {
+      const float dx = cmd[0] - base_lin_vel.x, dy = cmd[1] - base_lin_vel.y;
+      add(HX_R_TRACKING_LIN_VEL, expf(-(dx * dx + dy * dy) * cfg.tracking_sigma));
+    }
+    if (sc[HX_R_VEL_MISMATCH_EXP] != 0.f) {
+      const float lm = expf(-(base_lin_vel.z * base_lin_vel.z) * 10.f);
+      const float am = expf(-sqrtf(base_ang_vel.x * base_ang_vel.x + base_ang_vel.y * base_ang_vel.y) * 5.f);
+      add(HX_R_VEL_MISMATCH_EXP, (lm + am) / 2.f);
+    }
+    rew_total = cfg.only_positive_rewards ? fmaxf(rsum, 0.f) : rsum;
+  } else {
+    reset = true;
+  }
+
+  // ---- reset_idx (legged_robot.py:162-214 ; hector_env.py:256-261)
+  if (reset) {
+    for (int j = 0; j < 10; ++j) {
+      S.q[j] = cfg.default_dof_pos[j] + (0.3f * rng.uni(HX_RP_RESET_Q + j) - 0.15f);
+      S.qd[j] = 0.f;
+    }
+    S.pos = mk(cfg.base_init_state[0] + origin.x, cfg.base_init_state[1] + origin.y, cfg.base_init_state[2] + origin.z);
+    if (cfg.custom_origins) {
+      S.pos.x += 2.f * rng.uni(HX_RP_RESET_XY) - 1.f;
+      S.pos.y += 2.f * rng.uni(HX_RP_RESET_XY + 1) - 1.f;
+    }
+    for (int k = 0; k < 4; ++k) S.quat[k] = cfg.base_init_state[3 + k];
+    S.linvel = mk(cfg.base_init_state[7], cfg.base_init_state[8], cfg.base_init_state[9]);
+    S.angvel = mk(cfg.base_init_state[10], cfg.base_init_state[11], cfg.base_init_state[12]);
+    cmd[0] = (cfg.cmd_range[0][1] - cfg.cmd_range[0][0]) * rng.uni(HX_RP_CMD_B) + cfg.cmd_range[0][0];
+    cmd[1] = (cfg.cmd_range[1][1] - cfg.cmd_range[1][0]) * rng.uni(HX_RP_CMD_B + 1) + cfg.cmd_range[1][0];
+    if (cfg.heading_command) cmd[3] = (cfg.cmd_range[3][1] - cfg.cmd_range[3][0]) * rng.uni(HX_RP_CMD_B + 2) + cfg.cmd_range[3][0];
+    else cmd[2] = (cfg.cmd_range[2][1] - cfg.cmd_range[2][0]) * rng.uni(HX_RP_CMD_B + 2) + cfg.cmd_range[2][0];
+    const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.f : 0.f;
+    cmd[0] *= keep; cmd[1] *= keep;
+    for (int j = 0; j < 10; ++j) { act[j] = 0.f; last_act[j] = 0.f; last_last_act[j] = 0.f; last_dof_vel[j] = 0.f; }
+    air[0] = 0.f; air[1] = 0.f;
+    ep_len = 0;
+    for (int r = 0; r < HX_NUM_REWARDS; ++r) {
+      const float s = p.ep_sums[(size_t)r * n + e];
+      if (A.mode == 0 && s != 0.f) atomicAdd(&p.stat_sum[r], s);
+      p.ep_sums[(size_t)r * n + e] = 0.f;
+    }
+    if (A.mode == 0) {
+      atomicAdd(p.stat_cnt, 1);
+      atomicAdd(p.num_reset, 1);
+    }
+    euler = euler_xyz_wrapped(S.quat);
+    pgrav = quat_rotate_inverse(S.quat, mk(0.f, 0.f, -1.f));
+  }
+
+  // ---- compute_observations (hector_env.py:172-254) : newest 41 / 70 frame only; stacking is hx_stack_kernel
+  {
+    const float phase = (float)ep_len * cfg.env_dt / cfg.cycle_time;
+    const float sp = sinf(TWO_PI * phase), cp = cosf(TWO_PI * phase);
+    float sm[2];
+    stance_mask(ep_len, sm);
+    float f[HX_PRIV_FRAME];
+    f[0] = sp; f[1] = cp;
+    f[2] = cmd[0] * cfg.obs_scale_lin_vel; f[3] = cmd[1] * cfg.obs_scale_lin_vel; f[4] = cmd[2] * cfg.obs_scale_ang_vel;
+    for (int j = 0; j < 10; ++j) {
+      f[5 + j] = (S.q[j] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos;
+      f[15 + j] = S.qd[j] * cfg.obs_scale_dof_vel;
+      f[25 + j] = act[j];
+    }
+    // obs41 = [cmd5, q10, dq10, a10, ang_vel3, euler3]
+    float o[HX_OBS_FRAME];
+    for (int k = 0; k < 35; ++k) o[k] = f[k];
+    o[35] = base_ang_vel.x * cfg.obs_scale_ang_vel; o[36] = base_ang_vel.y * cfg.obs_scale_ang_vel; o[37] = base_ang_vel.z * cfg.obs_scale_ang_vel;
+    o[38] = euler.x * cfg.obs_scale_quat; o[39] = euler.y * cfg.obs_scale_quat; o[40] = euler.z * cfg.obs_scale_quat;
+    if (cfg.add_noise)
+      for (int k = 0; k < HX_OBS_FRAME; ++k) {
+        const float sv = cfg.noise_scale_vec[k];
+        if (sv != 0.f) o[k] = o[k] + rng.nrm(HX_RP_OBS_NOISE + k) * sv * cfg.noise_level;
+      }
+    for (int k = 0; k < HX_OBS_FRAME; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
+    f[35] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[36] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[37] = base_lin_vel.z * cfg.obs_scale_lin_vel;
+    f[38] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[39] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[40] = base_ang_vel.z * cfg.obs_scale_ang_vel;
+    f[41] = euler.x * cfg.obs_scale_quat; f[42] = euler.y * cfg.obs_scale_quat; f[43] = euler.z * cfg.obs_scale_quat;
+    f[44] = foot_pos[0].x; f[45] = foot_pos[0].y; f[46] = foot_pos[0].z; f[47] = foot_pos[1].x; f[48] = foot_pos[1].y; f[49] = foot_pos[1].z;
+    f[50] = foot_vel[0].x; f[51] = foot_vel[0].y; f[52] = foot_vel[0].z; f[53] = foot_vel[1].x; f[54] = foot_vel[1].y; f[55] = foot_vel[1].z;
+    f[56] = S.pos.x; f[57] = S.pos.y; f[58] = S.pos.z;
+    f[59] = push_f[0]; f[60] = push_f[1]; f[61] = push_t[0]; f[62] = push_t[1]; f[63] = push_t[2];
+    f[64] = friction; f[65] = base_mass / 30.f;
+    f[66] = sm[0]; f[67] = sm[1]; f[68] = contact[0] ? 1.f : 0.f; f[69] = contact[1] ? 1.f : 0.f;
+    for (int k = 0; k < HX_PRIV_FRAME; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+  }
+
+  // ---- bookkeeping (legged_robot.py:146-150) and store
+  if (A.mode == 0) {
+    for (int j = 0; j < 10; ++j) { last_last_act[j] = last_act[j]; last_act[j] = act[j]; last_dof_vel[j] = S.qd[j]; }
+    last_root_vel[0] = S.linvel.x; last_root_vel[1] = S.linvel.y; last_root_vel[2] = S.linvel.z;
+    last_root_vel[3] = S.angvel.x; last_root_vel[4] = S.angvel.y; last_root_vel[5] = S.angvel.z;
+  }
+  ST(S_ROOT_POS, S.pos.x); ST(S_ROOT_POS + 1, S.pos.y); ST(S_ROOT_POS + 2, S.pos.z);
+  for (int i = 0; i < 4; ++i) ST(S_ROOT_QUAT + i, S.quat[i]);
+  ST(S_LINVEL, S.linvel.x); ST(S_LINVEL + 1, S.linvel.y); ST(S_LINVEL + 2, S.linvel.z);
+  ST(S_ANGVEL, S.angvel.x); ST(S_ANGVEL + 1, S.angvel.y); ST(S_ANGVEL + 2, S.angvel.z);
+  for (int j = 0; j < 10; ++j) {
+    ST(S_Q + j, S.q[j]); ST(S_QD + j, S.qd[j]); ST(S_ACT + j, act[j]); ST(S_LAST_ACT + j, last_act[j]);
+    ST(S_LAST_LAST_ACT + j, last_last_act[j]); ST(S_LAST_DOF_VEL + j, last_dof_vel[j]);
+    p.torques[(size_t)j * n + e] = torques[j];
+  }
+  for (int j = 0; j < 6; ++j) ST(S_LAST_ROOT_VEL + j, last_root_vel[j]);
+  for (int j = 0; j < 4; ++j) ST(S_CMD + j, cmd[j]);
+  ST(S_AIR, air[0]); ST(S_AIR + 1, air[1]); ST(S_LAST_CONTACT, last_contact[0]); ST(S_LAST_CONTACT + 1, last_contact[1]);
+  ST(S_FEET_H, feet_h[0]); ST(S_FEET_H + 1, feet_h[1]); ST(S_LAST_FEET_Z, last_feet_z[0]); ST(S_LAST_FEET_Z + 1, last_feet_z[1]);
+  ST(S_PUSH_F, push_f[0]); ST(S_PUSH_F + 1, push_f[1]); ST(S_PUSH_T, push_t[0]); ST(S_PUSH_T + 1, push_t[1]); ST(S_PUSH_T + 2, push_t[2]);
+  ST(S_BLV, base_lin_vel.x); ST(S_BLV + 1, base_lin_vel.y); ST(S_BLV + 2, base_lin_vel.z);
+  ST(S_BAV, base_ang_vel.x); ST(S_BAV + 1, base_ang_vel.y); ST(S_BAV + 2, base_ang_vel.z);
+  p.ep_len[e] = ep_len;
+  p.rew[e] = rew_total;
+  p.reset[e] = reset ? 1 : 0;
+  p.timeout[e] = time_out ? 1 : 0;
+  // diagnostic tensors (contact_forces / rigid_state views of the reference)
+  const int shape_body[5] = {0, 3, 5, 8, 10};
+  for (int s = 0; s < 5; ++s) {
+    p.contact[(size_t)(shape_body[s] * 3 + 0) * n + e] = shape_force[s].x;
+    p.contact[(size_t)(shape_body[s] * 3 + 1) * n + e] = shape_force[s].y;
+    p.contact[(size_t)(shape_body[s] * 3 + 2) * n + e] = shape_force[s].z;
+  }
+  for (int b = 0; b < 4; ++b) {
+    float* o = p.bodies + (size_t)(b * 13) * n + e;
+    o[0] = bo[b].pos.x; o[(size_t)1 * n] = bo[b].pos.y; o[(size_t)2 * n] = bo[b].pos.z;
+    for (int k = 0; k < 4; ++k) o[(size_t)(3 + k) * n] = bo[b].quat[k];
+    o[(size_t)7 * n] = bo[b].linvel.x; o[(size_t)8 * n] = bo[b].linvel.y; o[(size_t)9 * n] = bo[b].linvel.z;
+    o[(size_t)10 * n] = bo[b].angvel.x; o[(size_t)11 * n] = bo[b].angvel.y; o[(size_t)12 * n] = bo[b].angvel.z;
+  }
+}
+
+// Frame stacking (hector_env.py:246-254 + clip of legged_robot.py:104-107), coalesced along the row:
+// dst[e][0:(S-1)*F] = reset ? 0 : src[e][F:S*F] ;  dst[e][(S-1)*F : S*F] = clip(frame[:,e]).
+__global__ void __launch_bounds__(256) hx_stack_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       const float* __restrict__ frame, const unsigned char* __restrict__ reset,
+                                                       int n, int F, int ld, float clip, const unsigned char* timeout,
+                                                       unsigned char* timeout_visible, const int* num_reset) {
+  const int e = blockIdx.x;
+  const int keep = (HX_FRAME_STACK - 1) * F;
+  const bool rst = reset[e] != 0;
+  const float* s = src + (size_t)e * ld;
+  float* d = dst + (size_t)e * ld;
+  for (int k = threadIdx.x; k < ld; k += blockDim.x) {
+    float v = 0.f;
+    if (k < keep) v = rst ? 0.f : s[k + F];
+    else if (k < keep + F) v = fminf(fmaxf(frame[(size_t)(k - keep) * n + e], -clip), clip);
+    d[k] = v;
+  }
+  // extras["time_outs"] is rebound only inside reset_idx, i.e. when at least one env reset this step
+  // (legged_robot.py:172-173,208-209)
+  if (timeout_visible && threadIdx.x == 0 && *num_reset > 0) timeout_visible[e] = timeout[e];
+}
+
+// ================================================================= host side
+static thread_local std::string g_err;
+extern "C" const char* hx_last_error(void) { return g_err.c_str(); }
+void hx_set_error(const std::string& s) { g_err = s; }
+extern "C" int hx_version(void) { return 100; }
+extern "C" int hx_sync(void* stream) { HX_CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+struct hx_sim {
+  hx_sim_cfg cfg;
+  hipStream_t stream;
+  bool own_stream;
+  SimPtrs p;
+  float *obs[2], *priv[2];
+  int cur;
+  unsigned char* timeout_visible;
+  long long step_counter;
+  uint32_t rng_step;
+  uint64_t seed;
+  std::vector<void*> allocs;
+};
+
+template <typename T> static int dalloc(hx_sim* s, T** ptr, size_t count) {
+  HX_CHECK(hipMalloc((void**)ptr, count * sizeof(T)));
+  HX_CHECK(hipMemset(*ptr, 0, count * sizeof(T)));
+  s->allocs.push_back(*ptr);
+  return 0;
+}
+
+extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, const float* base_mass_h, const float* origins_h,
+                             const float* start_pos_h, uint64_t seed, void* stream, hx_sim** out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_sim_create: no HIP device (this library has no CPU path)"); return -1; }
+  if (!cfg || cfg->num_envs <= 0) { hx_set_error("hx_sim_create: bad cfg"); return -2; }
+  hx_sim* s = new hx_sim();
+  s->cfg = *cfg;
+  s->seed = seed;
+  s->step_counter = 0;
+  s->rng_step = 0;
+  s->cur = 0;
+  if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
+  else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
+  const size_t n = cfg->num_envs;
+  int rc = 0;
+  rc |= dalloc(s, &s->p.st, (size_t)S_STATE_SIZE * n);
+  rc |= dalloc(s, &s->p.ep_len, n);
+  rc |= dalloc(s, &s->p.ep_sums, (size_t)HX_NUM_REWARDS * n);
+  rc |= dalloc(s, &s->p.torques, 10 * n);
+  rc |= dalloc(s, &s->p.contact, 33 * n);
+  rc |= dalloc(s, &s->p.bodies, 52 * n);
+  rc |= dalloc(s, &s->p.obs_frame, (size_t)HX_OBS_FRAME * n);
+  rc |= dalloc(s, &s->p.priv_frame, (size_t)HX_PRIV_FRAME * n);
+  rc |= dalloc(s, &s->p.rew, n);
+  rc |= dalloc(s, &s->p.reset, n);
+  rc |= dalloc(s, &s->p.timeout, n);
+  rc |= dalloc(s, &s->p.num_reset, 1);
+  rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS);
+  rc |= dalloc(s, &s->p.stat_cnt, 1);
+  rc |= dalloc(s, &s->timeout_visible, n);
+  for (int i = 0; i < 2; ++i) { rc |= dalloc(s, &s->obs[i], n * HX_OBS_LD); rc |= dalloc(s, &s->priv[i], n * HX_PRIV_LD); }
+  if (rc) return -3;
+  // initial state: actor creation pose, identity orientation, everything else zero; last_feet_z = 0.05 (hector_env.py:48)
+  std::vector<float> st((size_t)S_STATE_SIZE * n, 0.f);
+  for (size_t e = 0; e < n; ++e) {
+    for (int k = 0; k < 3; ++k) {
+      st[(size_t)(S_ROOT_POS + k) * n + e] = start_pos_h ? start_pos_h[e * 3 + k] : 0.f;
+      st[(size_t)(S_ORIGIN + k) * n + e] = origins_h ? origins_h[e * 3 + k] : 0.f;
+    }
+    st[(size_t)(S_ROOT_QUAT + 3) * n + e] = 1.f;
+    st[(size_t)S_LAST_FEET_Z * n + e] = 0.05f;
+    st[(size_t)(S_LAST_FEET_Z + 1) * n + e] = 0.05f;
+    st[(size_t)S_FRICTION * n + e] = friction_h ? friction_h[e] : 1.f;
+    st[(size_t)S_BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : HXM_MASS[0];
+  }
+  HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = s;
+  return 0;
+}
+
+extern "C" void hx_sim_destroy(hx_sim* s) {
+  if (!s) return;
+  hipStreamSynchronize(s->stream);
+  for (void* a : s->allocs) hipFree(a);
+  if (s->own_stream) hipStreamDestroy(s->stream);
+  delete s;
+}
+
+static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode) {
+  const int n = s->cfg.num_envs;
+  StepArgs A;
+  A.mode = mode;
+  if (mode == 0) s->step_counter += 1;
+  A.step_counter = s->step_counter;
+  A.k0 = (uint32_t)(s->seed & 0xffffffffu);
+  A.k1 = (uint32_t)(s->seed >> 32);
+  A.rng_step = s->rng_step++;
+  HX_CHECK(hipMemsetAsync(s->p.num_reset, 0, sizeof(int), s->stream));
+  hipLaunchKernelGGL(hx_env_step_kernel, dim3((n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg, actions, pack, A);
+  const int nxt = s->cur ^ 1;
+  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, s->obs[s->cur], s->obs[nxt], s->p.obs_frame, s->p.reset,
+                     n, HX_OBS_FRAME, HX_OBS_LD, s->cfg.clip_observations, s->p.timeout, s->timeout_visible, s->p.num_reset);
+  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, s->priv[s->cur], s->priv[nxt], s->p.priv_frame, s->p.reset,
+                     n, HX_PRIV_FRAME, HX_PRIV_LD, s->cfg.clip_observations, (const unsigned char*)nullptr, (unsigned char*)nullptr, (const int*)nullptr);
+  s->cur = nxt;
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int hx_sim_reset_all(hx_sim* s, const float* pack) { return launch_step(s, nullptr, pack, 1); }
+extern "C" int hx_sim_step(hx_sim* s, const float* actions, const float* pack) {
+  if (!actions) { hx_set_error("hx_sim_step: actions is NULL"); return -2; }
+  return launch_step(s, actions, pack, 0);
+}
+
+extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
+  switch (which) {
+    case HX_BUF_OBS: *dptr = s->obs[s->cur]; break;
+    case HX_BUF_PRIV: *dptr = s->priv[s->cur]; break;
+    case HX_BUF_REW: *dptr = s->p.rew; break;
+    case HX_BUF_RESET: *dptr = s->p.reset; break;
+    case HX_BUF_TIMEOUT: *dptr = s->p.timeout; break;
+    case HX_BUF_TIMEOUT_VISIBLE: *dptr = s->timeout_visible; break;
+    case HX_BUF_EP_LEN: *dptr = s->p.ep_len; break;
+    case HX_BUF_COMMANDS: *dptr = s->p.st + (size_t)S_CMD * s->cfg.num_envs; break;
+    case HX_BUF_TORQUES: *dptr = s->p.torques; break;
+    case HX_BUF_CONTACT: *dptr = s->p.contact; break;
+    case HX_BUF_BODY_STATE: *dptr = s->p.bodies; break;
+    case HX_BUF_EPISODE_SUMS: *dptr = s->p.ep_sums; break;
+    case HX_BUF_FEET_AIR_TIME: *dptr = s->p.st + (size_t)S_AIR * s->cfg.num_envs; break;
+    case HX_BUF_FEET_HEIGHT: *dptr = s->p.st + (size_t)S_FEET_H * s->cfg.num_envs; break;
+    case HX_BUF_NUM_RESET: *dptr = s->p.num_reset; break;
+    default: hx_set_error("hx_sim_buffer: unknown id"); return -2;
+  }
+  return 0;
+}
+
+extern "C" int hx_sim_get_state(hx_sim* s, float* root_h, float* q_h, float* qd_h) {
+  const size_t n = s->cfg.num_envs;
+  std::vector<float> st((size_t)33 * n);
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(st.data(), s->p.st, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < n; ++e) {
+    for (int k = 0; k < 13; ++k) root_h[e * 13 + k] = st[(size_t)k * n + e];
+    for (int j = 0; j < 10; ++j) { q_h[e * 10 + j] = st[(size_t)(S_Q + j) * n + e]; qd_h[e * 10 + j] = st[(size_t)(S_QD + j) * n + e]; }
+  }
+  return 0;
+}
+
+extern "C" int hx_sim_set_state(hx_sim* s, const float* root_h, const float* q_h, const float* qd_h) {
+  const size_t n = s->cfg.num_envs;
+  std::vector<float> st((size_t)33 * n);
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  for (size_t e = 0; e < n; ++e) {
+    for (int k = 0; k < 13; ++k) st[(size_t)k * n + e] = root_h[e * 13 + k];
+    for (int j = 0; j < 10; ++j) { st[(size_t)(S_Q + j) * n + e] = q_h[e * 10 + j]; st[(size_t)(S_QD + j) * n + e] = qd_h[e * 10 + j]; }
+  }
+  HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int hx_sim_set_episode_length(hx_sim* s, const int32_t* h) {
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(s->p.ep_len, h, (size_t)s->cfg.num_envs * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int hx_sim_set_step_counter(hx_sim* s, int64_t c) { s->step_counter = c; return 0; }
+
+extern "C" int hx_sim_episode_stats(hx_sim* s, float* mean_h, int32_t* count_h) {
+  float sum[HX_NUM_REWARDS]; int cnt = 0;
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(sum, s->p.stat_sum, sizeof(sum), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(&cnt, s->p.stat_cnt, sizeof(int), hipMemcpyDeviceToHost));
+  for (int r = 0; r < HX_NUM_REWARDS; ++r) mean_h[r] = cnt > 0 ? sum[r] / (float)cnt / s->cfg.max_episode_length_s : 0.f;
+  *count_h = cnt;
+  HX_CHECK(hipMemset(s->p.stat_sum, 0, sizeof(sum)));
+  HX_CHECK(hipMemset(s->p.stat_cnt, 0, sizeof(int)));
+  return 0;
+}
+extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }

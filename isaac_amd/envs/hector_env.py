@@ -1,0 +1,334 @@
+"""HectorFreeEnv: the reference's VecEnv for task `hector`, served by the HIP simulator (libhx.so).
+
+Constructor signature and attributes follow the reference (humanoid/envs/custom/hector_env.py:46-51,
+humanoid/envs/base/legged_robot.py:58-82, humanoid/envs/base/base_task.py:43-125) so that
+`task_class(cfg=..., sim_params=..., physics_engine=..., sim_device=..., headless=...)`
+(humanoid/utils/task_registry.py:97-101) keeps working.  All per-step arithmetic happens in
+isaac_amd/csrc/hx_sim.hip; this file only
+  * derives the flat C config from the nested config classes (what _parse_cfg / _init_buffers /
+    _prepare_reward_function / _get_noise_scale_vec do: legged_robot.py:710-720,433-540, hector_env.py:135-155),
+  * draws the creation-time randomisation on the host in the reference's call order
+    (legged_robot.py:650-664: start xy per env, friction buckets at env 0, payload per env),
+  * hands out DeviceArray views of the library's buffers.
+"""
+import math
+
+import numpy as np
+
+from .. import capi
+from ..devarray import DeviceArray, device_pointer
+from .vec_env import VecEnv
+
+DOF_NAMES = ["L_hip_joint", "L_hip_roll_joint", "L_thigh_joint", "L_calf_joint", "L_toe_joint",
+             "R_hip_joint", "R_hip_roll_joint", "R_thigh_joint", "R_calf_joint", "R_toe_joint"]
+BODY_NAMES = ["base", "L_hip", "L_hip2", "L_thigh", "L_calf", "L_toe", "R_hip", "R_hip2", "R_thigh", "R_calf", "R_toe"]
+URDF_EFFORT = [33.5, 33.5, 33.5, 67.0, 33.5] * 2       # robot.urdf <limit effort=...>
+BASE_MASS = 8.15528                                    # collapsed base link (tools/compile_urdf.py)
+
+# physics model constants (DESIGN.md "Physics model"); mirrored in oracle/physics.py
+PHYS = dict(contact_kn=4.0e4, contact_dn=4.0e2, friction_veps=2.0e-2, limit_k=2.0e3, limit_d=2.0e1)
+
+
+def class_to_dict(obj):
+    """reference humanoid/utils/helpers.py:43-58 -- dir() order == alphabetical (decides reward order)."""
+    if not hasattr(obj, "__dict__"):
+        return obj
+    out = {}
+    for key in dir(obj):
+        if key.startswith("_"):
+            continue
+        val = getattr(obj, key)
+        out[key] = [class_to_dict(i) for i in val] if isinstance(val, list) else class_to_dict(val)
+    return out
+
+
+def creation_randomisation(cfg, num_envs, env_origins):
+    """Per-env friction, base mass and start pose, drawn with the same generators in the same order as the
+    reference's _create_envs loop (legged_robot.py:650-664 with callbacks :244-301), so equal seeds give
+    equal robots.  torch's CPU generator is used when torch is importable (plumbing only)."""
+    fr = cfg.domain_rand
+    start = np.array(env_origins, np.float32).copy()
+    friction = np.ones(num_envs, np.float32)
+    mass = np.full(num_envs, BASE_MASS, np.float32)
+    try:
+        import torch
+        rand = lambda *s: torch.rand(*s).numpy()
+        randint = lambda hi, n: torch.randint(0, hi, (n, 1)).numpy()[:, 0]
+    except ImportError:                                   # pragma: no cover
+        rand = lambda *s: np.random.random_sample(s).astype(np.float32)
+        randint = lambda hi, n: np.random.randint(0, hi, n)
+    coeffs = None
+    for i in range(num_envs):
+        start[i, :2] += (2.0 * rand(2, 1)[:, 0] - 1.0).astype(np.float32)
+        if getattr(fr, "randomize_friction", False):
+            if i == 0:
+                buckets = randint(256, num_envs)
+                lo, hi = fr.friction_range
+                fb = ((hi - lo) * rand(256, 1) + lo)[:, 0].astype(np.float32)
+                coeffs = fb[buckets]
+            friction[i] = coeffs[i]
+        if getattr(fr, "randomize_base_mass", False):
+            lo, hi = fr.added_mass_range
+            mass[i] = np.float32(BASE_MASS + np.random.uniform(lo, hi))
+    return friction, mass, start
+
+
+class HectorFreeEnv(VecEnv):
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, stream=None,
+                 creation=None, init_pack=None):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.headless = headless
+        self.sim_device = sim_device
+        self.device = sim_device
+        L = capi.lib()
+        if str(sim_device).startswith("cuda") and ":" in str(sim_device):
+            capi.check(L.hx_set_device(int(str(sim_device).split(":")[1])), "hx_set_device")
+        # ---- _parse_cfg (legged_robot.py:710-720)
+        sim_dt = float(getattr(sim_params, "dt", cfg.sim.dt)) if sim_params is not None else float(cfg.sim.dt)
+        self.dt = cfg.control.decimation * sim_dt
+        self.obs_scales = cfg.normalization.obs_scales
+        self.reward_scales = class_to_dict(cfg.rewards.scales)
+        self.command_ranges = class_to_dict(cfg.commands.ranges)
+        if cfg.terrain.mesh_type not in ("plane", None, "none"):
+            raise NotImplementedError(
+                f"terrain.mesh_type={cfg.terrain.mesh_type!r}: only 'plane' is built in this round "
+                "(heightfield/trimesh terrain is the next row of SURVEY.md 8f)")
+        cfg.terrain.curriculum = False
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = math.ceil(self.max_episode_length_s / self.dt)
+        cfg.domain_rand.push_interval = math.ceil(cfg.domain_rand.push_interval_s / self.dt)
+        self.num_envs = cfg.env.num_envs
+        self.num_obs = cfg.env.num_observations
+        self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_actions = cfg.env.num_actions
+        self.num_dof = self.num_dofs = 10
+        self.num_bodies = 11
+        self.dof_names, self.body_names = DOF_NAMES, BODY_NAMES
+        if (self.num_obs, self.num_privileged_obs, self.num_actions) != (capi.NUM_OBS, capi.NUM_PRIV, 10):
+            raise ValueError("HectorFreeEnv serves the hector layout only: 615 / 1050 / 10")
+        self.feet_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.foot_name in n]
+        self.knee_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.knee_name in n]
+        self.termination_contact_indices = [i for k in cfg.asset.terminate_after_contacts_on
+                                            for i, n in enumerate(BODY_NAMES) if k in n]
+        self.penalised_contact_indices = [i for k in cfg.asset.penalize_contacts_on
+                                          for i, n in enumerate(BODY_NAMES) if k in n]
+        assert self.feet_indices == [5, 10] and self.knee_indices == [4, 9]
+        assert sorted(self.termination_contact_indices) == [0, 3, 8] == sorted(self.penalised_contact_indices)
+
+        # ---- env origins: grid (legged_robot.py:698-708)
+        n = self.num_envs
+        num_cols = int(np.floor(np.sqrt(n)))
+        num_rows = int(np.ceil(n / num_cols))
+        xx, yy = np.meshgrid(np.arange(num_rows), np.arange(num_cols), indexing="ij")
+        self.env_origins = np.zeros((n, 3), np.float32)
+        self.env_origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:n]
+        self.env_origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:n]
+        self.custom_origins = False
+        if creation is not None:          # tests: replay a recorded creation (friction, base mass, origins, start pose)
+            friction, mass, start = (np.asarray(creation[k], np.float32) for k in ("friction", "mass", "start"))
+            self.env_origins = np.asarray(creation["origins"], np.float32)
+        else:
+            friction, mass, start = creation_randomisation(cfg, n, self.env_origins)
+        self.env_frictions, self.body_mass, self.start_pos = friction, mass, start
+
+        # ---- flat C config
+        c = capi.SimCfg()
+        c.num_envs = n
+        c.decimation = cfg.control.decimation
+        c.sim_dt = sim_dt
+        c.gravity_z = cfg.sim.gravity[2]
+        c.action_scale = cfg.control.action_scale
+        c.clip_actions = cfg.normalization.clip_actions
+        c.clip_observations = cfg.normalization.clip_observations
+        self.default_dof_pos = np.array([cfg.init_state.default_joint_angles[nm] for nm in DOF_NAMES], np.float32)
+        self.p_gains, self.d_gains = np.zeros(10, np.float32), np.zeros(10, np.float32)
+        for i, nm in enumerate(DOF_NAMES):           # substring match, legged_robot.py:486-500
+            for key in cfg.control.stiffness:
+                if key in nm:
+                    self.p_gains[i] = cfg.control.stiffness[key]
+                    self.d_gains[i] = cfg.control.damping[key]
+        self.torque_limits = (np.array(URDF_EFFORT, np.float32) * np.float32(cfg.safety.torque_limit)).astype(np.float32)
+        for j in range(10):
+            c.default_dof_pos[j] = self.default_dof_pos[j]
+            c.p_gains[j], c.d_gains[j] = self.p_gains[j], self.d_gains[j]
+            c.torque_limits[j] = self.torque_limits[j]
+        dr = cfg.domain_rand
+        c.action_delay = getattr(dr, "action_delay", 0.0)
+        c.action_noise = getattr(dr, "action_noise", 0.0)
+        c.add_noise = int(cfg.noise.add_noise)
+        c.noise_level = cfg.noise.noise_level
+        ns, os_ = cfg.noise.noise_scales, self.obs_scales
+        self.noise_scale_vec = np.zeros(capi.OBS_FRAME, np.float32)      # hector_env.py:135-155
+        self.noise_scale_vec[5:15] = ns.dof_pos * os_.dof_pos
+        self.noise_scale_vec[15:25] = ns.dof_vel * os_.dof_vel
+        self.noise_scale_vec[35:38] = ns.ang_vel * os_.ang_vel
+        self.noise_scale_vec[38:41] = ns.quat * os_.quat
+        for k in range(capi.OBS_FRAME):
+            c.noise_scale_vec[k] = self.noise_scale_vec[k]
+        c.push_robots = int(dr.push_robots)
+        c.push_interval = int(dr.push_interval)
+        c.max_push_vel_xy = dr.max_push_vel_xy
+        c.max_push_ang_vel = getattr(dr, "max_push_ang_vel", 0.0)
+        c.resample_interval = int(cfg.commands.resampling_time / self.dt)
+        c.heading_command = int(cfg.commands.heading_command)
+        for i, key in enumerate(("lin_vel_x", "lin_vel_y", "ang_vel_yaw", "heading")):
+            c.cmd_range[i][0], c.cmd_range[i][1] = self.command_ranges[key]
+        c.obs_scale_lin_vel, c.obs_scale_ang_vel = os_.lin_vel, os_.ang_vel
+        c.obs_scale_dof_pos, c.obs_scale_dof_vel, c.obs_scale_quat = os_.dof_pos, os_.dof_vel, os_.quat
+        c.max_episode_length = float(self.max_episode_length)
+        c.max_episode_length_s = float(self.max_episode_length_s)
+        c.env_dt = self.dt
+        base_init = cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel
+        for k in range(13):
+            c.base_init_state[k] = base_init[k]
+        c.custom_origins = 0
+        # _prepare_reward_function (legged_robot.py:517-540): drop zero scales, multiply by dt
+        unknown = [k for k, v in self.reward_scales.items() if v != 0 and k not in capi.REWARD_NAMES and k != "termination"]
+        if unknown:
+            raise ValueError(f"reward terms without a kernel implementation: {unknown}")
+        self.reward_scales = {k: v * self.dt for k, v in self.reward_scales.items() if v != 0}
+        self.reward_names = [k for k in self.reward_scales if k != "termination"]
+        for i, nm in enumerate(capi.REWARD_NAMES):
+            c.reward_scale[i] = self.reward_scales.get(nm, 0.0)
+        rw = cfg.rewards
+        c.only_positive_rewards = int(rw.only_positive_rewards)
+        c.base_height_target, c.min_dist, c.max_dist = rw.base_height_target, rw.min_dist, rw.max_dist
+        c.target_joint_pos_scale, c.target_feet_height = rw.target_joint_pos_scale, rw.target_feet_height
+        c.cycle_time, c.tracking_sigma, c.max_contact_force = rw.cycle_time, rw.tracking_sigma, rw.max_contact_force
+        for k, v in PHYS.items():
+            setattr(c, k, v)
+        c.terrain_mu = cfg.terrain.static_friction
+        self._ccfg = c
+
+        seed = int(getattr(cfg, "seed", 0)) & 0xFFFFFFFF
+        h = capi.C.c_void_p()
+        capi.check(L.hx_sim_create(capi.C.byref(c), capi.ptr(capi.farr(friction)), capi.ptr(capi.farr(mass)),
+                                   capi.ptr(capi.farr(self.env_origins)), capi.ptr(capi.farr(start)),
+                                   seed | (0x5EED << 32), stream, capi.C.byref(h)), "hx_sim_create")
+        self._h = h
+        self._L = L
+        self.stream = L.hx_sim_stream(h)
+        self.common_step_counter = 0
+        self.extras = {}
+        self._keep = []
+        # constructor tail: reset_idx(all) + compute_observations (hector_env.py:50-51)
+        self._reset_all(init_pack)
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, which, shape, dtype=np.float32, strides=None):
+        p = capi.C.c_void_p()
+        capi.check(self._L.hx_sim_buffer(self._h, which, capi.C.byref(p)), "hx_sim_buffer")
+        return DeviceArray(p.value, shape, dtype, strides, self.stream, owner=self)
+
+    def _refresh_views(self):
+        n = self.num_envs
+        self.obs_buf = self._buf(capi.BUF_OBS, (n, capi.NUM_OBS), strides=(capi.OBS_LD * 4, 4))
+        self.privileged_obs_buf = self._buf(capi.BUF_PRIV, (n, capi.NUM_PRIV), strides=(capi.PRIV_LD * 4, 4))
+        self.rew_buf = self._buf(capi.BUF_REW, (n,))
+        self.reset_buf = self._buf(capi.BUF_RESET, (n,), np.uint8)
+        self.time_out_buf = self._buf(capi.BUF_TIMEOUT, (n,), np.uint8)
+        self.extras["time_outs"] = self._buf(capi.BUF_TIMEOUT_VISIBLE, (n,), np.uint8)
+
+    @property
+    def episode_length_buf(self):
+        return self._buf(capi.BUF_EP_LEN, (self.num_envs,), np.int32)
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        """`env.episode_length_buf = randint_like(...)` of on_policy_runner.py:103-106."""
+        arr = value.numpy() if isinstance(value, DeviceArray) else (value.cpu().numpy() if hasattr(value, "cpu") else np.asarray(value))
+        arr = np.ascontiguousarray(arr, np.int32)
+        capi.check(self._L.hx_sim_set_episode_length(self._h, capi.ptr(arr)), "set_episode_length")
+
+    def _reset_all(self, pack):
+        p = None
+        if pack is not None:
+            p, keep = device_pointer(np.ascontiguousarray(pack, np.float32))
+            self._keep = [keep]
+        capi.check(self._L.hx_sim_reset_all(self._h, p), "hx_sim_reset_all")
+        self._refresh_views()
+
+    # ------------------------------------------------------------------ VecEnv
+    def step(self, actions, pack=None):
+        a_ptr, keep_a = device_pointer(actions)
+        p_ptr, keep_p = (None, None) if pack is None else device_pointer(np.ascontiguousarray(pack, np.float32))
+        self._keep = [keep_a, keep_p]
+        capi.check(self._L.hx_sim_step(self._h, a_ptr, p_ptr), "hx_sim_step")
+        self.common_step_counter += 1
+        self._refresh_views()
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset(self):
+        """reset all robots, then one zero-action step (legged_robot.py:111-116)."""
+        # the library's constructor-style reset does not re-randomise the creation pose; mirror reset_idx(all)
+        self._reset_all(None)
+        zeros = capi.DeviceBuffer(self.num_envs * self.num_actions * 4)
+        obs, priv, _, _, _ = self.step(DeviceArray(zeros.ptr, (self.num_envs, self.num_actions), owner=zeros))
+        capi.check(self._L.hx_sync(self.stream), "sync")
+        return obs, priv
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    # ------------------------------------------------------------------ state access (tests, play-style scripts)
+    def get_state(self):
+        n = self.num_envs
+        root, q, qd = np.empty((n, 13), np.float32), np.empty((n, 10), np.float32), np.empty((n, 10), np.float32)
+        capi.check(self._L.hx_sim_get_state(self._h, capi.ptr(root), capi.ptr(q), capi.ptr(qd)), "get_state")
+        return root, q, qd
+
+    def set_state(self, root, q, qd):
+        capi.check(self._L.hx_sim_set_state(self._h, capi.ptr(capi.farr(root)), capi.ptr(capi.farr(q)), capi.ptr(capi.farr(qd))), "set_state")
+
+    def set_step_counter(self, c):
+        self.common_step_counter = int(c)
+        capi.check(self._L.hx_sim_set_step_counter(self._h, int(c)), "set_step_counter")
+
+    @property
+    def root_states(self):
+        return self.get_state()[0]
+
+    @property
+    def dof_pos(self):
+        return self.get_state()[1]
+
+    @property
+    def dof_vel(self):
+        return self.get_state()[2]
+
+    @property
+    def commands(self):
+        return self._buf(capi.BUF_COMMANDS, (4, self.num_envs)).numpy().T
+
+    @property
+    def torques(self):
+        return self._buf(capi.BUF_TORQUES, (10, self.num_envs)).numpy().T
+
+    @property
+    def contact_forces(self):
+        return self._buf(capi.BUF_CONTACT, (11, 3, self.num_envs)).numpy().transpose(2, 0, 1)
+
+    def episode_stats(self):
+        """extras['episode'] of legged_robot.py:198-201, averaged over the envs that reset since the last call."""
+        mean = np.zeros(capi.NUM_REWARDS, np.float32)
+        cnt = capi.C.c_int32(0)
+        capi.check(self._L.hx_sim_episode_stats(self._h, capi.ptr(mean), capi.C.byref(cnt)), "episode_stats")
+        return {"rew_" + k: float(mean[capi.REWARD_NAMES.index(k)]) for k in self.reward_names}, cnt.value
+
+    def sync(self):
+        capi.check(self._L.hx_sync(self.stream), "sync")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hx_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,75 @@
+"""GPU: the f32 MFMA GEMM template (isaac_amd/csrc/hx_gemm.h) against numpy float64, all three modes,
+including ragged M/N/K that exercise every bounds guard.  Tolerance: fp32 dot products of length K,
+|err| <= 2e-6 * sum|a*b| (MFMA f32 is an exact fma chain; numpy reference is float64)."""
+import numpy as np
+import pytest
+
+from isaac_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(hxlib, mode, M, N, K, rng):
+    r4 = lambda x: (x + 3) // 4 * 4
+    if mode in (0, 3):      # FWD: Y = elu(X W^T + b); X [M][K], W [N][K]
+        lda, ldb, ldc = r4(K), r4(K), N
+        A = np.zeros((M, lda), np.float32); A[:, :K] = rng.standard_normal((M, K))
+        B = np.zeros((N, ldb), np.float32); B[:, :K] = rng.standard_normal((N, K)) / np.sqrt(K)
+        bias = rng.standard_normal(N).astype(np.float32)
+        z = A[:, :K].astype(np.float64) @ B[:, :K].astype(np.float64).T + bias
+        ref = np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
+        H = None
+        Kk = lda
+    elif mode in (1, 4):    # DGRAD: dX = (dZ W) * elu'(H); dZ [M][K], W [K][N]
+        lda, ldb, ldc = K, N, N
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+        H = rng.standard_normal((M, N)).astype(np.float32)
+        H = np.where(H > 0, H, np.expm1(np.minimum(H, 0))).astype(np.float32)
+        bias = None
+        ref = (A.astype(np.float64) @ B.astype(np.float64)) * np.where(H > 0, 1.0, H.astype(np.float64) + 1.0)
+        Kk = K
+    else:                   # WGRAD: dW[M][N] = dZ[K][M]^T X[K][N]
+        lda, ldb, ldc = M, N, N
+        A = rng.standard_normal((K, M)).astype(np.float32)
+        B = rng.standard_normal((K, N)).astype(np.float32)
+        H = None
+        bias = np.zeros(M, np.float32)
+        ref = A.astype(np.float64).T @ B.astype(np.float64)
+        Kk = K
+    dA, dB = capi.DeviceBuffer.from_host(A), capi.DeviceBuffer.from_host(B)
+    dC = capi.DeviceBuffer(M * ldc * 4)
+    dbias = capi.DeviceBuffer.from_host(bias) if bias is not None else None
+    dH = capi.DeviceBuffer.from_host(H) if H is not None else None
+    capi.check(hxlib.hx_ppo_gemm_test(mode, M, N, Kk, dA.ptr, lda, dB.ptr, ldb, dbias.ptr if dbias else None,
+                                      dC.ptr, ldc, dH.ptr if dH else None, None), "gemm_test")
+    out = dC.download(np.float32, (M, ldc))[:, :N]
+    scale = np.abs(ref).max() + 1.0
+    err = np.abs(out - ref).max()
+    assert err <= 5e-5 * scale * max(1.0, np.sqrt(K) / 16), (mode, M, N, K, err, scale)
+    if mode == 2:
+        db = dbias.download(np.float32, (M,))
+        np.testing.assert_allclose(db, A.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("mode,M,N,K", [
+    (0, 256, 256, 64), (0, 4096, 512, 615), (0, 1000, 768, 1050), (0, 61, 130, 20),
+    (3, 64, 128, 615), (3, 4096, 256, 512), (3, 70, 100, 36),
+    (1, 512, 256, 128), (1, 1000, 512, 256), (4, 4096, 768, 256), (4, 33, 132, 8),
+    (2, 512, 616, 2048), (2, 768, 1052, 1000), (2, 128, 256, 960), (2, 100, 36, 77),
+])
+def test_gemm_modes(hxlib, mode, M, N, K):
+    _run(hxlib, mode, M, N, K, np.random.default_rng(mode * 1000 + M + N + K))
+
+
+def test_mfma_layout_asymmetric(hxlib):
+    """A = I with an asymmetric B catches a transposed C/D register map (guide: 'A=I-check with ASYMMETRIC B')."""
+    M = N = K = 128
+    A = np.eye(M, dtype=np.float32)
+    W = (np.arange(N)[:, None] * 1000 + np.arange(K)[None, :]).astype(np.float32) / 1.0e5    # W[n][k]
+    bias = np.zeros(N, np.float32)
+    dA, dB, db = capi.DeviceBuffer.from_host(A), capi.DeviceBuffer.from_host(W), capi.DeviceBuffer.from_host(bias)
+    dC = capi.DeviceBuffer(M * N * 4)
+    capi.check(hxlib.hx_ppo_gemm_test(0, M, N, K, dA.ptr, K, dB.ptr, K, db.ptr, dC.ptr, N, None, None), "gemm")
+    out = dC.download(np.float32, (M, N))
+    np.testing.assert_allclose(out, W.T, rtol=0, atol=1e-6)      # elu is the identity for positive inputs

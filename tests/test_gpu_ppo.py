@@ -1,0 +1,136 @@
+"""GPU: the HIP learner against (a) the golden outputs of the reference's own PPO (tests/golden/ppo_*.npz)
+and (b) the numpy oracle stage by stage, through the C ABI (isaac_amd.algo.ppo -> libhx.so).
+
+Tolerances (fp32; MFMA f32 sums k in a different order than MKL/OpenBLAS):
+  forward values / actions / log-probs  5e-5 absolute      returns, normalised advantages  1e-4
+  losses 1e-4 relative, grad-norms 2e-4 relative, learning-rate schedule exact
+  parameters after 8 Adam steps: |delta - delta_ref| sums within 2e-3 relative, 64-element slices 2e-6 absolute
+"""
+import os
+
+import numpy as np
+import pytest
+
+from isaac_amd import capi
+from isaac_amd.algo.ppo import PPO, ActorCritic
+from oracle.ppo import ActorCriticOracle, PPOOracle
+from tests.ppo_inputs import rollout_inputs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _make(seed, T, N, lr, epochs=2, nmb=4):
+    init = ActorCriticOracle.default_init(np.random.default_rng(seed))
+    ac = ActorCritic(615, 1050, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[768, 256, 128], init_noise_std=1.0)
+    ac.load_state_dict(init.state_dict())
+    alg = PPO(ac, num_learning_epochs=epochs, num_mini_batches=nmb, clip_param=0.2, gamma=0.994, lam=0.9, value_loss_coef=1.0,
+              entropy_coef=0.001, learning_rate=lr, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive",
+              desired_kl=0.01)
+    alg.init_storage(N, T, [615], [1050], [10])
+    return init, ac, alg
+
+
+@pytest.mark.parametrize("name", ["ppo_small", "ppo_clip"])
+def test_ppo_matches_reference_fixture(hxlib, name):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    seed, T, N, epochs, nmb = (int(x) for x in fx["meta"])
+    init, ac, alg = _make(seed, T, N, float(fx["lr0"]), epochs, nmb)
+    inp = rollout_inputs(seed, T, N)
+    # state_dict round trip through the padded device layout
+    sd = ac.state_dict()
+    for k, v in init.state_dict().items():
+        np.testing.assert_array_equal(sd[k], v)
+    for t in range(T):
+        a = alg.act(inp["obs"][t], inp["priv"][t], eps=inp["eps"][t]).numpy()
+        np.testing.assert_allclose(a, fx["actions"][t], rtol=0, atol=5e-5)
+        alg.process_env_step(inp["rewards"][t] * np.float32(fx["scale_rewards"]), inp["dones"][t].astype(np.uint8),
+                             {"time_outs": inp["time_outs"][t].astype(np.uint8)})
+    alg.compute_returns(inp["priv"][T])
+    np.testing.assert_allclose(alg.buffer(1, (T, N)).numpy(), fx["values"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(alg.buffer(2, (T, N)).numpy(), fx["logp"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(alg.buffer(3, (T, N, 10)).numpy(), fx["mu"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(alg.buffer(4, (T, N)).numpy(), fx["stored_rewards"], rtol=0, atol=1e-5 * float(fx["scale_rewards"]))
+    np.testing.assert_allclose(alg.buffer(5, (T, N)).numpy(), fx["returns"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(alg.buffer(6, (T, N)).numpy(), fx["advantages"], rtol=1e-4, atol=2e-4)
+    mvl, msl = alg.update(perm=fx["perm"])
+    assert abs(mvl - float(fx["mean_value_loss"])) <= 1e-4 * max(1.0, abs(float(fx["mean_value_loss"])))
+    assert abs(msl - float(fx["mean_surrogate_loss"])) <= 1e-4
+    assert abs(alg.learning_rate / float(fx["final_lr"]) - 1.0) < 1e-6
+    sd = ac.state_dict()
+    init_sd = init.state_dict()
+    for k in sd:
+        d = sd[k].astype(np.float64) - init_sd[k].astype(np.float64)
+        ref_abs = float(fx["delta_abs_" + k])
+        assert abs(np.abs(d).sum() - ref_abs) <= 2e-3 * ref_abs + 1e-9, k
+        np.testing.assert_allclose(sd[k].reshape(-1)[:64], fx["slice_" + k], rtol=0, atol=4e-6, err_msg=k)
+        np.testing.assert_allclose(sd[k].reshape(-1)[-64:], fx["slice_end_" + k], rtol=0, atol=4e-6, err_msg=k)
+    m, v, step = alg.optimizer_state()
+    assert step == int(fx["adam_step"])
+    np.testing.assert_allclose(m[:10], fx["adam_m_std"], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(v[:10], fx["adam_v_std"], rtol=4e-3, atol=1e-10)
+
+
+def test_ppo_stagewise_vs_oracle(hxlib):
+    """One minibatch at a time against the numpy oracle: gradient buffer, KL, LR decision, grad norm."""
+    seed, T, N = 21, 6, 32
+    init, ac, alg = _make(seed, T, N, 1e-4, epochs=1, nmb=2)
+    orc = PPOOracle(ActorCriticOracle.default_init(np.random.default_rng(seed)), N, T, num_learning_epochs=1,
+                    num_mini_batches=2, learning_rate=1e-4)
+    inp = rollout_inputs(seed, T, N)
+    for t in range(T):
+        alg.act(inp["obs"][t], inp["priv"][t], eps=inp["eps"][t])
+        orc.act(inp["obs"][t], inp["priv"][t], inp["eps"][t])
+        alg.process_env_step(inp["rewards"][t], inp["dones"][t].astype(np.uint8), {"time_outs": inp["time_outs"][t].astype(np.uint8)})
+        orc.process_env_step(inp["rewards"][t], inp["dones"][t], inp["time_outs"][t])
+    alg.compute_returns(inp["priv"][T])
+    orc.compute_returns(inp["priv"][T])
+    np.testing.assert_allclose(alg.buffer(6, (T, N)).numpy(), orc.advantages, rtol=1e-4, atol=2e-4)
+    perm = np.random.default_rng(3).permutation(T * N).astype(np.int32)
+    L = hxlib
+    dperm = capi.DeviceBuffer.from_host(perm)
+    capi.check(L.hx_ppo_update_begin(alg._h, dperm.ptr), "begin")
+    g, cnt = capi.C.c_void_p(), capi.C.c_int64()
+    mbs = T * N // 2
+    for i in range(2):
+        capi.check(L.hx_ppo_minibatch_backward(alg._h, i, capi.C.byref(g), capi.C.byref(cnt)), "bwd")
+        flat = capi.download(g.value, np.float32, (cnt.value,))
+        info, grads = orc.loss_and_grads(perm[i * mbs:(i + 1) * mbs])
+        # unpack the padded device layout with the same map the library uses (std is last on the device)
+        stats = flat[-4:]
+        assert abs(stats[0] / stats[3] - info["kl"]) < 2e-5 + 1e-3 * abs(info["kl"])
+        assert abs(stats[1] / stats[3] - info["value"]) < 1e-4 * max(1, abs(info["value"]))
+        assert abs(stats[2] / stats[3] - info["surrogate"]) < 1e-4
+        gn_ref = np.sqrt(sum(float(np.sum(x.astype(np.float64) ** 2)) for x in grads))
+        gn = np.sqrt(np.sum(flat[:-4].astype(np.float64) ** 2))
+        assert abs(gn / gn_ref - 1) < 2e-4, (gn, gn_ref)
+        orc.adapt_lr(info["kl"])
+        orc.optimizer_step(grads)
+        capi.check(L.hx_ppo_minibatch_step(alg._h, 1.0), "step")
+        assert abs(alg.learning_rate / orc.lr - 1) < 1e-6
+    sd = ac.state_dict()
+    # Adam divides by sqrt(v): for weights whose gradient is at round-off level the normalised step is
+    # noise, bounded by lr per step.  Require 99.9% of the elements within 3e-6 and all within 2 steps * lr.
+    for k, v in orc.ac.state_dict().items():
+        d = np.abs(sd[k] - v)
+        assert d.max() <= 2 * 2.0 * orc.lr, (k, d.max())
+        assert np.mean(d > 3e-6) < 1e-3, (k, float(np.mean(d > 3e-6)))
+
+
+def test_device_permutation_is_a_permutation(hxlib):
+    seed, T, N = 5, 4, 64
+    _, _, alg = _make(seed, T, N, 1e-5)
+    capi.check(hxlib.hx_ppo_update_begin(alg._h, None), "begin")
+    p = alg.buffer(8, (T * N,), np.int32).numpy()
+    assert sorted(p.tolist()) == list(range(T * N))
+    assert not np.array_equal(p, np.arange(T * N))
+
+
+def test_rollout_overflow_raises(hxlib):
+    _, _, alg = _make(1, 2, 16, 1e-5)
+    z = np.zeros((16, 615), np.float32), np.zeros((16, 1050), np.float32)
+    for _ in range(2):
+        alg.act(*z)
+        alg.process_env_step(np.zeros(16, np.float32), np.zeros(16, np.uint8), {})
+    with pytest.raises(RuntimeError, match="Rollout buffer overflow"):     # rollout_storage.py:88-89
+        alg.act(*z)

@@ -182,11 +182,17 @@ def main():
     L.append("#define HX_NB 11")
     L.append("#define HX_NJ 10")
 
-    def arr(name, vals, fmt="%.9gf"):
-        L.append("static const float %s[%d] = {%s};" % (name, len(vals), ", ".join(fmt % v for v in vals)))
+    def flit(v):
+        t = "%.9g" % v
+        if "." not in t and "e" not in t and "n" not in t:
+            t += ".0"
+        return t + "f"
+
+    def arr(name, vals):
+        L.append("static constexpr float %s[%d] = {%s};" % (name, len(vals), ", ".join(flit(v) for v in vals)))
 
     def iarr(name, vals):
-        L.append("static const int %s[%d] = {%s};" % (name, len(vals), ", ".join(str(v) for v in vals)))
+        L.append("static constexpr int %s[%d] = {%s};" % (name, len(vals), ", ".join(str(v) for v in vals)))
 
     iarr("HXM_PARENT", [b["parent"] for b in bodies])
     iarr("HXM_AXIS", [b.get("axis", -1) for b in bodies])
@@ -194,6 +200,15 @@ def main():
     arr("HXM_COM", [x for b in bodies for x in b["com"]])
     arr("HXM_ICOM", [np.array(b["inertia_com"])[i, j] for b in bodies
                      for (i, j) in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
+    # spatial inertia about the body-frame origin: I = [[Io, hx],[hx^T, m 1]], h = m*com,
+    # Io = Ic + m (c.c 1 - c c^T)   (6 values: xx yy zz xy xz yz)
+    io = []
+    for b in bodies:
+        c = np.array(b["com"]); m = b["mass"]
+        Io = np.array(b["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
+        io += [Io[0, 0], Io[1, 1], Io[2, 2], Io[0, 1], Io[0, 2], Io[1, 2]]
+    arr("HXM_IO", io)
+    arr("HXM_H", [b["mass"] * x for b in bodies for x in b["com"]])
     arr("HXM_OFFSET", [x for b in bodies for x in b.get("offset", [0, 0, 0])])
     arr("HXM_QLO", [b["lower"] for b in bodies[1:]])
     arr("HXM_QHI", [b["upper"] for b in bodies[1:]])
