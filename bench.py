@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x3
 GEMM_KERNELS = ["fwd_128x128", "fwd_64x128", "dgrad_128x128", "dgrad_64x128", "wgrad_128x128_splitk"]
 
 
-def cpu_baseline(sample_envs=256, sample_steps=2):
+def cpu_baseline(sample_envs=4096, sample_steps=6):
     """The numpy oracle (oracle/env.py + oracle/physics.py + oracle/ppo.py: the CPU restatement, kind="port")
     timed on this box's host cores for a bounded sample of the same iteration: `sample_steps` rollout steps of
     `sample_envs` robots (policy forward, env step with 10 substeps, store), GAE and the 2x4-minibatch update."""
@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
 
+    import contextlib
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr              # stdout carries exactly one line: the result JSON
     import __graft_entry__
     __graft_entry__.build()
     from isaac_amd import capi
@@ -134,7 +137,7 @@ def main():
             except Exception as e:                        # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     comm.barrier()
 
 

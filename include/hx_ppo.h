@@ -80,9 +80,10 @@ int hx_ppo_buffer(hx_ppo* p, int which, void** dptr);
 int hx_ppo_get_lr(hx_ppo* p, float* lr_h);
 int hx_ppo_set_lr(hx_ppo* p, float lr);
 int hx_ppo_inference(hx_ppo* p, const float* obs, int rows, float* actions_out);
-/* HIP-event timing of the dense kernels on the learner's stream: which=1 starts/clears, which=0 stops and
- * returns accumulated {milliseconds, launches, flops} */
-int hx_ppo_prof(hx_ppo* p, int which, double* out_h /*[3]*/, void* reserved);
+/* HIP-event timing of the GEMM kernels on the learner's stream (events recorded on that stream around every
+ * launch): which=1 starts/clears, which=0 stops and returns, per kernel symbol
+ * {fwd 128x128, fwd 64x128, dgrad 128x128, dgrad 64x128, wgrad split-K}: {milliseconds, launches, flops} */
+int hx_ppo_prof(hx_ppo* p, int which, double* out_h /*[15]*/, void* reserved);
 /* unit-test hook: one GEMM of the given mode (0 fwd bias+ELU, 1 dgrad * elu', 2 wgrad split-K) */
 int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      const float* bias, float* C, int ldc, const float* H, void* hip_stream);

@@ -145,8 +145,9 @@ int hx_sim_get_state(hx_sim* s, float* root13_h /*[N][13]*/, float* q_h /*[N][10
 int hx_sim_set_state(hx_sim* s, const float* root13_h, const float* q_h, const float* qd_h);
 int hx_sim_set_episode_length(hx_sim* s, const int32_t* ep_len_h);
 int hx_sim_set_step_counter(hx_sim* s, int64_t common_step_counter);
-/* mean over the envs that reset since the last call of episode_sum / max_episode_length_s, and the count */
-int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS]*/, int32_t* count_h);
+/* over the envs that reset since the last call: mean of episode_sum / max_episode_length_s per reward term
+ * (legged_robot.py:198-201), then mean episode return and mean episode length (on_policy_runner.py:140-154) */
+int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS + 2]*/, int32_t* count_h);
 void* hx_sim_stream(hx_sim* s);
 int hx_sync(void* hip_stream);
 

@@ -118,6 +118,9 @@ class OnPolicyRunner:
                         "Loss/learning_rate": self.alg.learning_rate, "Policy/mean_noise_std": mean_std,
                         "Perf/total_fps": fps, "Perf/collection time": locs["collection_time"],
                         "Perf/learning_time": locs["learn_time"]})
+        if locs["n_ep"] > 0:
+            scalars["Train/mean_reward"] = self.env.last_episode_return
+            scalars["Train/mean_episode_length"] = self.env.last_episode_length
         if self.writer is not None and (self.comm is None or self.comm.rank == 0):
             self.writer.write(json.dumps({"it": locs["it"], "tot_timesteps": self.tot_timesteps, "tot_time": self.tot_time, **scalars}) + "\n")
             self.writer.flush()

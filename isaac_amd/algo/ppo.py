@@ -298,9 +298,16 @@ class PPO:
         capi.check(self._L.hx_ppo_prof(self._h, 1, None, None), "prof")
 
     def prof_end(self):
-        out = np.zeros(3, np.float64)
+        out = np.zeros(15, np.float64)
         capi.check(self._L.hx_ppo_prof(self._h, 0, capi.ptr(out), None), "prof")
-        return dict(ms=float(out[0]), launches=int(out[1]), flops=float(out[2]))
+        names = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, rollout)",
+                 "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)", "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
+                 "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"]
+        ks = [dict(name=names[k], ms=float(out[3 * k]), launches=int(out[3 * k + 1]), flops=float(out[3 * k + 2]))
+              for k in range(5) if out[3 * k + 1] > 0]
+        for k in ks:
+            k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        return dict(kernels=ks)
 
     def close(self):
         if self._h:

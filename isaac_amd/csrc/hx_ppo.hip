@@ -453,7 +453,7 @@ struct hx_ppo {
   int mb_done, mb_total;
   uint32_t seed_lo, seed_hi, act_counter, perm_counter;
   // profiling
-  bool prof; std::vector<hipEvent_t> ev; size_t ev_used; double prof_flops; long prof_launches;
+  bool prof; std::vector<hipEvent_t> ev; std::vector<int> ev_kid; size_t ev_used; double prof_flops[5]; long prof_launches[5];
   std::vector<void*> allocs;
 };
 
@@ -469,13 +469,19 @@ template <int BM, int BN, bool AK, bool BK_, int EPI> static void launch_gemm(hx
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
+  // kernel id for the profiler: 0 fwd128, 1 fwd64, 2 dgrad128, 3 dgrad64, 4 wgrad
+  constexpr int kid = (EPI == EPI_SLAB) ? 4 : ((EPI == EPI_ELU_GRAD) ? (BM == 128 ? 2 : 3) : (BM == 128 ? 0 : 1));
+  if (s && s->prof) {
+    while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
+  }
   if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
-    hipEventRecord(s->ev[s->ev_used], st);
+    (void)hipEventRecord(s->ev[s->ev_used], st);
     hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
-    hipEventRecord(s->ev[s->ev_used + 1], st);
+    (void)hipEventRecord(s->ev[s->ev_used + 1], st);
+    s->ev_kid[s->ev_used] = kid;
     s->ev_used += 2;
-    s->prof_flops += 2.0 * g.M * g.N * g.K;
-    s->prof_launches += 1;
+    s->prof_flops[kid] += 2.0 * g.M * g.N * g.K;
+    s->prof_launches[kid] += 1;
   } else {
     hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
   }
@@ -605,7 +611,8 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   HX_CHECK(hipStreamSynchronize(s->stream));
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
-  s->prof = false; s->ev_used = 0; s->prof_flops = 0; s->prof_launches = 0;
+  s->prof = false; s->ev_used = 0;
+  for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
   *out = s;
   return 0;
 }
@@ -868,15 +875,16 @@ extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* ou
 
 extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
   if (which == 1) {
-    if (s->ev.empty()) { s->ev.resize(8192); for (auto& e : s->ev) HX_CHECK(hipEventCreate(&e)); }
-    s->ev_used = 0; s->prof_flops = 0; s->prof_launches = 0; s->prof = true;
+    s->ev_used = 0; s->prof = true;
+    for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
     return 0;
   }
   s->prof = false;
   HX_CHECK(hipStreamSynchronize(s->stream));
-  double ms = 0;
-  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); ms += t; }
-  if (out) { out[0] = ms; out[1] = (double)s->prof_launches; out[2] = s->prof_flops; }
+  double ms[5] = {0, 0, 0, 0, 0};
+  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); ms[s->ev_kid[i]] += t; }
+  // out[15]: per kernel id {milliseconds, launches, flops}
+  if (out) for (int k = 0; k < 5; ++k) { out[3 * k] = ms[k]; out[3 * k + 1] = (double)s->prof_launches[k]; out[3 * k + 2] = s->prof_flops[k]; }
   return 0;
 }
 

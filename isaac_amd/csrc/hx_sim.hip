@@ -23,8 +23,8 @@ enum {
   S_ROOT_POS = 0, S_ROOT_QUAT = 3, S_LINVEL = 7, S_ANGVEL = 10, S_Q = 13, S_QD = 23,
   S_ACT = 33, S_LAST_ACT = 43, S_LAST_LAST_ACT = 53, S_LAST_DOF_VEL = 63, S_LAST_ROOT_VEL = 73,
   S_CMD = 79, S_AIR = 83, S_LAST_CONTACT = 85, S_FEET_H = 87, S_LAST_FEET_Z = 89, S_PUSH_F = 91,
-  S_PUSH_T = 93, S_FRICTION = 96, S_BASE_MASS = 97, S_ORIGIN = 98, S_BLV = 101, S_BAV = 104,
-  S_STATE_SIZE = 107
+  S_PUSH_T = 93, S_FRICTION = 96, S_BASE_MASS = 97, S_ORIGIN = 98, S_BLV = 101, S_BAV = 104, S_EP_RET = 107,
+  S_STATE_SIZE = 108
 };
 
 struct SimPtrs {
@@ -40,7 +40,7 @@ struct SimPtrs {
   unsigned char* reset;    // [N]
   unsigned char* timeout;  // [N]
   int* num_reset;     // [1]
-  float* stat_sum;    // [HX_NUM_REWARDS] sums of episode sums of envs that reset
+  float* stat_sum;    // [HX_NUM_REWARDS + 2] sums over envs that reset: per-term episode sums, episode return, episode length
   int* stat_cnt;      // [1]
 };
 
@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
   V3 base_lin_vel = mk(LD(S_BLV), LD(S_BLV + 1), LD(S_BLV + 2));
   V3 base_ang_vel = mk(LD(S_BAV), LD(S_BAV + 1), LD(S_BAV + 2));
   int ep_len = p.ep_len[e];
+  float ep_ret = LD(S_EP_RET);
 
   float torques[10];
   for (int j = 0; j < 10; ++j) torques[j] = 0.f;
@@ -387,6 +388,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
       add(HX_R_VEL_MISMATCH_EXP, (lm + am) / 2.f);
     }
     rew_total = cfg.only_positive_rewards ? fmaxf(rsum, 0.f) : rsum;
+    ep_ret += rew_total;
   } else {
     reset = true;
   }
@@ -413,6 +415,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
     cmd[0] *= keep; cmd[1] *= keep;
     for (int j = 0; j < 10; ++j) { act[j] = 0.f; last_act[j] = 0.f; last_last_act[j] = 0.f; last_dof_vel[j] = 0.f; }
     air[0] = 0.f; air[1] = 0.f;
+    const int finished_len = ep_len;
     ep_len = 0;
     for (int r = 0; r < HX_NUM_REWARDS; ++r) {
       const float s = p.ep_sums[(size_t)r * n + e];
@@ -420,9 +423,13 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
       p.ep_sums[(size_t)r * n + e] = 0.f;
     }
     if (A.mode == 0) {
+      // Train/mean_reward and Train/mean_episode_length of the runner (on_policy_runner.py:140-154)
+      atomicAdd(&p.stat_sum[HX_NUM_REWARDS], ep_ret);
+      atomicAdd(&p.stat_sum[HX_NUM_REWARDS + 1], (float)finished_len);
       atomicAdd(p.stat_cnt, 1);
       atomicAdd(p.num_reset, 1);
     }
+    ep_ret = 0.f;
     euler = euler_xyz_wrapped(S.quat);
     pgrav = quat_rotate_inverse(S.quat, mk(0.f, 0.f, -1.f));
   }
@@ -487,6 +494,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
   ST(S_BLV, base_lin_vel.x); ST(S_BLV + 1, base_lin_vel.y); ST(S_BLV + 2, base_lin_vel.z);
   ST(S_BAV, base_ang_vel.x); ST(S_BAV + 1, base_ang_vel.y); ST(S_BAV + 2, base_ang_vel.z);
   p.ep_len[e] = ep_len;
+  ST(S_EP_RET, ep_ret);
   p.rew[e] = rew_total;
   p.reset[e] = reset ? 1 : 0;
   p.timeout[e] = time_out ? 1 : 0;
@@ -583,7 +591,7 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
   rc |= dalloc(s, &s->p.reset, n);
   rc |= dalloc(s, &s->p.timeout, n);
   rc |= dalloc(s, &s->p.num_reset, 1);
-  rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS);
+  rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS + 2);
   rc |= dalloc(s, &s->p.stat_cnt, 1);
   rc |= dalloc(s, &s->timeout_visible, n);
   for (int i = 0; i < 2; ++i) { rc |= dalloc(s, &s->obs[i], n * HX_OBS_LD); rc |= dalloc(s, &s->priv[i], n * HX_PRIV_LD); }
@@ -695,11 +703,13 @@ extern "C" int hx_sim_set_episode_length(hx_sim* s, const int32_t* h) {
 extern "C" int hx_sim_set_step_counter(hx_sim* s, int64_t c) { s->step_counter = c; return 0; }
 
 extern "C" int hx_sim_episode_stats(hx_sim* s, float* mean_h, int32_t* count_h) {
-  float sum[HX_NUM_REWARDS]; int cnt = 0;
+  float sum[HX_NUM_REWARDS + 2]; int cnt = 0;
   HX_CHECK(hipStreamSynchronize(s->stream));
   HX_CHECK(hipMemcpy(sum, s->p.stat_sum, sizeof(sum), hipMemcpyDeviceToHost));
   HX_CHECK(hipMemcpy(&cnt, s->p.stat_cnt, sizeof(int), hipMemcpyDeviceToHost));
   for (int r = 0; r < HX_NUM_REWARDS; ++r) mean_h[r] = cnt > 0 ? sum[r] / (float)cnt / s->cfg.max_episode_length_s : 0.f;
+  mean_h[HX_NUM_REWARDS] = cnt > 0 ? sum[HX_NUM_REWARDS] / (float)cnt : 0.f;
+  mean_h[HX_NUM_REWARDS + 1] = cnt > 0 ? sum[HX_NUM_REWARDS + 1] / (float)cnt : 0.f;
   *count_h = cnt;
   HX_CHECK(hipMemset(s->p.stat_sum, 0, sizeof(sum)));
   HX_CHECK(hipMemset(s->p.stat_cnt, 0, sizeof(int)));

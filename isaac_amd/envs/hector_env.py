@@ -313,11 +313,14 @@ class HectorFreeEnv(VecEnv):
         return self._buf(capi.BUF_CONTACT, (11, 3, self.num_envs)).numpy().transpose(2, 0, 1)
 
     def episode_stats(self):
-        """extras['episode'] of legged_robot.py:198-201, averaged over the envs that reset since the last call."""
-        mean = np.zeros(capi.NUM_REWARDS, np.float32)
+        """extras['episode'] of legged_robot.py:198-201 averaged over the envs that reset since the last call,
+        plus the runner's Train/mean_reward and Train/mean_episode_length over the same episodes."""
+        mean = np.zeros(capi.NUM_REWARDS + 2, np.float32)
         cnt = capi.C.c_int32(0)
         capi.check(self._L.hx_sim_episode_stats(self._h, capi.ptr(mean), capi.C.byref(cnt)), "episode_stats")
-        return {"rew_" + k: float(mean[capi.REWARD_NAMES.index(k)]) for k in self.reward_names}, cnt.value
+        info = {"rew_" + k: float(mean[capi.REWARD_NAMES.index(k)]) for k in self.reward_names}
+        self.last_episode_return, self.last_episode_length = float(mean[capi.NUM_REWARDS]), float(mean[capi.NUM_REWARDS + 1])
+        return info, cnt.value
 
     def sync(self):
         capi.check(self._L.hx_sync(self.stream), "sync")

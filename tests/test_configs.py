@@ -1,0 +1,42 @@
+"""CPU: the config surface equals the reference's (tests/golden/configs.json = class_to_dict of the reference
+classes), leaf by leaf, and class_to_dict keeps the alphabetical order that fixes the reward evaluation order."""
+import json
+import os
+
+from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO
+from isaac_amd.envs.hector_env import class_to_dict
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "configs.json")
+
+
+def _diff(a, b, path=""):
+    out = []
+    if isinstance(a, dict) and isinstance(b, dict):
+        for k in sorted(set(a) | set(b)):
+            if k not in a or k not in b:
+                out.append(f"{path}/{k}: missing on one side")
+            else:
+                out += _diff(a[k], b[k], f"{path}/{k}")
+    elif a != b:
+        out.append(f"{path}: {a!r} != {b!r}")
+    return out
+
+
+def test_hector_cfg_matches_reference():
+    ref = json.load(open(GOLD))
+    mine = json.loads(json.dumps(class_to_dict(HectorCfg())))
+    d = _diff(mine, ref["HectorCfg"])
+    # the one documented deviation: plane terrain until the heightfield row is built (configs.py docstring)
+    assert d == ["/terrain/mesh_type: 'plane' != 'trimesh'"], d
+
+
+def test_hector_cfg_ppo_matches_reference():
+    ref = json.load(open(GOLD))
+    mine = json.loads(json.dumps(class_to_dict(HectorCfgPPO())))
+    assert _diff(mine, ref["HectorCfgPPO"]) == []
+
+
+def test_reward_order_is_alphabetical():
+    scales = class_to_dict(HectorCfg().rewards.scales)
+    active = [k for k, v in scales.items() if v != 0]
+    assert active == sorted(active) and len(active) == 18

@@ -1,0 +1,53 @@
+"""CPU: the env-glue oracle (oracle/env.py) replays the golden trajectories produced by the reference's own
+HectorFreeEnv (tests/golden/make_env_fixtures.py) and must reproduce them step for step.
+This is what pins the oracle to the reference for SURVEY.md 8a rows a1-a3, a5-a11."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.env import REWARD_ORDER, REWARD_SCALE, HectorEnvOracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40)])
+def test_oracle_env_reproduces_reference(name, steps):
+    fx = np.load(os.path.join(GOLD, name + ".npz"))
+    n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
+    env = HectorEnvOracle(n, fx["init_shape_friction"], fx["init_base_mass"], fx["init_env_origins"], fx["packs"][0],
+                          add_noise=bool(noise), start_xy=fx["init_start_pos"])
+    np.testing.assert_allclose(env.obs_buf, fx["init_obs_full"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(env.priv_buf, fx["init_priv_full"], rtol=0, atol=1e-6)
+    assert list(fx["reward_names"]) == REWARD_ORDER          # alphabetical dir() order (helpers.py:47)
+    np.testing.assert_allclose(fx["reward_scales"], [REWARD_SCALE[k] * 0.01 for k in REWARD_ORDER], rtol=1e-12)
+    env.episode_length_buf[:] = fx["ep_len_init"]
+    env.common_step_counter = sc0
+    full = {int(s): i for i, s in enumerate(fx["full_steps"])}
+    for t in range(min(steps, total)):
+        obs, priv, rew, reset = env.step(fx["actions"][t], fx["packs"][t + 1])
+        np.testing.assert_allclose(obs[:, -41:], fx["obs41"][t], rtol=0, atol=1e-4, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(priv[:, -70:], fx["priv70"][t], rtol=0, atol=1e-4, err_msg=f"priv step {t}")
+        np.testing.assert_allclose(rew, fx["rew"][t], rtol=0, atol=1e-6)
+        assert np.array_equal(reset, fx["reset"][t].astype(bool))
+        assert np.array_equal(env.time_out_buf, fx["timeout"][t].astype(bool))
+        assert np.array_equal(env.time_outs_visible, fx["timeouts_visible"][t].astype(bool))     # stale-extras quirk
+        np.testing.assert_allclose(env.torques, fx["torques"][t], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(env.commands, fx["commands"][t], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(env.episode_length_buf, fx["ep_len"][t])
+        np.testing.assert_allclose(env.feet_air_time, fx["feet_air_time"][t], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(env.feet_height, fx["feet_height"][t], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(np.stack([env.episode_sums[k] for k in REWARD_ORDER]), fx["episode_sums"][t], rtol=0, atol=1e-5)
+        if (t + 1) in full:
+            np.testing.assert_allclose(obs, fx["full_obs"][full[t + 1]], rtol=0, atol=1e-4)
+            np.testing.assert_allclose(priv, fx["full_priv"][full[t + 1]], rtol=0, atol=1e-4)
+    if name == "env_rollout_b":
+        assert fx["timeout"].sum() == 3 and fx["reset"].sum() >= 3          # the fixture does exercise time-outs
+
+
+def test_fixture_exercises_events():
+    a = np.load(os.path.join(GOLD, "env_rollout_a.npz"))
+    b = np.load(os.path.join(GOLD, "env_rollout_b.npz"))
+    assert a["reset"].sum() >= 3                      # contact terminations
+    assert np.abs(b["packs"][:, 14:19]).sum() > 0     # a push happened (common_step_counter hits 400)
+    assert np.abs(b["packs"][1:, 11:14]).sum() > 0    # a command resample at ep_len % 800 == 0

@@ -1,0 +1,90 @@
+"""CPU: invariants of the float64 physics oracle (parity unpinned against PhysX -- see oracle/physics.py).
+These are the checks that stand in for golden vectors of the closed-source simulator: conservation laws in
+free flight, force balance at rest, analytic free fall, joint-limit and friction behaviour."""
+import numpy as np
+
+from oracle.physics import DT, GRAVITY, HectorPhysics, State
+
+Q0 = np.array([0, 0, .785, -1.578, .785] * 2)
+KP = np.array([40, 40, 60, 120, 20] * 2, float)
+KD = np.array([3, 3, 5, 4, 1] * 2, float)
+TL = 0.85 * np.array([33.5, 33.5, 33.5, 67, 33.5] * 2)
+
+
+def _free(n, seed=0):
+    ph = HectorPhysics(n)
+    ph.q_lo[:], ph.q_hi[:], ph.v_max[:] = -100, 100, 1e9
+    rng = np.random.default_rng(seed)
+    s = State(n)
+    s.root_pos[:, 2] = 5.0
+    s.q[:] = Q0 + rng.uniform(-.1, .1, (n, 10))
+    s.qd[:] = rng.uniform(-2, 2, (n, 10))
+    s.root_angvel[:] = rng.uniform(-1, 1, (n, 3))
+    s.root_linvel[:] = rng.uniform(-1, 1, (n, 3))
+    return ph, s
+
+
+def test_total_mass_matches_urdf():
+    assert abs(HectorPhysics(1).mass.sum() - 15.0058) < 1e-3
+
+
+def test_energy_and_momentum_conserved_in_free_flight():
+    ph, s = _free(3)
+    z = np.zeros((3, 10))
+    ke, pe = ph.energy(s)
+    P0, L0 = ph.momentum(s)
+    dt, steps = 1e-4, 200
+    for _ in range(steps):
+        ph.substep(s, z, z, z, z + 100.0, dt=dt)
+    ke1, pe1 = ph.energy(s)
+    P1, L1 = ph.momentum(s)
+    assert np.all(np.abs(ke1 + pe1 - ke - pe) < 5e-3)                 # first-order integrator, E ~ 740 J
+    mg = ph.mass.sum(0)[:, None] * np.array([0, 0, GRAVITY])
+    np.testing.assert_allclose(P1 - P0, mg * dt * steps, atol=1e-4)
+    np.testing.assert_allclose((L1 - L0)[:, 2], 0, atol=1e-4)         # gravity exerts no torque about z
+
+
+def test_free_fall_acceleration():
+    ph = HectorPhysics(1)
+    s = State(1)
+    s.root_pos[:, 2] = 3.0
+    s.q[:] = Q0
+    z = np.zeros((1, 10))
+    for _ in range(100):
+        ph.substep(s, np.broadcast_to(Q0, (1, 10)), KP, KD, TL)
+    np.testing.assert_allclose(s.root_linvel[0, 2], GRAVITY * 0.1, rtol=1e-3)
+
+
+def test_static_force_balance_equals_weight():
+    n = 2
+    ph = HectorPhysics(n, base_mass_added=[0.0, 3.0], shape_friction=[1.0, 0.3])
+    s = State(n)
+    s.root_pos[:, 2] = 0.56
+    s.q[:] = Q0
+    for _ in range(2500):                                           # topples (ankle Kp < m g h) and comes to rest
+        ph.substep(s, np.broadcast_to(Q0, (n, 10)), KP, KD, TL)
+    np.testing.assert_allclose(ph.contact_force[:, :, 2].sum(1), -GRAVITY * ph.mass.sum(0), rtol=2e-3)
+    assert np.all(np.abs(s.root_linvel) < 5e-2)
+
+
+def test_joint_limits_hold():
+    ph = HectorPhysics(1)
+    s = State(1)
+    s.root_pos[:, 2] = 3.0
+    s.q[:] = Q0
+    tgt = np.broadcast_to(Q0 + 5.0, (1, 10))                        # drive every joint far past its upper limit
+    for _ in range(400):
+        ph.substep(s, tgt, KP, KD, TL)
+    assert np.all(s.q[0] < ph.q_hi + 0.06)                          # soft limit: tau_max / k = 57/2000 rad overshoot
+
+
+def test_friction_cone_limits_tangential_force():
+    ph = HectorPhysics(1, shape_friction=[0.1])
+    s = State(1)
+    s.root_pos[:, 2] = 0.56
+    s.q[:] = Q0
+    for _ in range(300):
+        ph.substep(s, np.broadcast_to(Q0, (1, 10)), KP, KD, TL)
+    f = ph.contact_force[0, [5, 10]]
+    mu = 0.5 * (0.6 + 0.1)
+    assert np.all(np.linalg.norm(f[:, :2], axis=1) <= mu * np.abs(f[:, 2]) * 1.3 + 1.0)
