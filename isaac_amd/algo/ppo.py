@@ -163,7 +163,7 @@ class PPO:
             raise ValueError("num_envs * num_steps_per_env must be divisible by num_mini_batches")
         self._cfg = c
         ext = None
-        if self.comm is not None and self.comm.world_size > 1:
+        if self._distributed():
             ext = self.comm.alloc_grad_buffer(self._padded_count(c) + 4)
         h = capi.C.c_void_p()
         capi.check(self._L.hx_ppo_create(capi.C.byref(c), self._stream, ext, capi.C.byref(h)), "hx_ppo_create")
@@ -175,6 +175,10 @@ class PPO:
         ac.load_state_dict(ac._pending_state)
         self.storage = self          # `alg.storage.clear()` style calls land here
         self.step = 0
+
+    def _distributed(self):
+        # `force_collectives` lets a single rank walk the multi-rank code path (GPU plumbing test)
+        return self.comm is not None and (self.comm.world_size > 1 or getattr(self.comm, "force_collectives", False))
 
     @staticmethod
     def _padded_count(c):
@@ -223,7 +227,7 @@ class PPO:
     def compute_returns(self, last_critic_obs):
         pp, k = self._padded_ptr(last_critic_obs, self._cfg.num_priv, self.priv_ld)
         capi.check(self._L.hx_ppo_compute_returns(self._h, pp), "hx_ppo_compute_returns")
-        if self.comm is not None and self.comm.world_size > 1:
+        if self._distributed():
             m = capi.C.c_void_p()
             capi.check(self._L.hx_ppo_adv_moments(self._h, capi.C.byref(m)), "adv_moments")
             self.comm.all_reduce_moments(m.value, self.stream)
@@ -235,7 +239,7 @@ class PPO:
         pp, k = (None, None) if perm is None else device_pointer(np.ascontiguousarray(perm, np.int32))
         stats = np.zeros(4, np.float32)
         world = 1 if self.comm is None else self.comm.world_size
-        if world == 1:
+        if not self._distributed():
             capi.check(self._L.hx_ppo_update(self._h, pp, capi.ptr(stats)), "hx_ppo_update")
         else:
             capi.check(self._L.hx_ppo_update_begin(self._h, pp), "update_begin")

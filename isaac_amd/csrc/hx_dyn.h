@@ -1,8 +1,14 @@
 // hx_dyn.h -- per-lane articulated-body dynamics of the hector biped (device code, fp32).
 //
-// One environment per lane.  Featherstone's articulated-body algorithm on the 11-body tree compiled
-// from the reference's URDF (hx_model_data.h), with three linearly-implicit terms folded into the
-// articulated inertias (DESIGN.md "Physics model"):
+// TWO lanes per environment: lane 2e owns the left leg of robot e, lane 2e+1 the right leg; both carry the
+// floating base redundantly.  The hector tree is two 5-body chains hanging off the base, so Featherstone's
+// articulated-body algorithm splits cleanly: each lane runs the leaf-to-root recursion of its own chain
+// and the two chains' contributions to the base (6x6 articulated inertia + bias force, 33 floats) are
+// summed with one lane-pair exchange (__shfl_xor 1).  Per-leg constants (joint offsets, inertias, limits,
+// collision corners) are staged once per workgroup in LDS (hx_model_data.h HXM_LEGC) and read with the
+// lane's leg offset, which keeps the leg code identical for both lanes -- half the instruction footprint
+// of a one-lane-per-robot unrolling, which did not fit the instruction cache (DESIGN.md "Env-step kernel").
+// Three linearly-implicit terms are folded into the articulated inertias (DESIGN.md "Physics model"):
 //   * ground contact at the shape corner points:  f = f0 - B a_body   (B = sum Xc^T K Xc, 6x6 PSD)
 //   * PD actuation (reference legged_robot.py:339-355) while unclipped:  D_i += dt (Kd + dt Kp)
 //   * soft joint limits:  D_i += dt (d + dt k)
@@ -59,43 +65,38 @@ template <int K> HXD M3 rotM(float c, float s, const M3& a) {
   return o;
 }
 
+// sin/cos for joint angles.  Joint ranges are within +-2.3 rad (URDF limits + soft-limit overshoot), so the
+// argument is wrapped to [-pi, pi] (a no-op for any limited joint), folded into [-pi/2, pi/2] and evaluated
+// with Taylor polynomials (|err| < 6e-8 there).  This replaces sincosf's generic Payne-Hanek slow path,
+// which alone was ~1/6 of the kernel's instruction footprint.
+HXD void joint_sincos(float x, float* s, float* c) {
+  const float PI = 3.14159265358979f;
+  x = fmaf(-6.28318530717959f, rintf(x * 0.159154943091895f), x);
+  float sgn = 1.f;
+  if (x > 0.5f * PI) { x = PI - x; sgn = -1.f; }
+  else if (x < -0.5f * PI) { x = -PI - x; sgn = -1.f; }
+  const float x2 = x * x;
+  float ps = -2.50521084e-8f;                 // -1/11!
+  ps = fmaf(ps, x2, 2.75573192e-6f);          //  1/9!
+  ps = fmaf(ps, x2, -1.98412698e-4f);         // -1/7!
+  ps = fmaf(ps, x2, 8.33333333e-3f);          //  1/5!
+  ps = fmaf(ps, x2, -1.66666667e-1f);         // -1/3!
+  *s = fmaf(ps * x2, x, x);
+  float pc = 2.08767570e-9f;                  //  1/12!
+  pc = fmaf(pc, x2, -2.75573192e-7f);         // -1/10!
+  pc = fmaf(pc, x2, 2.48015873e-5f);          //  1/8!
+  pc = fmaf(pc, x2, -1.38888889e-3f);         // -1/6!
+  pc = fmaf(pc, x2, 4.16666667e-2f);          //  1/4!
+  pc = fmaf(pc, x2, -0.5f);
+  *c = sgn * fmaf(pc, x2, 1.0f);
+}
+
 struct SV { V3 w, v; };      // spatial motion [angular; linear] or force [moment; force]
 HXD SV operator+(SV a, SV b) { SV r; r.w = a.w + b.w; r.v = a.v + b.v; return r; }
 HXD SV operator-(SV a, SV b) { SV r; r.w = a.w - b.w; r.v = a.v - b.v; return r; }
 struct SI { M3 A, H, M; };   // 6x6 symmetric [[A,H],[H^T,M]]
 HXD SV mulSI(const SI& I, SV a) { SV f; f.w = mul(I.A, a.w) + mul(I.H, a.v); f.v = mulT(I.H, a.w) + mul(I.M, a.v); return f; }
 
-template <int I> struct BodyC {
-  static constexpr int parent = HXM_PARENT[I];
-  static constexpr int axis = HXM_AXIS[I];
-  HXD static V3 off() { return mk(HXM_OFFSET[3 * I], HXM_OFFSET[3 * I + 1], HXM_OFFSET[3 * I + 2]); }
-  HXD static V3 h() { return mk(HXM_H[3 * I], HXM_H[3 * I + 1], HXM_H[3 * I + 2]); }
-  HXD static SI inertia(float s) {   // s: per-env scale (base payload randomisation), 1 elsewhere
-    SI r;
-    const float xx = HXM_IO[6 * I], yy = HXM_IO[6 * I + 1], zz = HXM_IO[6 * I + 2];
-    const float xy = HXM_IO[6 * I + 3], xz = HXM_IO[6 * I + 4], yz = HXM_IO[6 * I + 5];
-    r.A.m[0] = s * xx; r.A.m[1] = s * xy; r.A.m[2] = s * xz;
-    r.A.m[3] = s * xy; r.A.m[4] = s * yy; r.A.m[5] = s * yz;
-    r.A.m[6] = s * xz; r.A.m[7] = s * yz; r.A.m[8] = s * zz;
-    const V3 hh = s * h();           // H = skew(m c)
-    r.H.m[0] = 0.f; r.H.m[1] = -hh.z; r.H.m[2] = hh.y;
-    r.H.m[3] = hh.z; r.H.m[4] = 0.f; r.H.m[5] = -hh.x;
-    r.H.m[6] = -hh.y; r.H.m[7] = hh.x; r.H.m[8] = 0.f;
-    const float m = s * HXM_MASS[I];
-    r.M = m3zero(); r.M.m[0] = m; r.M.m[4] = m; r.M.m[8] = m;
-    return r;
-  }
-  // v x* (I v) for the rigid body's own inertia
-  HXD static SV bias(SV v, float s) {
-    const V3 hh = s * h();
-    const float m = s * HXM_MASS[I];
-    SI in = inertia(s);
-    V3 hw = mul(in.A, v.w) + cross(hh, v.v);
-    V3 hv = m * v.v + cross(v.w, hh);
-    SV p; p.w = cross(v.w, hw) + cross(v.v, hv); p.v = cross(v.w, hv);
-    return p;
-  }
-};
 
 template <typename F, int... Is> HXD void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
@@ -106,20 +107,71 @@ struct DynParams {
   float dt, gz, kn, dn, veps, lim_k, lim_d, mu;
 };
 
-// contact shapes: index into HXM_CONTACT_BODY ; shape s has 8 corner points
-template <int I> struct ShapeOf { static constexpr int value = (I == 0) ? 0 : (I == 3) ? 1 : (I == 5) ? 2 : (I == 8) ? 3 : (I == 10) ? 4 : -1; };
+#define HX_LEG_NJ 5
+// joint axes along a leg (same for both legs): hip yaw z, hip roll x, thigh / calf / toe pitch y
+template <int L> struct LegAxis { static constexpr int value = (L == 0) ? 2 : (L == 1) ? 0 : 1; };
+#define HX_LDS_CONST_FLOATS (2 * HX_LEGC_STRIDE + 24)
 
-// Accumulate the contact terms of shape SH on a body with spatial velocity v (body coords), world
-// z-axis in body coords nb, world height of the body origin pz.
-// f0: explicit spatial force (body coords); B: implicit 6x6.  If a != nullptr also returns the
-// implicit-consistent net force (body coords)  sum_c [f0_c - K_c Xc a].
-template <int SH> HXD void contact_shape(const DynParams& P, SV v, V3 nb, float pz, SV& f0, SI& B,
-                                         const SV* a_true, V3* net_force) {
+// stage the per-leg table and the base collision corners into LDS (call with all threads, then __syncthreads)
+HXD void dyn_stage_constants(float* lds, int tid, int nthreads) {
+  for (int i = tid; i < 2 * HX_LEGC_STRIDE; i += nthreads) lds[i] = HXM_LEGC[i];
+  for (int i = tid; i < 24; i += nthreads) lds[2 * HX_LEGC_STRIDE + i] = HXM_CONTACT_PTS[i];
+}
+
+// this lane's view of the constants
+struct LegConst {
+  const float* t;      // LDS, leg table of this lane
+  const float* basept; // LDS, 8 base corners
+  HXD V3 off(int b) const { return mk(t[b * 16], t[b * 16 + 1], t[b * 16 + 2]); }
+  HXD V3 h(int b) const { return mk(t[b * 16 + 3], t[b * 16 + 4], t[b * 16 + 5]); }
+  HXD float mass(int b) const { return t[b * 16 + 12]; }
+  HXD float qlo(int b) const { return t[b * 16 + 13]; }
+  HXD float qhi(int b) const { return t[b * 16 + 14]; }
+  HXD float vmax(int b) const { return t[b * 16 + 15]; }
+  HXD SI inertia(int b) const {
+    SI r;
+    const float xx = t[b * 16 + 6], yy = t[b * 16 + 7], zz = t[b * 16 + 8], xy = t[b * 16 + 9], xz = t[b * 16 + 10], yz = t[b * 16 + 11];
+    r.A.m[0] = xx; r.A.m[1] = xy; r.A.m[2] = xz; r.A.m[3] = xy; r.A.m[4] = yy; r.A.m[5] = yz; r.A.m[6] = xz; r.A.m[7] = yz; r.A.m[8] = zz;
+    const V3 hh = h(b);
+    r.H.m[0] = 0.f; r.H.m[1] = -hh.z; r.H.m[2] = hh.y; r.H.m[3] = hh.z; r.H.m[4] = 0.f; r.H.m[5] = -hh.x; r.H.m[6] = -hh.y; r.H.m[7] = hh.x; r.H.m[8] = 0.f;
+    const float m = mass(b);
+    r.M = m3zero(); r.M.m[0] = m; r.M.m[4] = m; r.M.m[8] = m;
+    return r;
+  }
+  HXD const float* thigh_pts() const { return t + 80; }
+  HXD const float* toe_pts() const { return t + 104; }
+};
+
+// v x* (I v) for a rigid body with spatial inertia `in` (H = skew(h), M = m 1)
+HXD SV rb_bias(const SI& in, V3 hh, float m, SV v) {
+  const V3 hw = mul(in.A, v.w) + cross(hh, v.v);
+  const V3 hv = m * v.v + cross(v.w, hh);
+  SV p; p.w = cross(v.w, hw) + cross(v.v, hv); p.v = cross(v.w, hv);
+  return p;
+}
+
+HXD SI base_inertia(float s) {
+  SI r;
+  const float xx = HXM_IO[0], yy = HXM_IO[1], zz = HXM_IO[2], xy = HXM_IO[3], xz = HXM_IO[4], yz = HXM_IO[5];
+  r.A.m[0] = s * xx; r.A.m[1] = s * xy; r.A.m[2] = s * xz; r.A.m[3] = s * xy; r.A.m[4] = s * yy; r.A.m[5] = s * yz;
+  r.A.m[6] = s * xz; r.A.m[7] = s * yz; r.A.m[8] = s * zz;
+  const V3 hh = s * mk(HXM_H[0], HXM_H[1], HXM_H[2]);
+  r.H.m[0] = 0.f; r.H.m[1] = -hh.z; r.H.m[2] = hh.y; r.H.m[3] = hh.z; r.H.m[4] = 0.f; r.H.m[5] = -hh.x; r.H.m[6] = -hh.y; r.H.m[7] = hh.x; r.H.m[8] = 0.f;
+  const float m = s * HXM_MASS[0];
+  r.M = m3zero(); r.M.m[0] = m; r.M.m[4] = m; r.M.m[8] = m;
+  return r;
+}
+
+// Accumulate the contact terms of `npts` corner points (LDS, xyz triples) on a body with spatial velocity v
+// (body coords), world z-axis in body coords nb, world height of the body origin pz.
+// a_true == nullptr: f0 += explicit spatial force, B += implicit 6x6.
+// a_true != nullptr: returns the implicit-consistent net force (body coords)  sum_c [f0_c - K_c Xc a].
+HXD V3 contact_points(const DynParams& P, const float* pts, int npts, SV v, V3 nb, float pz, SV& f0, SI& B, const SV* a_true) {
   const float c_n = P.dn + P.kn * P.dt;
   V3 net = mk(0.f, 0.f, 0.f);
 #pragma unroll 1
-  for (int k = 0; k < 8; ++k) {
-    const V3 r = mk(HXM_CONTACT_PTS[(SH * 8 + k) * 3], HXM_CONTACT_PTS[(SH * 8 + k) * 3 + 1], HXM_CONTACT_PTS[(SH * 8 + k) * 3 + 2]);
+  for (int k = 0; k < npts; ++k) {
+    const V3 r = mk(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
     const float pen = -(pz + dot(nb, r));
     const V3 vp = v.v + cross(v.w, r);
     const float vn = dot(vp, nb);
@@ -153,7 +205,7 @@ template <int SH> HXD void contact_shape(const DynParams& P, SV v, V3 nb, float 
       net = net + (f - ka);
     }
   }
-  if (net_force) *net_force = net;
+  return net;
 }
 
 // 6x6 SPD solve (Cholesky, fully unrolled, static indices): x = A^-1 b
@@ -186,10 +238,13 @@ HXD void solve6(float (&a)[6][6], float (&b)[6]) {
   }
 }
 
+HXD float xchg(float x) { return __shfl_xor(x, 1); }     // the other leg's lane of the same robot
+HXD V3 xchg(V3 a) { return mk(xchg(a.x), xchg(a.y), xchg(a.z)); }
+
 struct DynState {
-  V3 pos; float quat[4];   // xyzw, body->world
-  V3 linvel, angvel;       // world frame
-  float q[HX_NJ], qd[HX_NJ];
+  V3 pos; float quat[4];   // base: xyzw, body->world (identical on both lanes of a robot)
+  V3 linvel, angvel;       // base, world frame
+  float q[HX_LEG_NJ], qd[HX_LEG_NJ];   // this lane's leg
 };
 
 HXD M3 quat_to_mat(const float* q) {
@@ -201,79 +256,76 @@ HXD M3 quat_to_mat(const float* q) {
   return r;
 }
 
-// One 1 ms substep.  target/kp/kd/tau_lim per joint; mass_scale = base mass / nominal base mass.
-// Outputs: tau (the reference's torque, before integration), and if want_forces the net contact force
-// per shape body in the world frame (shape order: base, L_thigh, L_toe, R_thigh, R_toe).
-HXD void dyn_substep(DynState& S, const DynParams& P, const float* target, const float* kp, const float* kd,
-                     const float* tau_lim, float mass_scale, float* tau_out, bool want_forces, V3* shape_force) {
-  SV v[HX_NB];
-  float cs_c[HX_NB], cs_s[HX_NB];
-  M3 Rw[HX_NB];
-  float pz[HX_NB];
-  // ---- pass 1: kinematics
-  {
-    M3 R0 = quat_to_mat(S.quat);
-    Rw[0] = R0;
-    pz[0] = S.pos.z;
-    v[0].w = mulT(R0, S.angvel);
-    v[0].v = mulT(R0, S.linvel);
-  }
-  V3 pw[HX_NB];
-  pw[0] = S.pos;
-  static_for<HX_NJ>([&](auto ic) {
-    constexpr int I = decltype(ic)::value + 1;
-    constexpr int Pp = BodyC<I>::parent;
-    constexpr int K = BodyC<I>::axis;
-    float s, c;
-    sincosf(S.q[I - 1], &s, &c);
-    cs_c[I] = c; cs_s[I] = s;
-    const V3 r = BodyC<I>::off();
-    const V3 t = v[Pp].v + cross(v[Pp].w, r);
-    v[I].w = rotT<K>(c, s, v[Pp].w);
-    v[I].v = rotT<K>(c, s, t);
-    if (K == 0) v[I].w.x += S.qd[I - 1];
-    if (K == 1) v[I].w.y += S.qd[I - 1];
-    if (K == 2) v[I].w.z += S.qd[I - 1];
-    for (int i = 0; i < 3; ++i) setrow(Rw[I], i, rotT<K>(c, s, row(Rw[Pp], i)));
-    pw[I] = pw[Pp] + mul(Rw[Pp], r);
-    pz[I] = pw[I].z;
-  });
+struct LegForces { V3 base, thigh, toe; };   // world frame; base = whole-base total (same on both lanes)
 
-  // ---- pass 2: articulated inertias, leaves to root
-  SV U[HX_NB];
-  float Dinv[HX_NB], uu[HX_NB];
-  SI accI[HX_NB];   // contribution passed to the parent, indexed by the CHILD that produced it
-  SV accP[HX_NB];
-  SI baseI = BodyC<0>::inertia(mass_scale);
-  SV baseP = BodyC<0>::bias(v[0], mass_scale);
-  static_for<HX_NJ>([&](auto ic) {
-    constexpr int I = HX_NJ - decltype(ic)::value;       // 10..1
-    constexpr int K = BodyC<I>::axis;
-    constexpr int SH = ShapeOf<I>::value;
-    constexpr bool leaf = (I == 5 || I == 10);
-    SI IA = BodyC<I>::inertia(1.f);
-    SV pA = BodyC<I>::bias(v[I], 1.f);
-    if (!leaf) {
-      IA.A = IA.A + accI[I + 1].A; IA.H = IA.H + accI[I + 1].H; IA.M = IA.M + accI[I + 1].M;
-      pA = pA + accP[I + 1];
+// One 1 ms substep of this lane's half of the robot.  target/kp/kd/tau_lim: this leg's 5 joints.
+HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg, const float* target, const float* kp,
+                     const float* kd, const float* tau_lim, float mass_scale, float* tau_out, bool want_forces, LegForces& F) {
+  SV v[HX_LEG_NJ + 1];       // index 0 = base, 1..5 = leg bodies
+  float cs_c[HX_LEG_NJ + 1], cs_s[HX_LEG_NJ + 1];
+  V3 nb_base, nb_thigh, nb_toe;
+  float pz_base, pz_thigh = 0.f, pz_toe = 0.f;
+  const M3 R0 = quat_to_mat(S.quat);
+  // ---- pass 1: kinematics down the leg
+  nb_base = row(R0, 2);
+  pz_base = S.pos.z;
+  v[0].w = mulT(R0, S.angvel);
+  v[0].v = mulT(R0, S.linvel);
+  {
+    M3 Rc = R0; V3 pc = S.pos;
+    static_for<HX_LEG_NJ>([&](auto ic) {
+      constexpr int L = decltype(ic)::value;      // local body 0..4, state index L+1
+      constexpr int K = LegAxis<L>::value;
+      float s, c;
+      joint_sincos(S.q[L], &s, &c);
+      cs_c[L + 1] = c; cs_s[L + 1] = s;
+      const V3 r = C.off(L);
+      const V3 t = v[L].v + cross(v[L].w, r);
+      v[L + 1].w = rotT<K>(c, s, v[L].w);
+      v[L + 1].v = rotT<K>(c, s, t);
+      if (K == 0) v[L + 1].w.x += S.qd[L];
+      if (K == 1) v[L + 1].w.y += S.qd[L];
+      if (K == 2) v[L + 1].w.z += S.qd[L];
+      pc = pc + mul(Rc, r);
+      for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
+      if (L == 2) { nb_thigh = row(Rc, 2); pz_thigh = pc.z; }
+      if (L == 4) { nb_toe = row(Rc, 2); pz_toe = pc.z; }
+    });
+  }
+
+  // ---- pass 2: articulated inertias, toe -> hip
+  SV U[HX_LEG_NJ + 1];
+  float Dinv[HX_LEG_NJ + 1], uu[HX_LEG_NJ + 1];
+  SI accI; SV accP;            // what this chain hands to its parent
+  accI.A = m3zero(); accI.H = m3zero(); accI.M = m3zero();
+  accP.w = mk(0, 0, 0); accP.v = mk(0, 0, 0);
+  static_for<HX_LEG_NJ>([&](auto ic) {
+    constexpr int L = HX_LEG_NJ - 1 - decltype(ic)::value;     // 4..0
+    constexpr int K = LegAxis<L>::value;
+    SI IA = C.inertia(L);
+    SV pA = rb_bias(IA, C.h(L), C.mass(L), v[L + 1]);
+    if (L < HX_LEG_NJ - 1) {
+      IA.A = IA.A + accI.A; IA.H = IA.H + accI.H; IA.M = IA.M + accI.M;
+      pA = pA + accP;
     }
-    if (SH >= 0) {
-      const V3 nb = row(Rw[I], 2);
+    if (L == 2 || L == 4) {
+      const V3 nb = (L == 2) ? nb_thigh : nb_toe;
+      const float pz = (L == 2) ? pz_thigh : pz_toe;
       SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
       SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-      contact_shape<(SH >= 0 ? SH : 0)>(P, v[I], nb, pz[I], f0, B, nullptr, nullptr);
+      contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], nb, pz, f0, B, nullptr);
       IA.A = IA.A + B.A; IA.H = IA.H + B.H; IA.M = IA.M + B.M;
       SV g; g.w = mk(0, 0, 0); g.v = P.gz * nb;
       pA = pA - f0 + mulSI(B, g);
     }
-    // joint-space terms
-    const float q = S.q[I - 1], qd = S.qd[I - 1];
-    const float raw = kp[I - 1] * (target[I - 1] - q) - kd[I - 1] * qd;
-    const float tau = fminf(fmaxf(raw, -tau_lim[I - 1]), tau_lim[I - 1]);
-    tau_out[I - 1] = tau;
-    float beta = (raw == tau) ? P.dt * (kd[I - 1] + P.dt * kp[I - 1]) : 0.f;
+    // joint-space terms: PD torque (reference legged_robot.py:339-355) + soft limits, linearly implicit
+    const float q = S.q[L], qd = S.qd[L];
+    const float raw = kp[L] * (target[L] - q) - kd[L] * qd;
+    const float tau = fminf(fmaxf(raw, -tau_lim[L]), tau_lim[L]);
+    tau_out[L] = tau;
+    float beta = (raw == tau) ? P.dt * (kd[L] + P.dt * kp[L]) : 0.f;
     const float c_lim = P.lim_d + P.lim_k * P.dt;
-    const float lo_pen = HXM_QLO[I - 1] - q, hi_pen = q - HXM_QHI[I - 1];
+    const float lo_pen = C.qlo(L) - q, hi_pen = q - C.qhi(L);
     const float t_lo = P.lim_k * lo_pen - c_lim * qd;
     const float t_hi = -P.lim_k * hi_pen - c_lim * qd;
     const bool act_lo = (lo_pen > 0.f) && (t_lo > 0.f);
@@ -285,49 +337,52 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const float* target, const
     const float D = get(Ui.w, K) + beta;
     const float di = 1.0f / D;
     const float ui = tau_j - get(pA.w, K);
-    U[I] = Ui; Dinv[I] = di; uu[I] = ui;
+    U[L + 1] = Ui; Dinv[L + 1] = di; uu[L + 1] = ui;
     // Ia = IA - U U^T / D ; pa = pA + Ia c + U ui / D
     addouter(IA.A, -di, Ui.w, Ui.w);
     addouter(IA.H, -di, Ui.w, Ui.v);
     addouter(IA.M, -di, Ui.v, Ui.v);
     SV cI;   // c_i = v_i x (S qd)
     {
-      V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
-      cI.w = cross(v[I].w, w2); cI.v = cross(v[I].v, w2);
+      const V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
+      cI.w = cross(v[L + 1].w, w2); cI.v = cross(v[L + 1].v, w2);
     }
     SV pa = pA + mulSI(IA, cI);
     pa.w = pa.w + (ui * di) * Ui.w; pa.v = pa.v + (ui * di) * Ui.v;
     // transform to the parent frame:  X^T Ia X,  X^T pa
-    const float c = cs_c[I], s = cs_s[I];
-    const V3 r = BodyC<I>::off();
-    M3 A1 = rotM<K>(c, s, IA.A), H1 = rotM<K>(c, s, IA.H), M1 = rotM<K>(c, s, IA.M);
-    M3 G = crossM(r, M1);                       // rx M'
-    M3 T1 = crossM(r, transpose(H1));           // rx H'^T
-    M3 Kk = crossM(r, transpose(G));            // rx G^T = (G rx^T)^T, symmetric
-    SI out;
-    out.A = A1 + T1 + transpose(T1) + Kk;
-    out.H = H1 + G;
-    out.M = M1;
-    SV po; po.v = rot<K>(c, s, pa.v); po.w = rot<K>(c, s, pa.w) + cross(r, po.v);
-    if (I == 1 || I == 6) {
-      baseI.A = baseI.A + out.A; baseI.H = baseI.H + out.H; baseI.M = baseI.M + out.M;
-      baseP = baseP + po;
-    } else {
-      accI[I] = out; accP[I] = po;
-    }
+    const float c = cs_c[L + 1], s = cs_s[L + 1];
+    const V3 r = C.off(L);
+    const M3 A1 = rotM<K>(c, s, IA.A), H1 = rotM<K>(c, s, IA.H), M1 = rotM<K>(c, s, IA.M);
+    const M3 G = crossM(r, M1);                       // rx M'
+    const M3 T1 = crossM(r, transpose(H1));           // rx H'^T
+    const M3 Kk = crossM(r, transpose(G));            // rx G^T = (G rx^T)^T, symmetric
+    accI.A = A1 + T1 + transpose(T1) + Kk;
+    accI.H = H1 + G;
+    accI.M = M1;
+    accP.v = rot<K>(c, s, pa.v);
+    accP.w = rot<K>(c, s, pa.w) + cross(r, accP.v);
   });
-  // base: contacts, then solve
-  SV a[HX_NB];       // accelerations relative to the gravity field
-  V3 g0;
+  // ---- base: each lane adds HALF of the base corners to its chain's contribution, then the two lanes of the
+  //      robot exchange and sum (a + b == b + a bitwise, so both lanes hold the identical base system)
+  const SV g0 = [&] { SV g; g.w = mk(0, 0, 0); g.v = P.gz * nb_base; return g; }();
   {
-    const V3 nb = row(Rw[0], 2);
     SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
     SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-    contact_shape<0>(P, v[0], nb, pz[0], f0, B, nullptr, nullptr);
-    baseI.A = baseI.A + B.A; baseI.H = baseI.H + B.H; baseI.M = baseI.M + B.M;
-    SV g; g.w = mk(0, 0, 0); g.v = P.gz * nb;
-    g0 = g.v;
-    baseP = baseP - f0 + mulSI(B, g);
+    contact_points(P, C.basept + 12 * leg, 4, v[0], nb_base, pz_base, f0, B, nullptr);
+    accI.A = accI.A + B.A; accI.H = accI.H + B.H; accI.M = accI.M + B.M;
+    accP = accP - f0 + mulSI(B, g0);
+  }
+  SI baseI = base_inertia(mass_scale);
+  SV baseP = rb_bias(baseI, mass_scale * mk(HXM_H[0], HXM_H[1], HXM_H[2]), mass_scale * HXM_MASS[0], v[0]);
+  for (int i = 0; i < 9; ++i) {
+    baseI.A.m[i] += accI.A.m[i] + xchg(accI.A.m[i]);
+    baseI.H.m[i] += accI.H.m[i] + xchg(accI.H.m[i]);
+    baseI.M.m[i] += accI.M.m[i] + xchg(accI.M.m[i]);
+  }
+  baseP.w = baseP.w + (accP.w + xchg(accP.w));
+  baseP.v = baseP.v + (accP.v + xchg(accP.v));
+  SV a[HX_LEG_NJ + 1];       // accelerations relative to the gravity field
+  {
     float Am[6][6], bm[6];
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
@@ -342,51 +397,58 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const float* target, const
     a[0].w = mk(bm[0], bm[1], bm[2]);
     a[0].v = mk(bm[3], bm[4], bm[5]);
   }
-  // ---- pass 3: accelerations, root to leaves
-  float qdd[HX_NJ];
-  static_for<HX_NJ>([&](auto ic) {
-    constexpr int I = decltype(ic)::value + 1;
-    constexpr int Pp = BodyC<I>::parent;
-    constexpr int K = BodyC<I>::axis;
-    const float c = cs_c[I], s = cs_s[I];
-    const V3 r = BodyC<I>::off();
-    const float qd = S.qd[I - 1];
+  // ---- pass 3: accelerations, hip -> toe
+  float qdd[HX_LEG_NJ];
+  static_for<HX_LEG_NJ>([&](auto ic) {
+    constexpr int L = decltype(ic)::value;
+    constexpr int K = LegAxis<L>::value;
+    const float c = cs_c[L + 1], s = cs_s[L + 1];
+    const V3 r = C.off(L);
+    const float qd = S.qd[L];
     SV ai;
-    ai.w = rotT<K>(c, s, a[Pp].w);
-    ai.v = rotT<K>(c, s, a[Pp].v + cross(a[Pp].w, r));
-    V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
-    ai.w = ai.w + cross(v[I].w, w2);
-    ai.v = ai.v + cross(v[I].v, w2);
-    const float dd = Dinv[I] * (uu[I] - (dot(U[I].w, ai.w) + dot(U[I].v, ai.v)));
-    qdd[I - 1] = dd;
+    ai.w = rotT<K>(c, s, a[L].w);
+    ai.v = rotT<K>(c, s, a[L].v + cross(a[L].w, r));
+    const V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
+    ai.w = ai.w + cross(v[L + 1].w, w2);
+    ai.v = ai.v + cross(v[L + 1].v, w2);
+    const float dd = Dinv[L + 1] * (uu[L + 1] - (dot(U[L + 1].w, ai.w) + dot(U[L + 1].v, ai.v)));
+    qdd[L] = dd;
     if (K == 0) ai.w.x += dd;
     if (K == 1) ai.w.y += dd;
     if (K == 2) ai.w.z += dd;
-    a[I] = ai;
+    a[L + 1] = ai;
   });
-  // ---- net contact forces (implicit-consistent), only when asked (last substep of an env step)
+  // ---- net contact forces (implicit-consistent), last substep of an env step only; rotations rebuilt here
   if (want_forces) {
-    static_for<HX_NB>([&](auto ic) {
-      constexpr int I = decltype(ic)::value;
-      constexpr int SH = ShapeOf<I>::value;
-      if (SH >= 0) {
-        const V3 nb = row(Rw[I], 2);
-        SV at = a[I]; at.v = at.v + P.gz * nb;     // true spatial acceleration
-        SV f0d; SI Bd; V3 net;
-        contact_shape<(SH >= 0 ? SH : 0)>(P, v[I], nb, pz[I], f0d, Bd, &at, &net);
-        shape_force[SH >= 0 ? SH : 0] = mul(Rw[I], net);
+    SV dmy; SI dmyB;
+    {
+      SV at = a[0]; at.v = at.v + g0.v;
+      const V3 part = contact_points(P, C.basept + 12 * leg, 4, v[0], nb_base, pz_base, dmy, dmyB, &at);
+      F.base = mul(R0, part + xchg(part));
+    }
+    M3 Rc = R0;
+    static_for<HX_LEG_NJ>([&](auto ic) {
+      constexpr int L = decltype(ic)::value;
+      constexpr int K = LegAxis<L>::value;
+      for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(cs_c[L + 1], cs_s[L + 1], row(Rc, i)));
+      if (L == 2 || L == 4) {
+        const V3 nb = (L == 2) ? nb_thigh : nb_toe;
+        SV at = a[L + 1]; at.v = at.v + P.gz * nb;     // true spatial acceleration
+        const V3 net = contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], nb, (L == 2) ? pz_thigh : pz_toe, dmy, dmyB, &at);
+        if (L == 2) F.thigh = mul(Rc, net); else F.toe = mul(Rc, net);
       }
     });
   }
-  // ---- integrate (semi-implicit Euler)
+  // ---- integrate (semi-implicit Euler); the base update is identical on both lanes
   {
     const V3 a_ang = a[0].w;
-    const V3 a_lin = a[0].v + g0 + cross(v[0].w, v[0].v);
-    S.angvel = S.angvel + P.dt * mul(Rw[0], a_ang);
-    S.linvel = S.linvel + P.dt * mul(Rw[0], a_lin);
-    for (int j = 0; j < HX_NJ; ++j) {
+    const V3 a_lin = a[0].v + g0.v + cross(v[0].w, v[0].v);
+    S.angvel = S.angvel + P.dt * mul(R0, a_ang);
+    S.linvel = S.linvel + P.dt * mul(R0, a_lin);
+    for (int j = 0; j < HX_LEG_NJ; ++j) {
       const float nqd = S.qd[j] + P.dt * qdd[j];
-      S.qd[j] = fminf(fmaxf(nqd, -HXM_VMAX[j]), HXM_VMAX[j]);
+      const float vm = C.vmax(j);
+      S.qd[j] = fminf(fmaxf(nqd, -vm), vm);
       S.q[j] += P.dt * S.qd[j];
     }
     S.pos = S.pos + P.dt * S.linvel;
@@ -402,56 +464,53 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const float* target, const
   }
 }
 
-// Forward kinematics for the observation/reward glue: world position, linear and angular velocity of the
-// body origins of bodies 4,5,9,10 (calves = "knees", toes = "feet"; reference hector_config.py:31-32).
+// Forward kinematics for the observation/reward glue: world position / velocity of the body origins of this
+// leg's calf ("knee") and toe ("foot") -- reference hector_config.py:31-32.
 struct BodyOut { V3 pos, linvel, angvel; float quat[4]; };
-HXD void dyn_body_states(const DynState& S, BodyOut* out /*[4]: L_calf, L_toe, R_calf, R_toe*/) {
-  SV v[HX_NB]; M3 Rw[HX_NB]; V3 pw[HX_NB];
-  Rw[0] = quat_to_mat(S.quat);
-  pw[0] = S.pos;
-  v[0].w = mulT(Rw[0], S.angvel);
-  v[0].v = mulT(Rw[0], S.linvel);
-  static_for<HX_NJ>([&](auto ic) {
-    constexpr int I = decltype(ic)::value + 1;
-    constexpr int Pp = BodyC<I>::parent;
-    constexpr int K = BodyC<I>::axis;
+HXD void mat_to_quat(const M3& R, float* q) {
+  const float m00 = R.m[0], m11 = R.m[4], m22 = R.m[8];
+  const float c0 = 1 + m00 - m11 - m22, c1 = 1 - m00 + m11 - m22, c2 = 1 - m00 - m11 + m22, c3 = 1 + m00 + m11 + m22;
+  float qx, qy, qz, qw;
+  if (c3 >= c0 && c3 >= c1 && c3 >= c2) {
+    const float t4 = 2.f * sqrtf(fmaxf(c3, 1e-30f));
+    qw = 0.25f * t4; qx = (R.m[7] - R.m[5]) / t4; qy = (R.m[2] - R.m[6]) / t4; qz = (R.m[3] - R.m[1]) / t4;
+  } else if (c0 >= c1 && c0 >= c2) {
+    const float t4 = 2.f * sqrtf(fmaxf(c0, 1e-30f));
+    qx = 0.25f * t4; qy = (R.m[1] + R.m[3]) / t4; qz = (R.m[2] + R.m[6]) / t4; qw = (R.m[7] - R.m[5]) / t4;
+  } else if (c1 >= c2) {
+    const float t4 = 2.f * sqrtf(fmaxf(c1, 1e-30f));
+    qx = (R.m[1] + R.m[3]) / t4; qy = 0.25f * t4; qz = (R.m[5] + R.m[7]) / t4; qw = (R.m[2] - R.m[6]) / t4;
+  } else {
+    const float t4 = 2.f * sqrtf(fmaxf(c2, 1e-30f));
+    qx = (R.m[2] + R.m[6]) / t4; qy = (R.m[5] + R.m[7]) / t4; qz = 0.25f * t4; qw = (R.m[3] - R.m[1]) / t4;
+  }
+  const float sg = qw < 0.f ? -1.f : 1.f;
+  q[0] = sg * qx; q[1] = sg * qy; q[2] = sg * qz; q[3] = sg * qw;
+}
+HXD void dyn_body_states(const DynState& S, const LegConst& C, BodyOut& calf, BodyOut& toe) {
+  M3 Rc = quat_to_mat(S.quat);
+  V3 pc = S.pos;
+  SV vc; vc.w = mulT(Rc, S.angvel); vc.v = mulT(Rc, S.linvel);
+  static_for<HX_LEG_NJ>([&](auto ic) {
+    constexpr int L = decltype(ic)::value;
+    constexpr int K = LegAxis<L>::value;
     float s, c;
-    sincosf(S.q[I - 1], &s, &c);
-    const V3 r = BodyC<I>::off();
-    const V3 t = v[Pp].v + cross(v[Pp].w, r);
-    v[I].w = rotT<K>(c, s, v[Pp].w);
-    v[I].v = rotT<K>(c, s, t);
-    if (K == 0) v[I].w.x += S.qd[I - 1];
-    if (K == 1) v[I].w.y += S.qd[I - 1];
-    if (K == 2) v[I].w.z += S.qd[I - 1];
-    for (int i = 0; i < 3; ++i) setrow(Rw[I], i, rotT<K>(c, s, row(Rw[Pp], i)));
-    pw[I] = pw[Pp] + mul(Rw[Pp], r);
-    constexpr int slot = (I == 4) ? 0 : (I == 5) ? 1 : (I == 9) ? 2 : (I == 10) ? 3 : -1;
-    if (slot >= 0) {
-      BodyOut& o = out[slot >= 0 ? slot : 0];
-      o.pos = pw[I];
-      o.linvel = mul(Rw[I], v[I].v);
-      o.angvel = mul(Rw[I], v[I].w);
-      // rotation matrix -> xyzw quaternion (w >= 0), largest-component branch
-      const M3& R = Rw[I];
-      const float m00 = R.m[0], m11 = R.m[4], m22 = R.m[8];
-      const float c0 = 1 + m00 - m11 - m22, c1 = 1 - m00 + m11 - m22, c2 = 1 - m00 - m11 + m22, c3 = 1 + m00 + m11 + m22;
-      float qx, qy, qz, qw;
-      if (c3 >= c0 && c3 >= c1 && c3 >= c2) {
-        const float t4 = 2.f * sqrtf(fmaxf(c3, 1e-30f));
-        qw = 0.25f * t4; qx = (R.m[7] - R.m[5]) / t4; qy = (R.m[2] - R.m[6]) / t4; qz = (R.m[3] - R.m[1]) / t4;
-      } else if (c0 >= c1 && c0 >= c2) {
-        const float t4 = 2.f * sqrtf(fmaxf(c0, 1e-30f));
-        qx = 0.25f * t4; qy = (R.m[1] + R.m[3]) / t4; qz = (R.m[2] + R.m[6]) / t4; qw = (R.m[7] - R.m[5]) / t4;
-      } else if (c1 >= c2) {
-        const float t4 = 2.f * sqrtf(fmaxf(c1, 1e-30f));
-        qx = (R.m[1] + R.m[3]) / t4; qy = 0.25f * t4; qz = (R.m[5] + R.m[7]) / t4; qw = (R.m[2] - R.m[6]) / t4;
-      } else {
-        const float t4 = 2.f * sqrtf(fmaxf(c2, 1e-30f));
-        qx = (R.m[2] + R.m[6]) / t4; qy = (R.m[5] + R.m[7]) / t4; qz = 0.25f * t4; qw = (R.m[3] - R.m[1]) / t4;
-      }
-      const float sg = qw < 0.f ? -1.f : 1.f;
-      o.quat[0] = sg * qx; o.quat[1] = sg * qy; o.quat[2] = sg * qz; o.quat[3] = sg * qw;
+    joint_sincos(S.q[L], &s, &c);
+    const V3 r = C.off(L);
+    const V3 t = vc.v + cross(vc.w, r);
+    vc.w = rotT<K>(c, s, vc.w);
+    vc.v = rotT<K>(c, s, t);
+    if (K == 0) vc.w.x += S.qd[L];
+    if (K == 1) vc.w.y += S.qd[L];
+    if (K == 2) vc.w.z += S.qd[L];
+    pc = pc + mul(Rc, r);
+    for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
+    if (L == 3 || L == 4) {
+      BodyOut& o = (L == 3) ? calf : toe;
+      o.pos = pc;
+      o.linvel = mul(Rc, vc.v);
+      o.angvel = mul(Rc, vc.w);
+      mat_to_quat(Rc, o.quat);
     }
   });
 }

@@ -36,7 +36,9 @@ __device__ __forceinline__ void philox4p(uint32_t k0, uint32_t k1, uint32_t c0, 
 
 #define LOG_SQRT_2PI 0.9189385332046727f
 
-// Rollout head (ppo.py:91-101): mu = W4 h3a + b4, a = mu + std*eps, logp, V = w4c.h3c + b4c.  One thread per env.
+// Rollout head (ppo.py:91-101): mu = W4 h3a + b4, a = mu + std*eps, logp, V = w4c.h3c + b4c.
+// 16 lanes per env row (each lane owns hw/16 consecutive k), partial dot products reduced with 4 xor-shuffles,
+// so a 4096-env rollout step fills 256 workgroups instead of 16.
 __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restrict__ h3a, const float* __restrict__ h3c, int hw,
                                                           const float* __restrict__ W4, const float* __restrict__ b4,
                                                           const float* __restrict__ W4c, const float* __restrict__ b4c,
@@ -49,22 +51,30 @@ __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restric
   for (int i = threadIdx.x; i < A * hw; i += blockDim.x) sW[i] = W4[i];
   for (int i = threadIdx.x; i < hw; i += blockDim.x) sWc[i] = W4c[i];
   __syncthreads();
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  const int part = threadIdx.x & 15;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int ec = e < n ? e : n - 1;            // keep every lane in the shuffles
+  const int per = hw / 16;
   float mu[MAX_A];
   for (int j = 0; j < A; ++j) mu[j] = 0.f;
   float v = 0.f;
-  const float* ha = h3a + (size_t)e * hw;
-  const float* hc = h3c + (size_t)e * hw;
-  for (int k = 0; k < hw; k += 4) {
+  const float* ha = h3a + (size_t)ec * hw + part * per;
+  const float* hc = h3c + (size_t)ec * hw + part * per;
+  for (int k = 0; k < per; k += 4) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(ha + k);
     const f32x4 y = *reinterpret_cast<const f32x4*>(hc + k);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      for (int j = 0; j < A; ++j) mu[j] = fmaf(x[q], sW[j * hw + k + q], mu[j]);
-      v = fmaf(y[q], sWc[k + q], v);
+      const int kk = part * per + k + q;
+      for (int j = 0; j < A; ++j) mu[j] = fmaf(x[q], sW[j * hw + kk], mu[j]);
+      v = fmaf(y[q], sWc[kk], v);
     }
   }
+  for (int o = 8; o > 0; o >>= 1) {
+    for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
+    v += __shfl_xor(v, o);
+  }
+  if (part != 0 || e >= n) return;
   float lp = 0.f;
   for (int j = 0; j < A; ++j) {
     const float m = mu[j] + b4[j];
@@ -358,6 +368,17 @@ __global__ void hx_reduce_slabs_kernel(const float* __restrict__ src, int S, siz
   dst[i] = accumulate ? dst[i] + s : s;
 }
 
+// stage 1 of the head-slab reduction: out[c][i] = sum of slabs [c*chunk, (c+1)*chunk) -- many workgroups
+__global__ void hx_slab_chunk_kernel(const float* __restrict__ slab, int S, int slab_w, int chunk, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (i >= slab_w) return;
+  const int lo = c * chunk, hi = min(S, lo + chunk);
+  float s = 0.f;
+  for (int k = lo; k < hi; ++k) s += slab[(size_t)k * slab_w + i];
+  out[(size_t)c * slab_w + i] = s;
+}
+
 // scatter the head slab sums into the flat gradient buffer + statistics
 struct HeadScatter { size_t w4, b4, w4c, b4c, stdo, stats; int A, hw; };
 __global__ void hx_head_scatter_kernel(const float* __restrict__ slab, int S, int slab_w, float* grads, HeadScatter o, float rows) {
@@ -433,6 +454,7 @@ struct Layer { int out, in, in_ld; size_t w, b; };
 struct hx_ppo {
   hx_ppo_cfg cfg;
   hipStream_t stream; bool own_stream;
+  hipStream_t stream2; hipEvent_t ev_fork, ev_join;   // critic chain of the rollout runs beside the actor chain
   Layer L[8];                  // actor 0..3, critic 4..7
   size_t std_off, padded, stats_off;
   int64_t torch_count;
@@ -446,7 +468,7 @@ struct hx_ppo {
   int Mmax;
   float *obs_mb, *priv_mb, *row_mb;
   float *act_a[3], *act_c[3], *dz_a[3], *dz_c[3];
-  float *slab, *bias_slab, *head_slab; size_t slab_floats; int head_blocks_max, head_slab_w;
+  float *slab, *bias_slab, *head_slab, *head_slab2; size_t slab_floats; int head_blocks_max, head_slab_w;
   int* perm; int perm_external;
   double* sumsq; SchedState* sched;
   int64_t adam_t;
@@ -536,11 +558,14 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
   if (cfg->num_actions > MAX_A) { hx_set_error("hx_ppo_create: num_actions > 16"); return -2; }
-  if (cfg->actor_hidden[2] != cfg->critic_hidden[2] || cfg->actor_hidden[2] % 4) { hx_set_error("hx_ppo_create: last hidden widths must match and be a multiple of 4"); return -2; }
+  if (cfg->actor_hidden[2] != cfg->critic_hidden[2] || cfg->actor_hidden[2] % 64) { hx_set_error("hx_ppo_create: last hidden widths must match and be a multiple of 64"); return -2; }
   hx_ppo* s = new hx_ppo();
   s->cfg = *cfg;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
+  HX_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  HX_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+  HX_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   const int A = cfg->num_actions, N = cfg->num_envs, T = cfg->num_steps;
   // ---- parameter layout
   int dims_a[5] = {cfg->num_obs, cfg->actor_hidden[0], cfg->actor_hidden[1], cfg->actor_hidden[2], A};
@@ -599,6 +624,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   s->head_slab_w = A * cfg->actor_hidden[2] + A + cfg->actor_hidden[2] + 1 + A + 4;
   s->head_blocks_max = (s->Mmax + HEAD_ROWS - 1) / HEAD_ROWS;
   rc |= palloc(s, &s->head_slab, (size_t)s->head_blocks_max * s->head_slab_w);
+  rc |= palloc(s, &s->head_slab2, (size_t)((s->head_blocks_max + 31) / 32) * s->head_slab_w);
   rc |= palloc(s, &s->perm, TN);
   rc |= palloc(s, &s->sumsq, 1); rc |= palloc(s, &s->sched, 1);
   if (rc) return -3;
@@ -622,6 +648,8 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
   (void)hipStreamSynchronize(s->stream);
   for (void* a : s->allocs) (void)hipFree(a);
   for (auto e : s->ev) (void)hipEventDestroy(e);
+  (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);
+  (void)hipEventDestroy(s->ev_fork); (void)hipEventDestroy(s->ev_join);
   if (s->own_stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -677,11 +705,12 @@ extern "C" int hx_ppo_get_opt_state_h(hx_ppo* s, float* m, float* v, int64_t* st
 }
 
 // hidden layers of one network: X[M][ld] -> act[0..2]
-static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act) {
+static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr) {
   const Layer* L = s->L + net * 4;
-  gemm_fwd(s, s->stream, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld);
-  gemm_fwd(s, s->stream, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld);
-  gemm_fwd(s, s->stream, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld);
+  if (!st) st = s->stream;
+  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld);
+  gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld);
+  gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld);
 }
 
 extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const float* eps, float** actions_out) {
@@ -691,12 +720,17 @@ extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const 
   float* sp = s->s_priv + (size_t)t * N * s->cfg.priv_ld;
   HX_CHECK(hipMemcpyAsync(so, obs, (size_t)N * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
   HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)N * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-  mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, N, s->act_a);
-  mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, N, s->act_c);
+  // fork: at M = num_envs one chain's GEMMs cannot fill 256 CUs, so the critic chain runs on a second stream
+  HX_CHECK(hipEventRecord(s->ev_fork, s->stream));
+  HX_CHECK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+  mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, N, s->act_a, s->stream);
+  mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, N, s->act_c, s->stream2);
+  HX_CHECK(hipEventRecord(s->ev_join, s->stream2));
+  HX_CHECK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
   const int hw = s->cfg.actor_hidden[2];
   if (t == 0) HX_CHECK(hipMemcpyAsync(s->sigma_old, s->params + s->std_off, A * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
   float* acts = s->s_actions + (size_t)t * N * A;
-  hipLaunchKernelGGL(hx_act_head_kernel, dim3((N + 255) / 256), dim3(256), (A + 1) * hw * sizeof(float), s->stream,
+  hipLaunchKernelGGL(hx_act_head_kernel, dim3((N + 15) / 16), dim3(256), (A + 1) * hw * sizeof(float), s->stream,
                      s->act_a[2], s->act_c[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
                      s->params + s->std_off, eps, N, A, s->seed_lo, s->seed_hi, s->act_counter++, acts, s->s_mu + (size_t)t * N * A,
                      s->s_values + (size_t)t * N, s->s_logp + (size_t)t * N);
@@ -776,7 +810,9 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   const size_t shm = (size_t)(2 * HEAD_ROWS * (hw + 1) + A * hw + hw + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
   hipLaunchKernelGGL(hx_loss_head_kernel, dim3(hblocks), dim3(256), shm, st, h);
   HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw};
-  hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab, hblocks, s->head_slab_w, s->grads, hs, (float)M);
+  const int hchunk = 32, hchunks = (hblocks + hchunk - 1) / hchunk;
+  hipLaunchKernelGGL(hx_slab_chunk_kernel, dim3((s->head_slab_w + 255) / 256, hchunks), dim3(256), 0, st, s->head_slab, hblocks, s->head_slab_w, hchunk, s->head_slab2);
+  hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab2, hchunks, s->head_slab_w, s->grads, hs, (float)M);
   // backward through the hidden layers of both networks
   for (int net = 0; net < 2; ++net) {
     const Layer* L = s->L + net * 4;

@@ -45,7 +45,7 @@ struct SimPtrs {
 };
 
 // ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
-__device__ __forceinline__ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+__device__ __attribute__((noinline)) void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -116,42 +116,37 @@ struct StepArgs {
 #define LD(f) (p.st[(size_t)(f) * n + e])
 #define ST(f, val) (p.st[(size_t)(f) * n + e] = (val))
 
-__global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg cfg, const float* __restrict__ actions,
+__global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim_cfg* __restrict__ cfgp, const float* __restrict__ actions,
                                                          const float* __restrict__ pack, StepArgs A) {
+  // lane pair (2e, 2e+1) = (left leg, right leg) of robot e; 32 robots per 64-lane workgroup
+  __shared__ float lds_const[HX_LDS_CONST_FLOATS];
+  dyn_stage_constants(lds_const, threadIdx.x, 64);
+  __syncthreads();
+  const hx_sim_cfg& cfg = *cfgp;
   const int n = cfg.num_envs;
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= n) return;
+  const int e = (blockIdx.x * 64 + threadIdx.x) >> 1;
+  const int leg = threadIdx.x & 1;
+  if (e >= n) return;                      // both lanes of a pair leave together
+  const bool writer = (leg == 0);          // env-level results are computed by both lanes, stored by one
+  LegConst C; C.t = lds_const + leg * HX_LEGC_STRIDE; C.basept = lds_const + 2 * HX_LEGC_STRIDE;
   Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
 
-  // ---- load state
+  // ---- load state: base (both lanes) + this lane's leg
   DynState S;
   S.pos = mk(LD(S_ROOT_POS), LD(S_ROOT_POS + 1), LD(S_ROOT_POS + 2));
   for (int i = 0; i < 4; ++i) S.quat[i] = LD(S_ROOT_QUAT + i);
   S.linvel = mk(LD(S_LINVEL), LD(S_LINVEL + 1), LD(S_LINVEL + 2));
   S.angvel = mk(LD(S_ANGVEL), LD(S_ANGVEL + 1), LD(S_ANGVEL + 2));
-  for (int j = 0; j < 10; ++j) { S.q[j] = LD(S_Q + j); S.qd[j] = LD(S_QD + j); }
-  float act[10], last_act[10], last_last_act[10], last_dof_vel[10], last_root_vel[6], cmd[4];
-  for (int j = 0; j < 10; ++j) { act[j] = LD(S_ACT + j); last_act[j] = LD(S_LAST_ACT + j); last_last_act[j] = LD(S_LAST_LAST_ACT + j); last_dof_vel[j] = LD(S_LAST_DOF_VEL + j); }
-  for (int j = 0; j < 6; ++j) last_root_vel[j] = LD(S_LAST_ROOT_VEL + j);
-  for (int j = 0; j < 4; ++j) cmd[j] = LD(S_CMD + j);
-  float air[2] = {LD(S_AIR), LD(S_AIR + 1)};
-  float last_contact[2] = {LD(S_LAST_CONTACT), LD(S_LAST_CONTACT + 1)};
-  float feet_h[2] = {LD(S_FEET_H), LD(S_FEET_H + 1)};
-  float last_feet_z[2] = {LD(S_LAST_FEET_Z), LD(S_LAST_FEET_Z + 1)};
-  float push_f[2] = {LD(S_PUSH_F), LD(S_PUSH_F + 1)};
-  float push_t[3] = {LD(S_PUSH_T), LD(S_PUSH_T + 1), LD(S_PUSH_T + 2)};
+  for (int j = 0; j < 5; ++j) { S.q[j] = LD(S_Q + leg * 5 + j); S.qd[j] = LD(S_QD + leg * 5 + j); }
+  // only what the physics needs is loaded before the substep loop; the glue state is loaded after it
+  float act[10];
+  for (int j = 0; j < 10; ++j) act[j] = LD(S_ACT + j);
   const float friction = LD(S_FRICTION), base_mass = LD(S_BASE_MASS);
-  const V3 origin = mk(LD(S_ORIGIN), LD(S_ORIGIN + 1), LD(S_ORIGIN + 2));
-  V3 base_lin_vel = mk(LD(S_BLV), LD(S_BLV + 1), LD(S_BLV + 2));
-  V3 base_ang_vel = mk(LD(S_BAV), LD(S_BAV + 1), LD(S_BAV + 2));
   int ep_len = p.ep_len[e];
-  float ep_ret = LD(S_EP_RET);
 
-  float torques[10];
-  for (int j = 0; j < 10; ++j) torques[j] = 0.f;
-  V3 shape_force[5];
-  for (int i = 0; i < 5; ++i) shape_force[i] = mk(0, 0, 0);
-  BodyOut bo[4];
+  float tau_leg[5];
+  for (int j = 0; j < 5; ++j) tau_leg[j] = 0.f;
+  LegForces F; F.base = mk(0, 0, 0); F.thigh = mk(0, 0, 0); F.toe = mk(0, 0, 0);
   bool reset = false, time_out = false;
   float rew_total = 0.f;
 
@@ -170,16 +165,62 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
     DynParams P;
     P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
     P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
-    float target[10];
-    for (int j = 0; j < 10; ++j) target[j] = act[j] * cfg.action_scale + cfg.default_dof_pos[j];
+    float target[5], kpl[5], kdl[5], tll[5];
+    for (int j = 0; j < 5; ++j) {
+      const float aj = leg ? act[5 + j] : act[j];
+      target[j] = aj * cfg.action_scale + cfg.default_dof_pos[leg * 5 + j];
+      kpl[j] = cfg.p_gains[leg * 5 + j]; kdl[j] = cfg.d_gains[leg * 5 + j]; tll[j] = cfg.torque_limits[leg * 5 + j];
+    }
     const float mass_scale = base_mass / HXM_MASS[0];
 #pragma unroll 1
     for (int sub = 0; sub < cfg.decimation; ++sub)
-      dyn_substep(S, P, target, cfg.p_gains, cfg.d_gains, cfg.torque_limits, mass_scale, torques,
-                  sub == cfg.decimation - 1, shape_force);
+      dyn_substep(S, P, C, leg, target, kpl, kdl, tll, mass_scale, tau_leg, sub == cfg.decimation - 1, F);
   }
-  // rigid_body_state of knees/feet (post-step pose; at construction: the actor creation pose)
-  dyn_body_states(S, bo);
+  // rigid_body_state of this leg's knee / foot (post-step pose; at construction: the actor creation pose)
+  BodyOut bo[4];     // L_calf, L_toe, R_calf, R_toe
+  {
+    BodyOut calf, toe;
+    dyn_body_states(S, C, calf, toe);
+    auto swap_in = [&](const BodyOut& own, BodyOut& left, BodyOut& right) {
+      BodyOut oth;
+      oth.pos = xchg(own.pos); oth.linvel = xchg(own.linvel); oth.angvel = xchg(own.angvel);
+      for (int k = 0; k < 4; ++k) oth.quat[k] = xchg(own.quat[k]);
+      left = leg ? oth : own; right = leg ? own : oth;
+    };
+    swap_in(calf, bo[0], bo[2]);
+    swap_in(toe, bo[1], bo[3]);
+  }
+  // whole-robot joint vectors in DOF order (left 0-4, right 5-9), identical on both lanes
+  float qa[10], qda[10], torques[10];
+  for (int j = 0; j < 5; ++j) {
+    const float oq = xchg(S.q[j]), oqd = xchg(S.qd[j]), ot = xchg(tau_leg[j]);
+    qa[j] = leg ? oq : S.q[j];       qa[5 + j] = leg ? S.q[j] : oq;
+    qda[j] = leg ? oqd : S.qd[j];    qda[5 + j] = leg ? S.qd[j] : oqd;
+    torques[j] = leg ? ot : tau_leg[j]; torques[5 + j] = leg ? tau_leg[j] : ot;
+  }
+  V3 shape_force[5];     // base, L_thigh, L_toe, R_thigh, R_toe
+  {
+    const V3 oth = xchg(F.thigh), oto = xchg(F.toe);
+    shape_force[0] = F.base;
+    shape_force[1] = leg ? oth : F.thigh; shape_force[3] = leg ? F.thigh : oth;
+    shape_force[2] = leg ? oto : F.toe;   shape_force[4] = leg ? F.toe : oto;
+  }
+
+  // ---- glue state
+  float last_act[10], last_last_act[10], last_dof_vel[10], last_root_vel[6], cmd[4];
+  for (int j = 0; j < 10; ++j) { last_act[j] = LD(S_LAST_ACT + j); last_last_act[j] = LD(S_LAST_LAST_ACT + j); last_dof_vel[j] = LD(S_LAST_DOF_VEL + j); }
+  for (int j = 0; j < 6; ++j) last_root_vel[j] = LD(S_LAST_ROOT_VEL + j);
+  for (int j = 0; j < 4; ++j) cmd[j] = LD(S_CMD + j);
+  float air[2] = {LD(S_AIR), LD(S_AIR + 1)};
+  float last_contact[2] = {LD(S_LAST_CONTACT), LD(S_LAST_CONTACT + 1)};
+  float feet_h[2] = {LD(S_FEET_H), LD(S_FEET_H + 1)};
+  float last_feet_z[2] = {LD(S_LAST_FEET_Z), LD(S_LAST_FEET_Z + 1)};
+  float push_f[2] = {LD(S_PUSH_F), LD(S_PUSH_F + 1)};
+  float push_t[3] = {LD(S_PUSH_T), LD(S_PUSH_T + 1), LD(S_PUSH_T + 2)};
+  const V3 origin = mk(LD(S_ORIGIN), LD(S_ORIGIN + 1), LD(S_ORIGIN + 2));
+  V3 base_lin_vel = mk(LD(S_BLV), LD(S_BLV + 1), LD(S_BLV + 2));
+  V3 base_ang_vel = mk(LD(S_BAV), LD(S_BAV + 1), LD(S_BAV + 2));
+  float ep_ret = LD(S_EP_RET);
 
   const float TWO_PI = 6.283185307179586f;
   V3 euler, pgrav;
@@ -244,13 +285,13 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
     float sm[2];
     stance_mask(ep_len, sm);
     float dq0[10];
-    for (int j = 0; j < 10; ++j) dq0[j] = S.q[j] - cfg.default_dof_pos[j];
+    for (int j = 0; j < 10; ++j) dq0[j] = qa[j] - cfg.default_dof_pos[j];
     const float* sc = cfg.reward_scale;
     float rsum = 0.f;
     auto add = [&](int id, float r) {
       const float x = r * sc[id];
       rsum += x;
-      p.ep_sums[(size_t)id * n + e] += x;
+      if (writer) p.ep_sums[(size_t)id * n + e] += x;
     };
     if (sc[HX_R_ACTION_SMOOTHNESS] != 0.f) {
       float t1 = 0, t2 = 0, t3 = 0;
@@ -281,11 +322,11 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
       add(HX_R_DEFAULT_JOINT_POS, expf(-yr * 100.f) - 0.01f * sqrtf(s2));
     }
     if (sc[HX_R_DOF_ACC] != 0.f) {
-      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = (last_dof_vel[j] - S.qd[j]) / cfg.env_dt; s2 += d * d; }
+      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = (last_dof_vel[j] - qda[j]) / cfg.env_dt; s2 += d * d; }
       add(HX_R_DOF_ACC, s2);
     }
     if (sc[HX_R_DOF_VEL] != 0.f) {
-      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += S.qd[j] * S.qd[j];
+      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += qda[j] * qda[j];
       add(HX_R_DOF_VEL, s2);
     }
     if (sc[HX_R_FEET_AIR_TIME] != 0.f) {
@@ -344,7 +385,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
       const float l = sp > 0.f ? 0.f : sp, r_ = sp < 0.f ? 0.f : sp;
       ref[2] = l * s1; ref[3] = l * s2c; ref[4] = l * s1; ref[7] = r_ * s1; ref[8] = r_ * s2c; ref[9] = r_ * s1;
       if (fabsf(sp) < 0.1f) for (int j = 0; j < 10; ++j) ref[j] = 0.f;
-      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = S.q[j] - ref[j]; s2 += d * d; }
+      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = qa[j] - ref[j]; s2 += d * d; }
       const float nn = sqrtf(s2);
       add(HX_R_JOINT_POS, expf(-2.f * nn) - 0.2f * clampf(nn, 0.f, 0.5f));
     }
@@ -396,8 +437,8 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
   // ---- reset_idx (legged_robot.py:162-214 ; hector_env.py:256-261)
   if (reset) {
     for (int j = 0; j < 10; ++j) {
-      S.q[j] = cfg.default_dof_pos[j] + (0.3f * rng.uni(HX_RP_RESET_Q + j) - 0.15f);
-      S.qd[j] = 0.f;
+      qa[j] = cfg.default_dof_pos[j] + (0.3f * rng.uni(HX_RP_RESET_Q + j) - 0.15f);
+      qda[j] = 0.f;
     }
     S.pos = mk(cfg.base_init_state[0] + origin.x, cfg.base_init_state[1] + origin.y, cfg.base_init_state[2] + origin.z);
     if (cfg.custom_origins) {
@@ -418,11 +459,13 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
     const int finished_len = ep_len;
     ep_len = 0;
     for (int r = 0; r < HX_NUM_REWARDS; ++r) {
-      const float s = p.ep_sums[(size_t)r * n + e];
-      if (A.mode == 0 && s != 0.f) atomicAdd(&p.stat_sum[r], s);
-      p.ep_sums[(size_t)r * n + e] = 0.f;
+      if (writer) {
+        const float s = p.ep_sums[(size_t)r * n + e];
+        if (A.mode == 0 && s != 0.f) atomicAdd(&p.stat_sum[r], s);
+        p.ep_sums[(size_t)r * n + e] = 0.f;
+      }
     }
-    if (A.mode == 0) {
+    if (A.mode == 0 && writer) {
       // Train/mean_reward and Train/mean_episode_length of the runner (on_policy_runner.py:140-154)
       atomicAdd(&p.stat_sum[HX_NUM_REWARDS], ep_ret);
       atomicAdd(&p.stat_sum[HX_NUM_REWARDS + 1], (float)finished_len);
@@ -444,8 +487,8 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
     f[0] = sp; f[1] = cp;
     f[2] = cmd[0] * cfg.obs_scale_lin_vel; f[3] = cmd[1] * cfg.obs_scale_lin_vel; f[4] = cmd[2] * cfg.obs_scale_ang_vel;
     for (int j = 0; j < 10; ++j) {
-      f[5 + j] = (S.q[j] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos;
-      f[15 + j] = S.qd[j] * cfg.obs_scale_dof_vel;
+      f[5 + j] = (qa[j] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos;
+      f[15 + j] = qda[j] * cfg.obs_scale_dof_vel;
       f[25 + j] = act[j];
     }
     // obs41 = [cmd5, q10, dq10, a10, ang_vel3, euler3]
@@ -458,7 +501,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
         const float sv = cfg.noise_scale_vec[k];
         if (sv != 0.f) o[k] = o[k] + rng.nrm(HX_RP_OBS_NOISE + k) * sv * cfg.noise_level;
       }
-    for (int k = 0; k < HX_OBS_FRAME; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
+    if (writer) for (int k = 0; k < HX_OBS_FRAME; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
     f[35] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[36] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[37] = base_lin_vel.z * cfg.obs_scale_lin_vel;
     f[38] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[39] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[40] = base_ang_vel.z * cfg.obs_scale_ang_vel;
     f[41] = euler.x * cfg.obs_scale_quat; f[42] = euler.y * cfg.obs_scale_quat; f[43] = euler.z * cfg.obs_scale_quat;
@@ -468,21 +511,22 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, hx_sim_cfg c
     f[59] = push_f[0]; f[60] = push_f[1]; f[61] = push_t[0]; f[62] = push_t[1]; f[63] = push_t[2];
     f[64] = friction; f[65] = base_mass / 30.f;
     f[66] = sm[0]; f[67] = sm[1]; f[68] = contact[0] ? 1.f : 0.f; f[69] = contact[1] ? 1.f : 0.f;
-    for (int k = 0; k < HX_PRIV_FRAME; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+    if (writer) for (int k = 0; k < HX_PRIV_FRAME; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
   }
 
   // ---- bookkeeping (legged_robot.py:146-150) and store
   if (A.mode == 0) {
-    for (int j = 0; j < 10; ++j) { last_last_act[j] = last_act[j]; last_act[j] = act[j]; last_dof_vel[j] = S.qd[j]; }
+    for (int j = 0; j < 10; ++j) { last_last_act[j] = last_act[j]; last_act[j] = act[j]; last_dof_vel[j] = qda[j]; }
     last_root_vel[0] = S.linvel.x; last_root_vel[1] = S.linvel.y; last_root_vel[2] = S.linvel.z;
     last_root_vel[3] = S.angvel.x; last_root_vel[4] = S.angvel.y; last_root_vel[5] = S.angvel.z;
   }
+  if (!writer) return;
   ST(S_ROOT_POS, S.pos.x); ST(S_ROOT_POS + 1, S.pos.y); ST(S_ROOT_POS + 2, S.pos.z);
   for (int i = 0; i < 4; ++i) ST(S_ROOT_QUAT + i, S.quat[i]);
   ST(S_LINVEL, S.linvel.x); ST(S_LINVEL + 1, S.linvel.y); ST(S_LINVEL + 2, S.linvel.z);
   ST(S_ANGVEL, S.angvel.x); ST(S_ANGVEL + 1, S.angvel.y); ST(S_ANGVEL + 2, S.angvel.z);
   for (int j = 0; j < 10; ++j) {
-    ST(S_Q + j, S.q[j]); ST(S_QD + j, S.qd[j]); ST(S_ACT + j, act[j]); ST(S_LAST_ACT + j, last_act[j]);
+    ST(S_Q + j, qa[j]); ST(S_QD + j, qda[j]); ST(S_ACT + j, act[j]); ST(S_LAST_ACT + j, last_act[j]);
     ST(S_LAST_LAST_ACT + j, last_last_act[j]); ST(S_LAST_DOF_VEL + j, last_dof_vel[j]);
     p.torques[(size_t)j * n + e] = torques[j];
   }
@@ -545,6 +589,7 @@ extern "C" int hx_sync(void* stream) { HX_CHECK(hipStreamSynchronize((hipStream_
 
 struct hx_sim {
   hx_sim_cfg cfg;
+  hx_sim_cfg* cfg_d;
   hipStream_t stream;
   bool own_stream;
   SimPtrs p;
@@ -610,6 +655,8 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
     st[(size_t)S_BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : HXM_MASS[0];
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (dalloc(s, &s->cfg_d, 1)) return -3;
+  HX_CHECK(hipMemcpy(s->cfg_d, &s->cfg, sizeof(hx_sim_cfg), hipMemcpyHostToDevice));
   *out = s;
   return 0;
 }
@@ -632,7 +679,7 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   A.k1 = (uint32_t)(s->seed >> 32);
   A.rng_step = s->rng_step++;
   HX_CHECK(hipMemsetAsync(s->p.num_reset, 0, sizeof(int), s->stream));
-  hipLaunchKernelGGL(hx_env_step_kernel, dim3((n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg, actions, pack, A);
+  hipLaunchKernelGGL(hx_env_step_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
   const int nxt = s->cur ^ 1;
   hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, s->obs[s->cur], s->obs[nxt], s->p.obs_frame, s->p.reset,
                      n, HX_OBS_FRAME, HX_OBS_LD, s->cfg.clip_observations, s->p.timeout, s->timeout_visible, s->p.num_reset);

@@ -100,12 +100,21 @@ class TorchComm(Comm):
             self.torch.cuda.current_stream().synchronize()
 
     def all_reduce_moments(self, ptr, stream):
-        from . import capi
-        m = capi.download(ptr, np.float64, (3,), stream)
+        """[sum, sum of squares, count] of the raw advantages (3 doubles) -> global moments on every rank."""
+        import ctypes
+        if self.backend == "nccl":
+            from . import capi
+            m = capi.download(ptr, np.float64, (3,), stream)
+        else:                                   # gloo: the pointer is host memory (CPU tests of the orchestration)
+            m = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), (3,)).copy()
         t = self.torch.from_numpy(m).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        m = t.cpu().numpy()
-        capi.check(capi.lib().hx_memcpy_h2d(ptr, capi.ptr(np.ascontiguousarray(m)), 24, stream), "h2d")
+        m = np.ascontiguousarray(t.cpu().numpy())
+        if self.backend == "nccl":
+            from . import capi
+            capi.check(capi.lib().hx_memcpy_h2d(ptr, capi.ptr(m), 24, stream), "h2d")
+        else:
+            ctypes.memmove(ptr, m.ctypes.data, 24)
 
     def barrier(self):
         self.dist.barrier()

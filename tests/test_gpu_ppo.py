@@ -134,3 +134,40 @@ def test_rollout_overflow_raises(hxlib):
         alg.process_env_step(np.zeros(16, np.float32), np.zeros(16, np.uint8), {})
     with pytest.raises(RuntimeError, match="Rollout buffer overflow"):     # rollout_storage.py:88-89
         alg.act(*z)
+
+
+def test_collective_code_path_single_rank(hxlib):
+    """Walk the multi-GPU path with one rank: torch-owned external gradient buffer, RCCL all-reduce through
+    torch.distributed (backend nccl), 1/world scaling in the Adam kernel.  With world_size 1 the result must be
+    bit-identical to the fused single-process path."""
+    import os
+    import torch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from isaac_amd.parallel import TorchComm
+    comm = TorchComm("nccl")
+    comm.force_collectives = True
+    seed, T, N = 31, 4, 64
+    inp = rollout_inputs(seed, T, N)
+    perm = np.random.default_rng(1).permutation(T * N).astype(np.int32)
+    results = []
+    for c in (None, comm):
+        init = ActorCriticOracle.default_init(np.random.default_rng(seed))
+        ac = ActorCritic(615, 1050, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[768, 256, 128])
+        ac.load_state_dict(init.state_dict())
+        alg = PPO(ac, num_learning_epochs=2, num_mini_batches=4, gamma=0.994, lam=0.9, entropy_coef=0.001, learning_rate=1e-4,
+                  schedule="adaptive", desired_kl=0.01, comm=c)
+        alg.init_storage(N, T, [615], [1050], [10])
+        for t in range(T):
+            alg.act(inp["obs"][t], inp["priv"][t], eps=inp["eps"][t])
+            alg.process_env_step(inp["rewards"][t], inp["dones"][t].astype(np.uint8), {"time_outs": inp["time_outs"][t].astype(np.uint8)})
+        alg.compute_returns(inp["priv"][T])
+        losses = alg.update(perm=perm)
+        results.append((losses, alg.learning_rate, ac.state_dict()))
+        alg.close()
+    (l0, lr0, sd0), (l1, lr1, sd1) = results
+    assert l0 == l1 and lr0 == lr1
+    for k in sd0:
+        np.testing.assert_array_equal(sd0[k], sd1[k], err_msg=k)
+    torch.distributed.destroy_process_group()

@@ -217,6 +217,25 @@ def main():
     iarr("HXM_CONTACT_BODY", [c["body"] for c in contacts])
     arr("HXM_CONTACT_PTS", [x for c in contacts for p in c["points"] for x in p])
     L.append("#define HX_NCSHAPE %d" % len(contacts))
+    # per-leg constant table staged in LDS by the two-lanes-per-robot kernel:
+    # leg l, local body b (0 hip, 1 hip2, 2 thigh, 3 calf, 4 toe) at [l*128 + b*16 + ...]:
+    #   0-2 joint offset, 3-5 h = m*com, 6-11 Io (xx yy zz xy xz yz), 12 mass, 13 q_lo, 14 q_hi, 15 v_max
+    # then 24 floats thigh box corners at [l*128 + 80], 24 floats toe box corners at [l*128 + 104]
+    legc = []
+    for leg in range(2):
+        row = []
+        for b in range(5):
+            bd = bodies[1 + leg * 5 + b]
+            c = np.array(bd["com"]); m = bd["mass"]
+            Io = np.array(bd["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
+            row += list(bd["offset"]) + list(m * c) + [Io[0, 0], Io[1, 1], Io[2, 2], Io[0, 1], Io[0, 2], Io[1, 2]]
+            row += [m, bd["lower"], bd["upper"], bd["velocity"]]
+        row += [x for pt in contacts[1 + 2 * leg]["points"] for x in pt]
+        row += [x for pt in contacts[2 + 2 * leg]["points"] for x in pt]
+        assert len(row) == 128
+        legc += row
+    L.append("#define HX_LEGC_STRIDE 128")
+    L.append("__device__ static const float HXM_LEGC[256] = {%s};" % ", ".join(flit(v) for v in legc))
     with open(os.path.join(ROOT, "isaac_amd/csrc/hx_model_data.h"), "w") as f:
         f.write("\n".join(L) + "\n")
 
