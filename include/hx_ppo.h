@@ -84,9 +84,13 @@ int hx_ppo_inference(hx_ppo* p, const float* obs, int rows, float* actions_out);
  * launch): which=1 starts/clears, which=0 stops and returns, per kernel symbol
  * {fwd 128x128, fwd 64x128, dgrad 128x128, dgrad 64x128, wgrad split-K}: {milliseconds, launches, flops} */
 int hx_ppo_prof(hx_ppo* p, int which, double* out_h /*[15]*/, void* reserved);
-/* unit-test hook: one GEMM of the given mode (0 fwd bias+ELU, 1 dgrad * elu', 2 wgrad split-K) */
+/* unit-test hook: one GEMM of the given mode (0/3 fwd bias+ELU 128/64-row tile, 1/4 dgrad * elu', 2 wgrad single
+ * split); add 10 for the BK = 32 variant */
 int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      const float* bias, float* C, int ldc, const float* H, void* hip_stream);
+
+/* timing hook: mean ms per launch of one learner GEMM (kind 0 fwd, 1 dgrad, 2 wgrad split-K; bk 16 or 32) */
+int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out);
 
 /* device memory helpers for hosts without a tensor library */
 int hx_malloc(size_t bytes, void** out);

@@ -126,6 +126,7 @@ def lib():
     L.hx_ppo_set_lr.argtypes = [vp, C.c_float]
     L.hx_ppo_inference.argtypes = [vp, vp, C.c_int, vp]
     L.hx_ppo_prof.argtypes = [vp, C.c_int, vp, vp]
+    L.hx_ppo_gemm_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.hx_ppo_gemm_test.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     _lib = L
     return L

@@ -7,7 +7,7 @@
 //   WGRAD  dW[M,N] = dZ[K,M]^T X[K,N]   (split-K)     A M-major, B N-major,  epilogue -> partial slab
 // (M,N,K are always the GEMM's own output rows / output cols / reduction length.)
 //
-// Tile: BM x BN x 16 per 256-thread workgroup (4 waves as 2x2), each wave (BM/2)x(BN/2) as 32x32 MFMA
+// Tile: BM x BN x BK (BK = 16 or 32) per 256-thread workgroup (4 waves as 2x2), each wave (BM/2)x(BN/2) as 32x32 MFMA
 // tiles.  fp32 MFMA is exact fp32 (k-ordered fma chain) and runs at the fp32 vector rate, so LDS and
 // global bandwidth are never the limiter; the layout work here is about keeping every LDS access
 // conflict-free and every global access a whole 64-byte segment:
@@ -37,12 +37,13 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-#define HX_BK 16
 #define HX_KPAD 4
 
-__device__ __forceinline__ float hx_elu(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU(alpha=1).  exp(x)-1 through the hardware exp2 (abs error < 1.2e-7 for x <= 0, i.e. fp32 round-off of the
+// activation's own scale); the libm expm1f it replaces cost ~10 % of a short-K GEMM's epilogue.
+__device__ __forceinline__ float hx_elu(float x) { return x > 0.f ? x : (__expf(x) - 1.0f); }
 
-template <int BM, int BN, bool A_KM, bool B_KM, int EPI>
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI>
 __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
       const int idx = tid + i * 256;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (A_KM) {
-        const int row = idx >> 2, k4 = idx & 3;
+        const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
         const int gm = m0 + row, gk = k0 + k4 * 4;
         if (gm < g.M && gk < k_end) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gm * g.lda + gk);
       } else {
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
       const int idx = tid + i * 256;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (B_KM) {
-        const int row = idx >> 2, k4 = idx & 3;
+        const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
         const int gn = n0 + row, gk = k0 + k4 * 4;
         if (gn < g.N && gk < k_end) v = *reinterpret_cast<const f32x4*>(g.B + (size_t)gn * g.ldb + gk);
       } else {
@@ -125,13 +126,13 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int idx = tid + i * 256;
-      if (A_KM) { const int row = idx >> 2, k4 = idx & 3; *reinterpret_cast<f32x4*>(As + row * (HX_BK + HX_KPAD) + k4 * 4) = ra[i]; }
+      if (A_KM) { const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4); *reinterpret_cast<f32x4*>(As + row * (HX_BK + HX_KPAD) + k4 * 4) = ra[i]; }
       else { const int k = idx / (BM / 4), m4 = idx % (BM / 4); *reinterpret_cast<f32x4*>(As + k * BM + m4 * 4) = ra[i]; }
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
       const int idx = tid + i * 256;
-      if (B_KM) { const int row = idx >> 2, k4 = idx & 3; *reinterpret_cast<f32x4*>(Bs + row * (HX_BK + HX_KPAD) + k4 * 4) = rb[i]; }
+      if (B_KM) { const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4); *reinterpret_cast<f32x4*>(Bs + row * (HX_BK + HX_KPAD) + k4 * 4) = rb[i]; }
       else { const int k = idx / (BN / 4), n4 = idx % (BN / 4); *reinterpret_cast<f32x4*>(Bs + k * BN + n4 * 4) = rb[i]; }
     }
   };

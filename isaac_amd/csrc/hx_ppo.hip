@@ -19,6 +19,12 @@
 #include "hx_gemm.h"
 
 #define MAX_A 16
+#ifndef HX_BK_UPD
+#define HX_BK_UPD 16      // K-depth of the LDS tile for the 61 440-row update GEMMs
+#endif
+#ifndef HX_BK_ROLL
+#define HX_BK_ROLL 16     // K-depth for the 4096-row rollout GEMMs
+#endif
 static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
 // ================================================================= small kernels
@@ -487,7 +493,7 @@ template <typename T> static int palloc(hx_ppo* s, T** ptr, size_t count) {
 }
 
 // ---- GEMM dispatch
-template <int BM, int BN, bool AK, bool BK_, int EPI> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
@@ -498,28 +504,32 @@ template <int BM, int BN, bool AK, bool BK_, int EPI> static void launch_gemm(hx
   }
   if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
     (void)hipEventRecord(s->ev[s->ev_used], st);
-    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
     (void)hipEventRecord(s->ev[s->ev_used + 1], st);
     s->ev_kid[s->ev_used] = kid;
     s->ev_used += 2;
     s->prof_flops[kid] += 2.0 * g.M * g.N * g.K;
     s->prof_launches[kid] += 1;
   } else {
-    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
   }
 }
 
+// Variant choice per shape is from measurement (tools/gemm_bench.py, profiles/r01_gemm_variants.txt): with few
+// output tiles (N <= 256) the tail of the launch dominates, and either two resident workgroups of a deeper
+// K tile (forward) or half-height tiles (dgrad, K <= 256) shorten it.
 static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
-  if (M >= 16384) launch_gemm<128, 128, true, true, EPI_BIAS_ELU>(s, g, st);
-  else launch_gemm<64, 128, true, true, EPI_BIAS_ELU>(s, g, st);
+  if (M >= 16384) {
+    if (N <= 256 && K >= 512) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
+    else launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
+  } else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
   GemmArgs g{};
   g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = N; g.M = M; g.N = N; g.K = K; g.H = H; g.ldh = N;
-  if (M >= 16384) launch_gemm<128, 128, true, false, EPI_ELU_GRAD>(s, g, st);
-  else launch_gemm<64, 128, true, false, EPI_ELU_GRAD>(s, g, st);
+  launch_gemm<64, 128, 16, true, false, EPI_ELU_GRAD>(s, g, st);
 }
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab / bias_slab
 static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab) {
@@ -529,10 +539,10 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   int splits = (1024 + tiles - 1) / tiles;
   int max_splits = Mrows / 256; if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
-  int kchunk = rup((Mrows + splits - 1) / splits, HX_BK);
+  int kchunk = rup((Mrows + splits - 1) / splits, 32);
   splits = (Mrows + kchunk - 1) / kchunk;
   g.splits = splits; g.kchunk = kchunk; g.dbias = bias_slab;
-  launch_gemm<128, 128, false, false, EPI_SLAB>(s, g, st);
+  launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
   return splits;
 }
 
@@ -541,16 +551,63 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.H = H; g.ldh = ldc;
-  if (mode == 0) launch_gemm<128, 128, true, true, EPI_BIAS_ELU>(nullptr, g, st);
-  else if (mode == 3) launch_gemm<64, 128, true, true, EPI_BIAS_ELU>(nullptr, g, st);
-  else if (mode == 1) launch_gemm<128, 128, true, false, EPI_ELU_GRAD>(nullptr, g, st);
-  else if (mode == 4) launch_gemm<64, 128, true, false, EPI_ELU_GRAD>(nullptr, g, st);
-  else if (mode == 2) {
-    // single split, direct output (C must hold [M][ldc]); bias -> column sums written to `bias` (cast away const for the test)
-    g.splits = 1; g.kchunk = rup(K, HX_BK); g.dbias = const_cast<float*>(bias);
-    launch_gemm<128, 128, false, false, EPI_SLAB>(nullptr, g, st);
+  const int variant = mode / 10;     // 0: BK 16, 1: BK 32
+  mode %= 10;
+#define HX_DISPATCH(BKV)                                                                                   \
+  if (mode == 0) launch_gemm<128, 128, BKV, true, true, EPI_BIAS_ELU>(nullptr, g, st);                      \
+  else if (mode == 3) launch_gemm<64, 128, BKV, true, true, EPI_BIAS_ELU>(nullptr, g, st);                  \
+  else if (mode == 1) launch_gemm<128, 128, BKV, true, false, EPI_ELU_GRAD>(nullptr, g, st);                \
+  else if (mode == 4) launch_gemm<64, 128, BKV, true, false, EPI_ELU_GRAD>(nullptr, g, st);                 \
+  else if (mode == 2) {                                                                                    \
+    /* single split, direct output (C holds [M][ldc]); column sums of A are written to `bias` */           \
+    g.splits = 1; g.kchunk = rup(K, 32); g.dbias = const_cast<float*>(bias);                               \
+    launch_gemm<128, 128, BKV, false, false, EPI_SLAB>(nullptr, g, st);                                     \
   } else { hx_set_error("hx_ppo_gemm_test: bad mode"); return -2; }
+  if (variant == 0) { HX_DISPATCH(16) } else { HX_DISPATCH(32) }
+#undef HX_DISPATCH
   HX_CHECK(hipGetLastError());
+  return 0;
+}
+
+// timing hook (tools/gemm_bench.py): `iters` launches of one learner GEMM on scratch buffers filled with a
+// non-trivial bit pattern; returns the mean milliseconds per launch measured with HIP events on the stream.
+extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out) {
+  // kind 0: fwd  Y[rows][out] = X[rows][in_ld] W[out][in_ld]^T ; 1: dgrad dX[rows][in_ld] = dZ[rows][out] W[out][in_ld]
+  // kind 2: wgrad dW[out][in_ld] = dZ[rows][out]^T X[rows][in_ld] with the production split-K
+  float *X, *W, *Y, *slab, *bslab;
+  const size_t nx = (size_t)rows * in_ld, ny = (size_t)rows * out, nw = (size_t)out * in_ld;
+  HX_CHECK(hipMalloc(&X, nx * 4)); HX_CHECK(hipMalloc(&W, nw * 4)); HX_CHECK(hipMalloc(&Y, ny * 4));
+  const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
+  int splits = (1024 + tiles - 1) / tiles; int max_splits = rows / 256; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
+  int kchunk = rup((rows + splits - 1) / splits, 32); splits = (rows + kchunk - 1) / kchunk;
+  HX_CHECK(hipMalloc(&slab, (size_t)splits * nw * 4)); HX_CHECK(hipMalloc(&bslab, (size_t)splits * out * 4));
+  HX_CHECK(hipMemset(X, 0x3d, nx * 4)); HX_CHECK(hipMemset(W, 0x3c, nw * 4)); HX_CHECK(hipMemset(Y, 0x3b, ny * 4));
+  hipStream_t st; HX_CHECK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; HX_CHECK(hipEventCreate(&e0)); HX_CHECK(hipEventCreate(&e1));
+  const int bm = bk / 100 ? 64 : 128; bk %= 100;
+  auto run = [&]() {
+    GemmArgs g{};
+#define HX_V(BMV, BKV, AK, BKM, EPI) launch_gemm<BMV, 128, BKV, AK, BKM, EPI>(nullptr, g, st)
+#define HX_PICK(AK, BKM, EPI) do { if (bm == 128) { if (bk == 16) HX_V(128, 16, AK, BKM, EPI); else HX_V(128, 32, AK, BKM, EPI); } \
+                                   else { if (bk == 16) HX_V(64, 16, AK, BKM, EPI); else HX_V(64, 32, AK, BKM, EPI); } } while (0)
+    if (kind == 0) { g.A = X; g.lda = in_ld; g.B = W; g.ldb = in_ld; g.C = Y; g.ldc = out; g.M = rows; g.N = out; g.K = in_ld; g.bias = bslab;
+      HX_PICK(true, true, EPI_BIAS_ELU); }
+    else if (kind == 1) { g.A = Y; g.lda = out; g.B = W; g.ldb = in_ld; g.C = X; g.ldc = in_ld; g.M = rows; g.N = in_ld; g.K = out; g.H = X; g.ldh = in_ld;
+      HX_PICK(true, false, EPI_ELU_GRAD); }
+    else { g.A = Y; g.lda = out; g.B = X; g.ldb = in_ld; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = rows; g.splits = splits; g.kchunk = kchunk; g.dbias = bslab;
+      if (bk == 16) HX_V(128, 16, false, false, EPI_SLAB); else HX_V(128, 32, false, false, EPI_SLAB); }
+#undef HX_PICK
+#undef HX_V
+  };
+  for (int i = 0; i < 3; ++i) run();
+  HX_CHECK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) run();
+  HX_CHECK(hipEventRecord(e1, st));
+  HX_CHECK(hipStreamSynchronize(st));
+  float ms = 0; HX_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(slab); (void)hipFree(bslab);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
   return 0;
 }
 
@@ -645,7 +702,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
 
 extern "C" void hx_ppo_destroy(hx_ppo* s) {
   if (!s) return;
-  (void)hipStreamSynchronize(s->stream);
+  (void)hipDeviceSynchronize();      // the stream may be borrowed from an env that no longer exists
   for (void* a : s->allocs) (void)hipFree(a);
   for (auto e : s->ev) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);

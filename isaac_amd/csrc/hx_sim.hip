@@ -663,7 +663,7 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
 
 extern "C" void hx_sim_destroy(hx_sim* s) {
   if (!s) return;
-  hipStreamSynchronize(s->stream);
+  (void)hipDeviceSynchronize();
   for (void* a : s->allocs) hipFree(a);
   if (s->own_stream) hipStreamDestroy(s->stream);
   delete s;

@@ -73,3 +73,13 @@ def test_mfma_layout_asymmetric(hxlib):
     capi.check(hxlib.hx_ppo_gemm_test(0, M, N, K, dA.ptr, K, dB.ptr, K, db.ptr, dC.ptr, N, None, None), "gemm")
     out = dC.download(np.float32, (M, N))
     np.testing.assert_allclose(out, W.T, rtol=0, atol=1e-6)      # elu is the identity for positive inputs
+
+
+@pytest.mark.parametrize("mode,M,N,K", [(10, 1000, 768, 1050), (13, 4096, 256, 512), (11, 1000, 512, 256), (14, 33, 132, 8),
+                                        (12, 768, 1052, 1000), (12, 100, 36, 77)])
+def test_gemm_modes_bk32(hxlib, mode, M, N, K):
+    """The BK = 32 instantiations (mode + 10) against the same float64 references."""
+    import types
+    real = hxlib.hx_ppo_gemm_test
+    shim = types.SimpleNamespace(hx_ppo_gemm_test=lambda m, *a: real(m + 10, *a))
+    _run(shim, mode - 10, M, N, K, np.random.default_rng(mode + M + N + K))
