@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--shards", type=int, default=1, help="env shards per GPU driven round-robin on separate streams (1 = off; measured slower than the deferred-critic overlap, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -79,7 +80,7 @@ def main():
     from isaac_amd import capi
     from isaac_amd.parallel import init_comm
     from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO
-    from isaac_amd.envs.hector_env import HectorFreeEnv, class_to_dict
+    from isaac_amd.envs.hector_env import HectorFreeEnv, PipelinedHectorEnv, class_to_dict
     from isaac_amd.algo.on_policy_runner import OnPolicyRunner
     from isaac_amd.utils.helpers import set_seed
 
@@ -94,7 +95,10 @@ def main():
     env_cfg, train_cfg = HectorCfg(), HectorCfgPPO()
     env_cfg.env.num_envs = args.envs
     env_cfg.seed = set_seed(train_cfg.seed + comm.rank)
-    env = HectorFreeEnv(env_cfg, sim_device=f"cuda:{local}", headless=True)
+    if args.shards > 1:
+        env = PipelinedHectorEnv(env_cfg, sim_device=f"cuda:{local}", headless=True, num_shards=args.shards)
+    else:
+        env = HectorFreeEnv(env_cfg, sim_device=f"cuda:{local}", headless=True)
     runner = OnPolicyRunner(env, class_to_dict(train_cfg), log_dir=None, device=f"cuda:{local}", comm=comm)
     T = runner.num_steps_per_env
 
@@ -120,7 +124,7 @@ def main():
                "config": {"workload": f"hector {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
                                       "update 2 epochs x 4 minibatches, fp32 HIP sim + MLP actor [512,256,128] / critic [768,256,128]",
                           "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
-                          "terrain": "plane", "collection_s": runner.last_perf.get("collection_time"),
+                          "terrain": "plane", "env_shards": args.shards, "collection_s": runner.last_perf.get("collection_time"),
                           "learn_s": runner.last_perf.get("learn_time")}}
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])

@@ -66,7 +66,14 @@ int hx_ppo_get_opt_state_h(hx_ppo* p, float* exp_avg_h, float* exp_avg_sq_h, int
 
 int hx_ppo_act(hx_ppo* p, const float* obs, const float* priv, const float* eps /*[N][A], nullable*/, float** actions_out);
 int hx_ppo_process_step(hx_ppo* p, const float* rewards, const uint8_t* dones, const uint8_t* time_outs /*nullable*/);
-int hx_ppo_compute_returns(hx_ppo* p, const float* last_priv);
+int hx_ppo_compute_returns(hx_ppo* p, const float* last_priv /*NULL: values set by hx_ppo_last_values_range*/);
+/* Shard forms for a rollout that runs as several independent env shards, each on its own stream, so that one
+ * shard's (latency-bound) env step overlaps another shard's GEMMs.  Rows [env0, env0+count) of the same slot. */
+int hx_ppo_act_range(hx_ppo* p, const float* obs, const float* priv, const float* eps, int env0, int count,
+                     void* hip_stream, float** actions_out);
+int hx_ppo_process_step_range(hx_ppo* p, const float* rewards, const uint8_t* dones, const uint8_t* time_outs,
+                              int env0, int count, void* hip_stream, int advance_slot);
+int hx_ppo_last_values_range(hx_ppo* p, const float* last_priv, int env0, int count, void* hip_stream);
 int hx_ppo_adv_moments(hx_ppo* p, void** moments /* double[3] on device: sum, sum of squares, count */);
 int hx_ppo_adv_normalize(hx_ppo* p);
 
@@ -75,6 +82,11 @@ int hx_ppo_minibatch_backward(hx_ppo* p, int mb_index, void** grad_buffer, int64
 int hx_ppo_minibatch_step(hx_ppo* p, float inv_world_size);
 int hx_ppo_update_end(hx_ppo* p, float* stats_h /*[4]: mean value loss, mean surrogate loss, lr, last kl*/);
 int hx_ppo_update(hx_ppo* p, const int32_t* perm, float* stats_h);
+
+/* `steps` iterations of {PPO.act, env.step, PPO.process_env_step} (on_policy_runner.py:127-138) without returning
+ * to the host language; sims[h] simulates env rows [env0[h], env0[h]+count[h]).  hx_sim is declared in hx_sim.h. */
+struct hx_sim;
+int hx_rollout(hx_ppo* p, struct hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps);
 
 int hx_ppo_buffer(hx_ppo* p, int which, void** dptr);
 int hx_ppo_get_lr(hx_ppo* p, float* lr_h);

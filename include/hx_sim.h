@@ -109,6 +109,9 @@ typedef struct hx_sim_cfg {
   float cycle_time, tracking_sigma, max_contact_force;
   /* physics model (DESIGN.md "Physics model"; no counterpart in the reference, PhysX is opaque) */
   float contact_kn, contact_dn, friction_veps, limit_k, limit_d, terrain_mu;
+  /* this object simulates envs [env_id_offset, env_id_offset + num_envs) of a larger logical batch: only the
+   * random streams depend on it (Philox is keyed by the global env id) */
+  int32_t env_id_offset;
 } hx_sim_cfg;
 
 typedef struct hx_sim hx_sim;

@@ -55,7 +55,7 @@ class OnPolicyRunner:
         self.tot_time = 0
         self.current_learning_iteration = 0
         self.last_perf = {}
-        _, _ = self.env.reset()
+        self.env.reset()
 
     # ------------------------------------------------------------------ training loop
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
@@ -70,6 +70,9 @@ class OnPolicyRunner:
             except ImportError:                          # pragma: no cover
                 r = np.random.randint(0, int(env.max_episode_length), env.num_envs)
             env.episode_length_buf = r.astype(np.int32)
+        shards = getattr(env, "shards", None)
+        if shards is not None:
+            return self._learn_pipelined(num_learning_iterations)
         obs = env.get_observations()
         privileged_obs = env.get_privileged_observations()
         critic_obs = privileged_obs if privileged_obs is not None else obs
@@ -78,11 +81,16 @@ class OnPolicyRunner:
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
-            for _ in range(self.num_steps_per_env):
-                actions = alg.act(obs, critic_obs)
-                obs, privileged_obs, rewards, dones, infos = env.step(actions)
+            if hasattr(env, "_h") and hasattr(alg, "rollout"):
+                alg.rollout([env], self.num_steps_per_env)          # the same 60-step loop, issued from C
+                obs, privileged_obs = env.get_observations(), env.get_privileged_observations()
                 critic_obs = privileged_obs if privileged_obs is not None else obs
-                alg.process_env_step(rewards, dones, infos)
+            else:
+                for _ in range(self.num_steps_per_env):
+                    actions = alg.act(obs, critic_obs)
+                    obs, privileged_obs, rewards, dones, infos = env.step(actions)
+                    critic_obs = privileged_obs if privileged_obs is not None else obs
+                    alg.process_env_step(rewards, dones, infos)
             env.sync()
             stop = time.time()
             collection_time = stop - start
@@ -98,6 +106,40 @@ class OnPolicyRunner:
                 self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,
                               mean_value_loss=mean_value_loss, mean_surrogate_loss=mean_surrogate_loss,
                               ep_info=ep_info, n_ep=n_ep, rewbuffer=rewbuffer, lenbuffer=lenbuffer))
+                if it % self.save_interval == 0:
+                    self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
+        self.current_learning_iteration += num_learning_iterations
+        if self.log_dir is not None:
+            self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
+
+    def _learn_pipelined(self, num_learning_iterations):
+        """The same loop over a PipelinedHectorEnv: every shard advances on its own stream, so the GPU overlaps
+        one shard's env-step kernel with the other shards' policy GEMMs.  Nothing here synchronises per step."""
+        env, alg = self.env, self.alg
+        shards = env.shards
+        obs = [s.get_observations() for s in shards]
+        priv = [s.get_privileged_observations() for s in shards]
+        tot_iter = self.current_learning_iteration + num_learning_iterations
+        for it in range(self.current_learning_iteration, tot_iter):
+            start = time.time()
+            alg.rollout(shards, self.num_steps_per_env)
+            obs = [s.get_observations() for s in shards]
+            priv = [s.get_privileged_observations() for s in shards]
+            env.sync()
+            stop = time.time()
+            collection_time = stop - start
+            start = stop
+            alg.compute_returns_shards([(priv[h], sh.env_lo, sh.num_envs, sh.stream) for h, sh in enumerate(shards)])
+            mean_value_loss, mean_surrogate_loss = alg.update()
+            stop = time.time()
+            learn_time = stop - start
+            self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
+                                  fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
+            if self.log_dir is not None:
+                ep_info, n_ep = env.episode_stats()
+                self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,
+                              mean_value_loss=mean_value_loss, mean_surrogate_loss=mean_surrogate_loss,
+                              ep_info=ep_info, n_ep=n_ep, rewbuffer=None, lenbuffer=None))
                 if it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
         self.current_learning_iteration += num_learning_iterations

@@ -213,6 +213,44 @@ class PPO:
         self._keep = [k1, k2, k3]
         return DeviceArray(out.value, (self.N, self.A), np.float32, None, self.stream)
 
+    # ---- shard forms (PipelinedHectorEnv): rows [env0, env0+count) of the current rollout slot, on the shard's stream
+    def act_range(self, obs, critic_obs, env0, count, stream):
+        po, _ = device_pointer(obs)
+        pp, _ = device_pointer(critic_obs)
+        out = capi.C.c_void_p()
+        capi.check(self._L.hx_ppo_act_range(self._h, po, pp, None, env0, count, stream, capi.C.byref(out)), "hx_ppo_act_range")
+        return DeviceArray(out.value, (count, self.A), np.float32, None, stream)
+
+    def process_env_step_range(self, rewards, dones, infos, env0, count, stream, advance):
+        pr, _ = device_pointer(rewards)
+        pd, _ = device_pointer(dones)
+        pt = device_pointer(infos["time_outs"])[0] if "time_outs" in infos else None
+        capi.check(self._L.hx_ppo_process_step_range(self._h, pr, pd, pt, env0, count, stream, int(advance)), "hx_ppo_process_step_range")
+
+    def rollout(self, envs, steps):
+        """`steps` x {act, env.step, process_env_step} in one C call (hx_rollout).  envs: list of HectorFreeEnv shards
+        (one element = the plain unsharded env).  Returns nothing: results live in the rollout storage."""
+        n = len(envs)
+        sims = (capi.C.c_void_p * n)(*[e._h for e in envs])
+        env0 = (capi.C.c_int32 * n)(*[e.env_lo for e in envs])
+        cnt = (capi.C.c_int32 * n)(*[e.num_envs for e in envs])
+        capi.check(self._L.hx_rollout(self._h, sims, env0, cnt, n, int(steps)), "hx_rollout")
+        for e in envs:
+            e.common_step_counter += steps
+            e._refresh_views()
+
+    def compute_returns_shards(self, shard_priv):
+        """shard_priv: list of (critic_obs, env0, count, stream)."""
+        for priv, env0, count, stream in shard_priv:
+            capi.check(self._L.hx_ppo_last_values_range(self._h, device_pointer(priv)[0], env0, count, stream), "last_values_range")
+            capi.check(self._L.hx_sync(stream), "sync")
+        capi.check(self._L.hx_ppo_compute_returns(self._h, None), "hx_ppo_compute_returns")
+        if self._distributed():
+            m = capi.C.c_void_p()
+            capi.check(self._L.hx_ppo_adv_moments(self._h, capi.C.byref(m)), "adv_moments")
+            self.comm.all_reduce_moments(m.value, self.stream)
+        capi.check(self._L.hx_ppo_adv_normalize(self._h), "hx_ppo_adv_normalize")
+
     def process_env_step(self, rewards, dones, infos):
         pr, k1 = device_pointer(rewards)
         pd, k2 = device_pointer(dones if not isinstance(dones, np.ndarray) else dones.astype(np.uint8))

@@ -8,6 +8,13 @@ SRC = [os.path.join(HERE, "csrc", f) for f in ("hx_sim.hip", "hx_ppo.hip")]
 HDR = [os.path.join(HERE, "csrc", f) for f in ("hx_dyn.h", "hx_gemm.h", "hx_common.h", "hx_model_data.h")] + \
       [os.path.join(os.path.dirname(HERE), "include", f) for f in ("hx_sim.h", "hx_ppo.h")]
 OUT = os.path.join(HERE, "libhx.so")
+# per-file flags chosen by measurement (profiles/): see DESIGN.md "Env-step kernel"
+EXTRA_FLAGS = {
+    # env-step kernel: SLP-packing fp32 into v_pk_* costs more register moves and spills than it saves in this
+    # latency-bound, register-heavy kernel (288 -> 194 us per step), and relaxed fp32 (rcp/rsq instead of IEEE
+    # division sequences, contraction) brings it to 162 us; parity tests run with exactly these flags.
+    "hx_sim.hip": ["-fno-slp-vectorize", "-ffast-math"],
+}
 
 
 def needs_build():
@@ -24,8 +31,10 @@ def build(force=False, verbose=False):
     objs = []
     for src in SRC:
         obj = src[:-4] + ".o"
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-array-bounds",
-               "-c", src, "-o", obj]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-array-bounds"]
+        cmd += EXTRA_FLAGS.get(os.path.basename(src), [])
+        cmd += os.environ.get("HX_EXTRA_FLAGS_" + os.path.basename(src).split(".")[0].upper(), "").split()
+        cmd += ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

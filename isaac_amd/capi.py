@@ -47,6 +47,7 @@ class SimCfg(C.Structure):
         ("cycle_time", C.c_float), ("tracking_sigma", C.c_float), ("max_contact_force", C.c_float),
         ("contact_kn", C.c_float), ("contact_dn", C.c_float), ("friction_veps", C.c_float),
         ("limit_k", C.c_float), ("limit_d", C.c_float), ("terrain_mu", C.c_float),
+        ("env_id_offset", C.c_int32),
     ]
 
 
@@ -114,6 +115,9 @@ def lib():
     L.hx_ppo_act.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
     L.hx_ppo_process_step.argtypes = [vp, vp, vp, vp]
     L.hx_ppo_compute_returns.argtypes = [vp, vp]
+    L.hx_ppo_act_range.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.hx_ppo_process_step_range.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int]
+    L.hx_ppo_last_values_range.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.hx_ppo_adv_moments.argtypes = [vp, C.POINTER(vp)]
     L.hx_ppo_adv_normalize.argtypes = [vp]
     L.hx_ppo_update_begin.argtypes = [vp, vp]
@@ -121,6 +125,7 @@ def lib():
     L.hx_ppo_minibatch_step.argtypes = [vp, C.c_float]
     L.hx_ppo_update_end.argtypes = [vp, vp]
     L.hx_ppo_update.argtypes = [vp, vp, vp]
+    L.hx_rollout.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int]
     L.hx_ppo_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hx_ppo_get_lr.argtypes = [vp, vp]
     L.hx_ppo_set_lr.argtypes = [vp, C.c_float]

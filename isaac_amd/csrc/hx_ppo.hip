@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include "../../include/hx_ppo.h"
+#include "../../include/hx_sim.h"
 #include "hx_common.h"
 #include "hx_gemm.h"
 
@@ -104,15 +105,67 @@ __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restric
   logp[e] = lp;
 }
 
+// actor half of the rollout head: mu, sample, log-prob (16 lanes per row).  Values come from the deferred critic.
+__global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restrict__ h3a, int hw, const float* __restrict__ W4,
+                                                            const float* __restrict__ b4, const float* __restrict__ stdp,
+                                                            const float* __restrict__ eps, int n, int A, uint32_t k0, uint32_t k1,
+                                                            uint32_t step, float* actions, float* mu_out, float* logp) {
+  extern __shared__ float sm[];
+  float* sW = sm;
+  for (int i = threadIdx.x; i < A * hw; i += blockDim.x) sW[i] = W4[i];
+  __syncthreads();
+  const int part = threadIdx.x & 15;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int ec = e < n ? e : n - 1;
+  const int per = hw / 16;
+  float mu[MAX_A];
+  for (int j = 0; j < A; ++j) mu[j] = 0.f;
+  const float* ha = h3a + (size_t)ec * hw + part * per;
+  for (int k = 0; k < per; k += 4) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(ha + k);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = part * per + k + q;
+      for (int j = 0; j < A; ++j) mu[j] = fmaf(x[q], sW[j * hw + kk], mu[j]);
+    }
+  }
+  for (int o = 8; o > 0; o >>= 1)
+    for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
+  if (part != 0 || e >= n) return;
+  float lp = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float m = mu[j] + b4[j];
+    const float sg = m * 0.f + stdp[j];
+    float z;
+    if (eps) z = eps[(size_t)e * A + j];
+    else {
+      uint32_t o[4];
+      philox4p(k0, k1, (uint32_t)e, step, (uint32_t)j, 7u, o);
+      const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+      const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+      z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    const float a = m + sg * z;
+    actions[(size_t)e * A + j] = a;
+    mu_out[(size_t)e * A + j] = m;
+    const float d = a - m;
+    lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - LOG_SQRT_2PI;
+  }
+  logp[e] = lp;
+}
+
 // critic head only (bootstrap value of compute_returns, ppo.py:116)
 __global__ void __launch_bounds__(256) hx_value_head_kernel(const float* __restrict__ h3c, int hw, const float* __restrict__ W4c,
                                                             const float* __restrict__ b4c, int n, float* values) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
+  const int part = threadIdx.x & 15;
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int ec = e < n ? e : n - 1;
+  const int per = hw / 16;
   float v = 0.f;
-  const float* hc = h3c + (size_t)e * hw;
-  for (int k = 0; k < hw; ++k) v = fmaf(hc[k], W4c[k], v);
-  values[e] = v + b4c[0];
+  const float* hc = h3c + (size_t)ec * hw + part * per;
+  for (int k = 0; k < per; ++k) v = fmaf(hc[k], W4c[part * per + k], v);
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (part == 0 && e < n) values[e] = v + b4c[0];
 }
 
 // actor head only (act_inference, actor_critic.py:122-124)
@@ -126,20 +179,22 @@ __global__ void __launch_bounds__(256) hx_mean_head_kernel(const float* __restri
   out[i] = m + b4[j];
 }
 
-// process_env_step (ppo.py:103-113): time-out bootstrap, store reward / done
+// process_env_step (ppo.py:103-113): store reward / done / time-out flag.  The bootstrap  r += gamma * V * time_out
+// (ppo.py:107-108) is applied by the GAE kernel, because the critic that produces V runs deferred, in large batches
+// beside the env-step kernels (see act_impl).
 __global__ void hx_process_step_kernel(const float* __restrict__ rew, const unsigned char* __restrict__ dones,
-                                       const unsigned char* __restrict__ timeouts, const float* __restrict__ values, float gamma,
-                                       int n, float* rew_out, unsigned char* done_out) {
+                                       const unsigned char* __restrict__ timeouts, int n, float* rew_out,
+                                       unsigned char* done_out, unsigned char* timeout_out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
-  float r = rew[e];
-  if (timeouts) r += gamma * (values[e] * (timeouts[e] ? 1.f : 0.f));
-  rew_out[e] = r;
+  rew_out[e] = rew[e];
   done_out[e] = dones[e] ? 1 : 0;
+  timeout_out[e] = (timeouts && timeouts[e]) ? 1 : 0;
 }
 
 // GAE (rollout_storage.py:122-132) + first pass of the advantage moments
-__global__ void __launch_bounds__(256) hx_gae_kernel(const float* __restrict__ rewards, const unsigned char* __restrict__ dones,
+__global__ void __launch_bounds__(256) hx_gae_kernel(float* __restrict__ rewards, const unsigned char* __restrict__ dones,
+                                                     const unsigned char* __restrict__ timeouts,
                                                      const float* __restrict__ values, const float* __restrict__ last_values,
                                                      int T, int n, float gamma, float lam, float* returns, float* adv_raw,
                                                      double* moments) {
@@ -151,7 +206,9 @@ __global__ void __launch_bounds__(256) hx_gae_kernel(const float* __restrict__ r
       const float nv = (t == T - 1) ? last_values[e] : values[(size_t)(t + 1) * n + e];
       const float nt = 1.0f - (float)dones[(size_t)t * n + e];
       const float v = values[(size_t)t * n + e];
-      const float delta = rewards[(size_t)t * n + e] + nt * gamma * nv - v;
+      const float r = rewards[(size_t)t * n + e] + gamma * (v * (float)timeouts[(size_t)t * n + e]);   // ppo.py:107-108
+      rewards[(size_t)t * n + e] = r;
+      const float delta = r + nt * gamma * nv - v;
       adv = delta + nt * gamma * lam * adv;
       const float ret = adv + v;
       returns[(size_t)t * n + e] = ret;
@@ -467,7 +524,9 @@ struct hx_ppo {
   float *params, *grads, *m, *v; bool ext_grads;
   // storage
   float *s_obs, *s_priv, *s_actions, *s_mu, *s_values, *s_logp, *s_rewards, *s_returns, *s_adv_raw, *s_adv, *sigma_old;
-  unsigned char* s_dones;
+  unsigned char* s_dones; unsigned char* s_timeouts;
+  int crit_done;                 // rollout slots [0, crit_done) already have their critic values
+  hipEvent_t ev_priv, ev_crit;   // priv rows of a slot copied (main stream) / deferred critic finished (stream2)
   float* last_values; double* moments;
   int step;
   // workspace
@@ -620,9 +679,19 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   s->cfg = *cfg;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
-  HX_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+  {
+    // the deferred critic is background work: lowest priority, so the rollout's critical path (actor GEMMs, env-step
+    // kernel) is dispatched first whenever both have workgroups waiting
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HX_CHECK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least));
+  }
   HX_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HX_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  HX_CHECK(hipEventCreateWithFlags(&s->ev_priv, hipEventDisableTiming));
+  HX_CHECK(hipEventCreateWithFlags(&s->ev_crit, hipEventDisableTiming));
+  HX_CHECK(hipEventRecord(s->ev_crit, s->stream2));
+  s->crit_done = 0;
   const int A = cfg->num_actions, N = cfg->num_envs, T = cfg->num_steps;
   // ---- parameter layout
   int dims_a[5] = {cfg->num_obs, cfg->actor_hidden[0], cfg->actor_hidden[1], cfg->actor_hidden[2], A};
@@ -654,7 +723,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   rc |= palloc(s, &s->s_actions, TN * A); rc |= palloc(s, &s->s_mu, TN * A);
   rc |= palloc(s, &s->s_values, TN); rc |= palloc(s, &s->s_logp, TN); rc |= palloc(s, &s->s_rewards, TN);
   rc |= palloc(s, &s->s_returns, TN); rc |= palloc(s, &s->s_adv_raw, TN); rc |= palloc(s, &s->s_adv, TN);
-  rc |= palloc(s, &s->s_dones, TN); rc |= palloc(s, &s->sigma_old, MAX_A);
+  rc |= palloc(s, &s->s_dones, TN); rc |= palloc(s, &s->s_timeouts, TN); rc |= palloc(s, &s->sigma_old, MAX_A);
   rc |= palloc(s, &s->last_values, (size_t)N); rc |= palloc(s, &s->moments, 3);
   // ---- workspace
   const int mbs = (int)(TN / cfg->num_mini_batches);
@@ -706,7 +775,7 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
   for (void* a : s->allocs) (void)hipFree(a);
   for (auto e : s->ev) (void)hipEventDestroy(e);
   (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);
-  (void)hipEventDestroy(s->ev_fork); (void)hipEventDestroy(s->ev_join);
+  (void)hipEventDestroy(s->ev_fork); (void)hipEventDestroy(s->ev_join); (void)hipEventDestroy(s->ev_priv); (void)hipEventDestroy(s->ev_crit);
   if (s->own_stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -770,49 +839,123 @@ static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, f
   gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld);
 }
 
-extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const float* eps, float** actions_out) {
+#ifndef HX_CRITIC_CHUNK
+#define HX_CRITIC_CHUNK 5
+#endif
+// values for rollout slots [crit_done, upto) on the second stream: one critic forward over (slots * N) rows
+static int critic_flush(hx_ppo* s, int upto) {
+  const int N = s->cfg.num_envs;
+  while (s->crit_done < upto) {
+    int slots = upto - s->crit_done;
+    const int max_slots = s->Mmax / N > 0 ? s->Mmax / N : 1;
+    if (slots > max_slots) slots = max_slots;
+    const int rows = slots * N;
+    HX_CHECK(hipStreamWaitEvent(s->stream2, s->ev_priv, 0));   // the newest slot's rows have been copied
+    const float* sp = s->s_priv + (size_t)s->crit_done * N * s->cfg.priv_ld;
+    mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, rows, s->act_c, s->stream2);
+    hipLaunchKernelGGL(hx_value_head_kernel, dim3((rows + 15) / 16), dim3(256), 0, s->stream2, s->act_c[2], s->cfg.critic_hidden[2],
+                       s->params + s->L[7].w, s->params + s->L[7].b, rows, s->s_values + (size_t)s->crit_done * N);
+    HX_CHECK(hipGetLastError());
+    s->crit_done += slots;
+  }
+  HX_CHECK(hipEventRecord(s->ev_crit, s->stream2));
+  return 0;
+}
+
+// PPO.act for the env rows [env0, env0+count) of rollout slot t.  `st` = stream of the caller's env shard;
+// with `dual` the critic chain is forked onto the learner's second stream (whole-batch call), otherwise both
+// chains run back to back on `st` and the overlap comes from the other shard's stream.
+static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float* eps, int env0, int count, hipStream_t st,
+                    bool dual, float** actions_out) {
   const int N = s->cfg.num_envs, A = s->cfg.num_actions, t = s->step;
   if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }   // rollout_storage.py:88-89
-  float* so = s->s_obs + (size_t)t * N * s->cfg.obs_ld;
-  float* sp = s->s_priv + (size_t)t * N * s->cfg.priv_ld;
-  HX_CHECK(hipMemcpyAsync(so, obs, (size_t)N * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-  HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)N * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-  // fork: at M = num_envs one chain's GEMMs cannot fill 256 CUs, so the critic chain runs on a second stream
-  HX_CHECK(hipEventRecord(s->ev_fork, s->stream));
-  HX_CHECK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
-  mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, N, s->act_a, s->stream);
-  mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, N, s->act_c, s->stream2);
-  HX_CHECK(hipEventRecord(s->ev_join, s->stream2));
-  HX_CHECK(hipStreamWaitEvent(s->stream, s->ev_join, 0));
+  if (env0 < 0 || count <= 0 || env0 + count > N) { hx_set_error("hx_ppo_act: env range out of bounds"); return -2; }
+  float* so = s->s_obs + ((size_t)t * N + env0) * s->cfg.obs_ld;
+  float* sp = s->s_priv + ((size_t)t * N + env0) * s->cfg.priv_ld;
+  HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)count * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+  float* aa[3]; float* ac[3];
+  for (int l = 0; l < 3; ++l) { aa[l] = s->act_a[l] + (size_t)env0 * s->cfg.actor_hidden[l]; ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l]; }
   const int hw = s->cfg.actor_hidden[2];
-  if (t == 0) HX_CHECK(hipMemcpyAsync(s->sigma_old, s->params + s->std_off, A * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-  float* acts = s->s_actions + (size_t)t * N * A;
-  hipLaunchKernelGGL(hx_act_head_kernel, dim3((N + 15) / 16), dim3(256), (A + 1) * hw * sizeof(float), s->stream,
-                     s->act_a[2], s->act_c[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
-                     s->params + s->std_off, eps, N, A, s->seed_lo, s->seed_hi, s->act_counter++, acts, s->s_mu + (size_t)t * N * A,
-                     s->s_values + (size_t)t * N, s->s_logp + (size_t)t * N);
+  if (t == 0 && env0 == 0) HX_CHECK(hipMemcpyAsync(s->sigma_old, s->params + s->std_off, A * sizeof(float), hipMemcpyDeviceToDevice, st));
+  float* acts = s->s_actions + ((size_t)t * N + env0) * A;
+  if (dual) {
+    // Whole-batch rollout: only the ACTOR is on the critical path (action -> env step -> next observation).
+    // The critic's values are first needed by GAE, so the critic runs DEFERRED: every HX_CRITIC_CHUNK slots one
+    // large batch (chunk * N rows -> full-size tiles) on the second stream, where it fills the CUs that the
+    // latency-bound env-step kernels (128 waves) leave idle.
+    HX_CHECK(hipEventRecord(s->ev_priv, st));                 // slot t's privileged rows are in the storage
+    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
+    hipLaunchKernelGGL(hx_actor_head_kernel, dim3((count + 15) / 16), dim3(256), A * hw * sizeof(float), st, aa[2], hw,
+                       s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
+                       s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
+    if (t + 1 - s->crit_done >= HX_CRITIC_CHUNK) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
+  } else {
+    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
+    mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);
+    hipLaunchKernelGGL(hx_act_head_kernel, dim3((count + 15) / 16), dim3(256), (A + 1) * hw * sizeof(float), st,
+                       aa[2], ac[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
+                       s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi + (uint32_t)env0, s->act_counter, acts,
+                       s->s_mu + ((size_t)t * N + env0) * A, s->s_values + (size_t)t * N + env0, s->s_logp + (size_t)t * N + env0);
+    if (env0 + count == N) s->crit_done = t + 1;             // shard path computes values inline
+  }
   HX_CHECK(hipGetLastError());
   if (actions_out) *actions_out = acts;
   return 0;
 }
 
-extern "C" int hx_ppo_process_step(hx_ppo* s, const float* rew, const uint8_t* dones, const uint8_t* timeouts) {
+extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const float* eps, float** actions_out) {
+  const int rc = act_impl(s, obs, priv, eps, 0, s->cfg.num_envs, s->stream, true, actions_out);
+  s->act_counter++;
+  return rc;
+}
+extern "C" int hx_ppo_act_range(hx_ppo* s, const float* obs, const float* priv, const float* eps, int env0, int count, void* stream,
+                                float** actions_out) {
+  return act_impl(s, obs, priv, eps, env0, count, (hipStream_t)stream, false, actions_out);
+}
+
+static int process_impl(hx_ppo* s, const float* rew, const uint8_t* dones, const uint8_t* timeouts, int env0, int count, hipStream_t st) {
   const int N = s->cfg.num_envs, t = s->step;
   if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }
-  hipLaunchKernelGGL(hx_process_step_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, rew, dones, timeouts,
-                     s->s_values + (size_t)t * N, s->cfg.gamma, N, s->s_rewards + (size_t)t * N, s->s_dones + (size_t)t * N);
+  hipLaunchKernelGGL(hx_process_step_kernel, dim3((count + 255) / 256), dim3(256), 0, st, rew, dones, timeouts, count,
+                     s->s_rewards + (size_t)t * N + env0, s->s_dones + (size_t)t * N + env0, s->s_timeouts + (size_t)t * N + env0);
   HX_CHECK(hipGetLastError());
-  s->step += 1;
+  return 0;
+}
+extern "C" int hx_ppo_process_step(hx_ppo* s, const float* rew, const uint8_t* dones, const uint8_t* timeouts) {
+  const int rc = process_impl(s, rew, dones, timeouts, 0, s->cfg.num_envs, s->stream);
+  if (rc == 0) s->step += 1;
+  return rc;
+}
+// shard form: `advance` != 0 on the last shard of a step moves the rollout slot forward
+extern "C" int hx_ppo_process_step_range(hx_ppo* s, const float* rew, const uint8_t* dones, const uint8_t* timeouts, int env0, int count,
+                                         void* stream, int advance) {
+  const int rc = process_impl(s, rew, dones, timeouts, env0, count, (hipStream_t)stream);
+  if (rc == 0 && advance) { s->step += 1; s->act_counter++; }
+  return rc;
+}
+
+// bootstrap values V(s_T) for env rows [env0, env0+count)  (first half of PPO.compute_returns, ppo.py:116)
+extern "C" int hx_ppo_last_values_range(hx_ppo* s, const float* last_priv, int env0, int count, void* stream) {
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  float* ac[3];
+  for (int l = 0; l < 3; ++l) ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l];
+  mlp_hidden_fwd(s, 1, last_priv, s->cfg.priv_ld, count, ac, st);
+  hipLaunchKernelGGL(hx_value_head_kernel, dim3((count + 15) / 16), dim3(256), 0, st, ac[2], s->cfg.critic_hidden[2],
+                     s->params + s->L[7].w, s->params + s->L[7].b, count, s->last_values + env0);
+  HX_CHECK(hipGetLastError());
   return 0;
 }
 
+// last_priv == NULL: the bootstrap values were already produced by hx_ppo_last_values_range
 extern "C" int hx_ppo_compute_returns(hx_ppo* s, const float* last_priv) {
   const int N = s->cfg.num_envs, T = s->cfg.num_steps;
-  mlp_hidden_fwd(s, 1, last_priv, s->cfg.priv_ld, N, s->act_c);
-  hipLaunchKernelGGL(hx_value_head_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, s->act_c[2], s->cfg.critic_hidden[2],
-                     s->params + s->L[7].w, s->params + s->L[7].b, N, s->last_values);
+  // finish the deferred critic for every stored slot, then make the main stream wait for it
+  if (s->crit_done < s->step) { HX_CHECK(hipEventRecord(s->ev_priv, s->stream)); const int rc = critic_flush(s, s->step); if (rc) return rc; }
+  HX_CHECK(hipStreamWaitEvent(s->stream, s->ev_crit, 0));
+  if (last_priv) { const int rc = hx_ppo_last_values_range(s, last_priv, 0, N, s->stream); if (rc) return rc; }
   HX_CHECK(hipMemsetAsync(s->moments, 0, 3 * sizeof(double), s->stream));
-  hipLaunchKernelGGL(hx_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, s->s_rewards, s->s_dones, s->s_values, s->last_values,
+  hipLaunchKernelGGL(hx_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, s->s_rewards, s->s_dones, s->s_timeouts, s->s_values, s->last_values,
                      T, N, s->cfg.gamma, s->cfg.lam, s->s_returns, s->s_adv_raw, s->moments);
   HX_CHECK(hipGetLastError());
   return 0;
@@ -917,6 +1060,7 @@ extern "C" int hx_ppo_update_end(hx_ppo* s, float* stats_h) {
   const float n = (float)(s->mb_done > 0 ? s->mb_done : 1);
   if (stats_h) { stats_h[0] = st.vloss_sum / n; stats_h[1] = st.sloss_sum / n; stats_h[2] = st.lr; stats_h[3] = st.last_kl; }
   s->step = 0;       // storage.clear(), ppo.py:182
+  s->crit_done = 0;
   return 0;
 }
 
@@ -978,6 +1122,31 @@ extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
   for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); ms[s->ev_kid[i]] += t; }
   // out[15]: per kernel id {milliseconds, launches, flops}
   if (out) for (int k = 0; k < 5; ++k) { out[3 * k] = ms[k]; out[3 * k + 1] = (double)s->prof_launches[k]; out[3 * k + 2] = s->prof_flops[k]; }
+  return 0;
+}
+
+// The rollout loop of OnPolicyRunner.learn (on_policy_runner.py:127-138) for `steps` env steps, driven from C so
+// that launch issue (~40 launches per step with two shards) never waits for the Python interpreter.
+// One shard: whole-batch calls (critic chain forked on the learner's second stream).  Several shards: every
+// shard advances on its own stream; one shard's env-step kernel overlaps the other shards' GEMMs.
+extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps) {
+  for (int t = 0; t < steps; ++t) {
+    for (int h = 0; h < nshards; ++h) {
+      void *obs, *priv, *rew, *rst, *tov;
+      int rc = hx_sim_buffer(sims[h], HX_BUF_OBS, &obs); if (rc) return rc;
+      rc = hx_sim_buffer(sims[h], HX_BUF_PRIV, &priv); if (rc) return rc;
+      float* act = nullptr;
+      if (nshards == 1) rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act);
+      else rc = hx_ppo_act_range(p, (const float*)obs, (const float*)priv, nullptr, env0[h], count[h], hx_sim_stream(sims[h]), &act);
+      if (rc) return rc;
+      rc = hx_sim_step(sims[h], act, nullptr); if (rc) return rc;
+      hx_sim_buffer(sims[h], HX_BUF_REW, &rew); hx_sim_buffer(sims[h], HX_BUF_RESET, &rst); hx_sim_buffer(sims[h], HX_BUF_TIMEOUT_VISIBLE, &tov);
+      if (nshards == 1) rc = hx_ppo_process_step(p, (const float*)rew, (const uint8_t*)rst, (const uint8_t*)tov);
+      else rc = hx_ppo_process_step_range(p, (const float*)rew, (const uint8_t*)rst, (const uint8_t*)tov, env0[h], count[h],
+                                          hx_sim_stream(sims[h]), h == nshards - 1);
+      if (rc) return rc;
+    }
+  }
   return 0;
 }
 

@@ -60,17 +60,18 @@ __device__ __attribute__((noinline)) void philox4(uint32_t k0, uint32_t k1, uint
 struct Rng {
   const float* pack;   // injected [HX_RP_SIZE][N] or nullptr
   int n, env;
+  uint32_t gid;        // global env id: keys the counter-based generator
   uint32_t k0, k1, step;
   __device__ __forceinline__ float uni(int field) const {
     if (pack) return pack[(size_t)field * n + env];
     uint32_t o[4];
-    philox4(k0, k1, (uint32_t)env, step, (uint32_t)field, 0u, o);
+    philox4(k0, k1, gid, step, (uint32_t)field, 0u, o);
     return (float)(o[0] >> 8) * (1.0f / 16777216.0f);
   }
   __device__ __forceinline__ float nrm(int field) const {
     if (pack) return pack[(size_t)field * n + env];
     uint32_t o[4];
-    philox4(k0, k1, (uint32_t)env, step, (uint32_t)field, 1u, o);
+    philox4(k0, k1, gid, step, (uint32_t)field, 1u, o);
     const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);   // (0,1]
     const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -129,7 +130,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   if (e >= n) return;                      // both lanes of a pair leave together
   const bool writer = (leg == 0);          // env-level results are computed by both lanes, stored by one
   LegConst C; C.t = lds_const + leg * HX_LEGC_STRIDE; C.basept = lds_const + 2 * HX_LEGC_STRIDE;
-  Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
+  Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
 
   // ---- load state: base (both lanes) + this lane's leg
   DynState S;
@@ -621,7 +622,12 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
   s->rng_step = 0;
   s->cur = 0;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
-  else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
+  else {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HX_CHECK(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, greatest));   // the rollout's critical path
+    s->own_stream = true;
+  }
   const size_t n = cfg->num_envs;
   int rc = 0;
   rc |= dalloc(s, &s->p.st, (size_t)S_STATE_SIZE * n);

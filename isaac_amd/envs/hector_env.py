@@ -75,7 +75,9 @@ def creation_randomisation(cfg, num_envs, env_origins):
 
 class HectorFreeEnv(VecEnv):
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, stream=None,
-                 creation=None, init_pack=None):
+                 creation=None, init_pack=None, env_range=None):
+        """env_range=(lo, hi): this object simulates envs lo..hi-1 of the logical batch of cfg.env.num_envs robots
+        (used by PipelinedHectorEnv); creation-time draws are made for the whole batch and sliced."""
         self.cfg = cfg
         self.sim_params = sim_params
         self.headless = headless
@@ -98,7 +100,9 @@ class HectorFreeEnv(VecEnv):
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = math.ceil(self.max_episode_length_s / self.dt)
         cfg.domain_rand.push_interval = math.ceil(cfg.domain_rand.push_interval_s / self.dt)
-        self.num_envs = cfg.env.num_envs
+        self.total_envs = cfg.env.num_envs
+        self.env_lo, self.env_hi = env_range if env_range is not None else (0, cfg.env.num_envs)
+        self.num_envs = self.env_hi - self.env_lo
         self.num_obs = cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
@@ -117,19 +121,18 @@ class HectorFreeEnv(VecEnv):
         assert sorted(self.termination_contact_indices) == [0, 3, 8] == sorted(self.penalised_contact_indices)
 
         # ---- env origins: grid (legged_robot.py:698-708)
-        n = self.num_envs
-        num_cols = int(np.floor(np.sqrt(n)))
-        num_rows = int(np.ceil(n / num_cols))
-        xx, yy = np.meshgrid(np.arange(num_rows), np.arange(num_cols), indexing="ij")
-        self.env_origins = np.zeros((n, 3), np.float32)
-        self.env_origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:n]
-        self.env_origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:n]
+        n = self.total_envs
+        self.env_origins = self._grid_origins(cfg, n)
         self.custom_origins = False
         if creation is not None:          # tests: replay a recorded creation (friction, base mass, origins, start pose)
             friction, mass, start = (np.asarray(creation[k], np.float32) for k in ("friction", "mass", "start"))
             self.env_origins = np.asarray(creation["origins"], np.float32)
         else:
             friction, mass, start = creation_randomisation(cfg, n, self.env_origins)
+        if env_range is not None:
+            sl = slice(self.env_lo, self.env_hi)
+            friction, mass, start, self.env_origins = friction[sl], mass[sl], start[sl], self.env_origins[sl]
+        n = self.num_envs
         self.env_frictions, self.body_mass, self.start_pos = friction, mass, start
 
         # ---- flat C config
@@ -199,6 +202,7 @@ class HectorFreeEnv(VecEnv):
         for k, v in PHYS.items():
             setattr(c, k, v)
         c.terrain_mu = cfg.terrain.static_friction
+        c.env_id_offset = self.env_lo
         self._ccfg = c
 
         seed = int(getattr(cfg, "seed", 0)) & 0xFFFFFFFF
@@ -214,6 +218,16 @@ class HectorFreeEnv(VecEnv):
         self._keep = []
         # constructor tail: reset_idx(all) + compute_observations (hector_env.py:50-51)
         self._reset_all(init_pack)
+
+    @staticmethod
+    def _grid_origins(cfg, n):
+        num_cols = int(np.floor(np.sqrt(n)))
+        num_rows = int(np.ceil(n / num_cols))
+        xx, yy = np.meshgrid(np.arange(num_rows), np.arange(num_cols), indexing="ij")
+        origins = np.zeros((n, 3), np.float32)
+        origins[:, 0] = cfg.env.env_spacing * xx.flatten()[:n]
+        origins[:, 1] = cfg.env.env_spacing * yy.flatten()[:n]
+        return origins
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, which, shape, dtype=np.float32, strides=None):
@@ -335,3 +349,77 @@ class HectorFreeEnv(VecEnv):
             self.close()
         except Exception:
             pass
+
+
+class PipelinedHectorEnv(VecEnv):
+    """The same batch of robots as HectorFreeEnv(cfg), run as `num_shards` independent simulators on their own HIP
+    streams.  The env-step kernel is latency-bound (one lane pair per robot: 128 waves on 1024 SIMDs) while the
+    policy GEMMs are throughput-bound, so when the runner drives the shards round-robin
+    (OnPolicyRunner.learn) one shard's physics overlaps the other shards' GEMMs on the same GPU.
+    Robots, random streams (Philox keyed by global env id) and results are those of the unsharded env.
+    One documented difference: the reference's stale-`extras["time_outs"]` quirk is
+    evaluated per shard ("some env of this shard reset this step") instead of over the whole batch."""
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, num_shards=2):
+        n = cfg.env.num_envs
+        assert n % num_shards == 0
+        per = n // num_shards
+        # draw the creation-time randomisation ONCE for the whole batch, in the reference's order
+        probe_origins = HectorFreeEnv._grid_origins(cfg, n)
+        friction, mass, start = creation_randomisation(cfg, n, probe_origins)
+        creation = dict(friction=friction, mass=mass, start=start, origins=probe_origins)
+        self.shards = [HectorFreeEnv(cfg, sim_params, physics_engine, sim_device, headless, creation=creation,
+                                     env_range=(i * per, (i + 1) * per)) for i in range(num_shards)]
+        s0 = self.shards[0]
+        self.cfg, self.num_envs, self.num_obs, self.num_privileged_obs, self.num_actions = cfg, n, s0.num_obs, s0.num_privileged_obs, s0.num_actions
+        self.max_episode_length, self.dt, self.device = s0.max_episode_length, s0.dt, s0.device
+        self.reward_names = s0.reward_names
+        self.stream = s0.stream
+        self.extras = {}
+
+    @property
+    def episode_length_buf(self):
+        return np.concatenate([s.episode_length_buf.numpy() for s in self.shards])
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        arr = value.cpu().numpy() if hasattr(value, "cpu") else np.asarray(value)
+        for s in self.shards:
+            s.episode_length_buf = arr[s.env_lo:s.env_hi]
+
+    def step(self, actions):
+        """Whole-batch step (no overlap); the runner uses the shards directly instead."""
+        from ..devarray import DeviceArray
+        p, keep = device_pointer(actions)
+        outs = []
+        for s in self.shards:
+            a = DeviceArray(p + s.env_lo * self.num_actions * 4, (s.num_envs, self.num_actions), owner=keep)
+            outs.append(s.step(a))
+        self.sync()
+        return outs
+
+    def reset(self):
+        return [s.reset() for s in self.shards]
+
+    def get_observations(self):
+        return [s.get_observations() for s in self.shards]
+
+    def get_privileged_observations(self):
+        return [s.get_privileged_observations() for s in self.shards]
+
+    def episode_stats(self):
+        infos, cnts = zip(*[s.episode_stats() for s in self.shards])
+        tot = sum(cnts)
+        w = [c / tot if tot else 0.0 for c in cnts]
+        info = {k: sum(wi * i[k] for wi, i in zip(w, infos)) for k in infos[0]}
+        self.last_episode_return = sum(wi * s.last_episode_return for wi, s in zip(w, self.shards))
+        self.last_episode_length = sum(wi * s.last_episode_length for wi, s in zip(w, self.shards))
+        return info, tot
+
+    def sync(self):
+        for s in self.shards:
+            s.sync()
+
+    def close(self):
+        for s in self.shards:
+            s.close()

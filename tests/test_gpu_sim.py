@@ -106,3 +106,34 @@ def test_full_stacks_and_history_zeroing(hxlib):
             np.testing.assert_allclose(obs.numpy(), fx["full_obs"][i], rtol=0, atol=2e-3)
             np.testing.assert_allclose(priv.numpy(), fx["full_priv"][i], rtol=0, atol=5e-3)
     env.close()
+
+
+def test_pipelined_shards_equal_single_env(hxlib):
+    """PipelinedHectorEnv (2 shards, own streams) simulates exactly the robots of the unsharded env: same creation
+    draws, same Philox streams (keyed by global env id) -> bit-identical observations, rewards and resets."""
+    from isaac_amd.envs.hector_env import PipelinedHectorEnv
+    from isaac_amd.utils.helpers import set_seed
+    n = 64
+    rng = np.random.default_rng(0)
+    acts = (0.5 * rng.standard_normal((6, n, 10))).astype(np.float32)
+    outs = []
+    for sharded in (False, True):
+        cfg = HectorCfg()
+        cfg.env.num_envs = n
+        cfg.seed = set_seed(11)
+        env = PipelinedHectorEnv(cfg, num_shards=2) if sharded else HectorFreeEnv(cfg)
+        rec = []
+        for t in range(6):
+            if sharded:
+                res = env.step(acts[t])
+                rec.append((np.concatenate([r[0].numpy() for r in res]), np.concatenate([r[2].numpy() for r in res]),
+                            np.concatenate([r[3].numpy() for r in res])))
+            else:
+                o, p, r, d, _ = env.step(acts[t])
+                rec.append((o.numpy(), r.numpy(), d.numpy()))
+        outs.append(rec)
+        env.close()
+    for (o0, r0, d0), (o1, r1, d1) in zip(*outs):
+        np.testing.assert_array_equal(o0, o1)
+        np.testing.assert_array_equal(r0, r1)
+        np.testing.assert_array_equal(d0, d1)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Env-step-only timing: `steps` hx_sim_step calls on N robots, perf-mode RNG.  GPU box only."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from isaac_amd import capi
+from isaac_amd.envs.configs import HectorCfg
+from isaac_amd.envs.hector_env import HectorFreeEnv
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+cfg = HectorCfg(); cfg.env.num_envs = n; cfg.seed = 5
+env = HectorFreeEnv(cfg)
+act = capi.DeviceBuffer.from_host((0.3 * np.random.default_rng(0).standard_normal((n, 10))).astype(np.float32))
+L = capi.lib()
+for _ in range(20):
+    L.hx_sim_step(env._h, act.ptr, None)
+env.sync()
+t0 = time.perf_counter()
+for _ in range(steps):
+    L.hx_sim_step(env._h, act.ptr, None)
+env.sync()
+dt = (time.perf_counter() - t0) / steps
+print(f"N={n}: {dt*1e6:.1f} us per env step (incl. 2 stack kernels + memset), {n/dt/1e6:.2f} M env-steps/s sim-only")
