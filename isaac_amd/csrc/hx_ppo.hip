@@ -574,21 +574,19 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launc
   }
 }
 
-// Variant choice per shape is from measurement (tools/gemm_bench.py, profiles/r01_gemm_variants.txt): with few
-// output tiles (N <= 256) the tail of the launch dominates, and either two resident workgroups of a deeper
-// K tile (forward) or half-height tiles (dgrad, K <= 256) shorten it.
+// Variant choice is from measurement (tools/gemm_bench.py, profiles/r01_gemm_variants*.txt): after the branch-free
+// epilogue all variants are within ~5 %; BK = 32 is best for the forward layers and 64-row BK = 32 tiles for dgrad
+// (short K = 128..256, where a shorter launch tail matters most).
 static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
-  if (M >= 16384) {
-    if (N <= 256 && K >= 512) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
-    else launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
-  } else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
+  if (M >= 16384) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
+  else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
   GemmArgs g{};
   g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = N; g.M = M; g.N = N; g.K = K; g.H = H; g.ldh = N;
-  launch_gemm<64, 128, 16, true, false, EPI_ELU_GRAD>(s, g, st);
+  launch_gemm<64, 128, 32, true, false, EPI_ELU_GRAD>(s, g, st);
 }
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab / bias_slab
 static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab) {
