@@ -321,21 +321,29 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   for (int i = tid; i < A * hw; i += 256) sW[i] = g.W4[i];
   for (int i = tid; i < hw; i += 256) sWc[i] = g.W4c[i];
   __syncthreads();
-  if (tid < HEAD_ROWS) {
-    const int r = tid, m = r0 + r;
+  {
+    // 8 lanes per row: each lane owns hw/8 consecutive k of both dot products, 3 xor-shuffles reduce them,
+    // lane 0 of the row finishes the loss terms
+    const int r = tid >> 3, part = tid & 7, m = r0 + r;
+    const int per = hw / 8;
+    float mu[MAX_A];
+    for (int j = 0; j < A; ++j) mu[j] = 0.f;
+    float v = 0.f;
+    for (int k = part * per; k < (part + 1) * per; ++k) {
+      const float x = sHa[r * hp + k];
+      for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
+      v = fmaf(sHc[r * hp + k], sWc[k], v);
+    }
+    for (int o = 4; o > 0; o >>= 1) {
+      for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
+      v += __shfl_xor(v, o);
+    }
+    if (part == 0) {
     float* L = sL + r * (4 + A);
     float* D = sD + r * (A + 1);
     if (m < g.M) {
       const float invM = 1.0f / (float)g.M;
       const float* row = g.row_mb + (size_t)m * (2 * A + 4);
-      float mu[MAX_A];
-      for (int j = 0; j < A; ++j) mu[j] = 0.f;
-      float v = 0.f;
-      for (int k = 0; k < hw; ++k) {
-        const float x = sHa[r * hp + k];
-        for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
-        v = fmaf(sHc[r * hp + k], sWc[k], v);
-      }
       v += g.b4c[0];
       float logp = 0.f, ent = 0.f, kl = 0.f;
       float sg[MAX_A];
@@ -378,6 +386,7 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
     } else {
       for (int j = 0; j <= A; ++j) D[j] = 0.f;
       for (int j = 0; j < 4 + A; ++j) L[j] = 0.f;
+    }
     }
   }
   __syncthreads();
@@ -440,6 +449,28 @@ __global__ void hx_slab_chunk_kernel(const float* __restrict__ slab, int S, int 
   float s = 0.f;
   for (int k = lo; k < hi; ++k) s += slab[(size_t)k * slab_w + i];
   out[(size_t)c * slab_w + i] = s;
+}
+
+// All split-K partial slabs of one minibatch (6 weight + 6 bias segments) summed in ONE launch: segment table in
+// kernel arguments, each workgroup owns 256 consecutive elements of one segment.  Fixed summation order -> bitwise
+// reproducible gradients.
+#define HX_MAX_SEG 12
+struct ReduceTable {
+  const float* src[HX_MAX_SEG]; float* dst[HX_MAX_SEG];
+  unsigned count[HX_MAX_SEG]; int S[HX_MAX_SEG]; unsigned block0[HX_MAX_SEG + 1];
+  int nseg;
+};
+__global__ void __launch_bounds__(256) hx_reduce_all_kernel(ReduceTable t) {
+  int seg = 0;
+#pragma unroll
+  for (int k = 1; k < HX_MAX_SEG; ++k) if (k < t.nseg && blockIdx.x >= t.block0[k]) seg = k;
+  const unsigned i = (blockIdx.x - t.block0[seg]) * 256u + threadIdx.x;
+  if (i >= t.count[seg]) return;
+  const float* src = t.src[seg];
+  const size_t stride = t.count[seg];
+  float s = 0.f;
+  for (int k = 0; k < t.S[seg]; ++k) s += src[(size_t)k * stride + i];
+  t.dst[seg][i] = s;
 }
 
 // scatter the head slab sums into the flat gradient buffer + statistics
@@ -533,7 +564,9 @@ struct hx_ppo {
   int Mmax;
   float *obs_mb, *priv_mb, *row_mb;
   float *act_a[3], *act_c[3], *dz_a[3], *dz_c[3];
-  float *slab, *bias_slab, *head_slab, *head_slab2; size_t slab_floats; int head_blocks_max, head_slab_w;
+  float *slab, *bias_slab, *head_slab, *head_slab2; size_t slab_floats;
+  size_t slab_off[8], bslab_off[8];     // per-layer regions so that all six wgrads finish before one reduce launch
+  int head_blocks_max, head_slab_w;
   int* perm; int perm_external;
   double* sumsq; SchedState* sched;
   int64_t adam_t;
@@ -673,6 +706,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
   if (cfg->num_actions > MAX_A) { hx_set_error("hx_ppo_create: num_actions > 16"); return -2; }
   if (cfg->actor_hidden[2] != cfg->critic_hidden[2] || cfg->actor_hidden[2] % 64) { hx_set_error("hx_ppo_create: last hidden widths must match and be a multiple of 64"); return -2; }
+  static_assert(HEAD_ROWS * 8 == 256, "loss head: 8 lanes per row");
   hx_ppo* s = new hx_ppo();
   s->cfg = *cfg;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
@@ -733,18 +767,21 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
     rc |= palloc(s, &s->act_a[l], Mm * cfg->actor_hidden[l]); rc |= palloc(s, &s->dz_a[l], Mm * cfg->actor_hidden[l]);
     rc |= palloc(s, &s->act_c[l], Mm * cfg->critic_hidden[l]); rc |= palloc(s, &s->dz_c[l], Mm * cfg->critic_hidden[l]);
   }
-  size_t slab_max = 0;
+  size_t slab_tot = 0, bslab_tot = 0;
   for (int i = 0; i < 8; ++i) {
+    s->slab_off[i] = slab_tot; s->bslab_off[i] = bslab_tot;
     if (i % 4 == 3) continue;
     const Layer& Ly = s->L[i];
     const int tiles = ((Ly.out + 127) / 128) * ((Ly.in_ld + 127) / 128);
     int splits = (1024 + tiles - 1) / tiles + 1;
-    const size_t need = (size_t)splits * Ly.out * Ly.in_ld;
-    if (need > slab_max) slab_max = need;
+    int max_splits = s->Mmax / 256; if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits + 1) splits = max_splits + 1;
+    slab_tot += (size_t)splits * Ly.out * Ly.in_ld;
+    bslab_tot += (size_t)splits * Ly.out;
   }
-  s->slab_floats = slab_max;
-  rc |= palloc(s, &s->slab, slab_max);
-  rc |= palloc(s, &s->bias_slab, (size_t)1100 * 1024);
+  s->slab_floats = slab_tot;
+  rc |= palloc(s, &s->slab, slab_tot);
+  rc |= palloc(s, &s->bias_slab, bslab_tot);
   s->head_slab_w = A * cfg->actor_hidden[2] + A + cfg->actor_hidden[2] + 1 + A + 4;
   s->head_blocks_max = (s->Mmax + HEAD_ROWS - 1) / HEAD_ROWS;
   rc |= palloc(s, &s->head_slab, (size_t)s->head_blocks_max * s->head_slab_w);
@@ -1011,7 +1048,8 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   const int hchunk = 32, hchunks = (hblocks + hchunk - 1) / hchunk;
   hipLaunchKernelGGL(hx_slab_chunk_kernel, dim3((s->head_slab_w + 255) / 256, hchunks), dim3(256), 0, st, s->head_slab, hblocks, s->head_slab_w, hchunk, s->head_slab2);
   hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab2, hchunks, s->head_slab_w, s->grads, hs, (float)M);
-  // backward through the hidden layers of both networks
+  // backward through the hidden layers of both networks; partial slabs go to per-layer regions, one reduce at the end
+  ReduceTable rt{}; unsigned blocks = 0;
   for (int net = 0; net < 2; ++net) {
     const Layer* L = s->L + net * 4;
     float** act = net ? s->act_c : s->act_a;
@@ -1021,13 +1059,20 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
     for (int l = 2; l >= 0; --l) {
       const float* in = (l == 0) ? X : act[l - 1];
       const int ld_in = (l == 0) ? ldx : L[l].in_ld;
-      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, s->slab, s->bias_slab);
-      const size_t cnt = (size_t)L[l].out * L[l].in_ld;
-      hipLaunchKernelGGL(hx_reduce_slabs_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, s->slab, splits, cnt, cnt, s->grads + L[l].w, 0);
-      hipLaunchKernelGGL(hx_reduce_slabs_kernel, dim3((L[l].out + 255) / 256), dim3(256), 0, st, s->bias_slab, splits, (size_t)L[l].out, (size_t)L[l].out, s->grads + L[l].b, 0);
+      float* slab = s->slab + s->slab_off[net * 4 + l];
+      float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
+      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab);
+      const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
+      int k = rt.nseg;
+      rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 255) / 256;
+      k = ++rt.nseg;
+      rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (L[l].out + 255) / 256;
+      ++rt.nseg;
       if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out);
     }
   }
+  rt.block0[rt.nseg] = blocks;
+  hipLaunchKernelGGL(hx_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, rt);
   HX_CHECK(hipGetLastError());
   if (grad_buffer) *grad_buffer = s->grads;
   if (count) *count = (int64_t)s->padded + 4;
