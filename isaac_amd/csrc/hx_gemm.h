@@ -160,6 +160,9 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
           for (int j = 0; j < 4; ++j) fb[i][j] = Bs[(kb * 8 + 4 * h + j) * BN + row];
         }
       }
+#ifdef HX_GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -167,6 +170,9 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
 #pragma unroll
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+#ifdef HX_GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if (EPI == EPI_SLAB && !A_KM) {
       // bias gradient = column sums of dZ = row sums over k of the A tile; done once per tile row

@@ -154,6 +154,119 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
   logp[e] = lp;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused actor forward for the rollout (actor_critic.py:111-117 at M = num_envs): obs -> 3 x (Linear + ELU) -> Linear ->
+// sample -> log-prob in ONE launch.  At 4096 rows the layer-by-layer GEMMs are latency-bound (a 64x128 tile walks its
+// whole K loop alone on a CU), so here a workgroup owns only 16 rows -- 256 workgroups, one per CU -- keeps every
+// activation in LDS (16 x (616+512+256+128) floats) and streams the weights from L2 straight into MFMA B fragments.
+// v_mfma_f32_16x16x4_f32: lane l holds A[row l&15][k = l>>4], B[k = l>>4][col l&15]; with the k-permutation used by
+// hx_gemm.h a float4 per lane (k = 4*(l>>4) .. +3 of a 16-deep block) feeds 4 MFMAs.  C/D: col = l&15, row = 4*(l>>4)+reg.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define FA_ROWS 16
+template <int NT>   // NT = 16-column tiles per wave
+__device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, int ldw,
+                                         const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane) {
+  const int r16 = lane & 15, kq = lane >> 4;
+  f32x4v acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  const int nkb = (K + 15) / 16;
+  f32x4v bcur[NT], bnxt[NT];
+  auto loadB = [&](int kb, f32x4v* dst) {
+    const int k = kb * 16 + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4v v = {0.f, 0.f, 0.f, 0.f};
+      if (k < K) v = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
+      dst[t] = v;
+    }
+  };
+  loadB(0, bcur);
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb + 1 < nkb) loadB(kb + 1, bnxt);
+    const int k = kb * 16 + 4 * kq;
+    f32x4v a = {0.f, 0.f, 0.f, 0.f};
+    if (k < K) a = *reinterpret_cast<const f32x4v*>(Xs + r16 * ldx + k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bcur[t][i], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bcur[t] = bnxt[t];
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n_wave0 + t * 16 + r16;
+    const float bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Hs[(kq * 4 + r) * ldh + col] = hx_elu(acc[t][r] + bv);
+  }
+}
+
+__global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __restrict__ obs, int obs_ld, int n,
+                                                             const float* __restrict__ W1, const float* __restrict__ b1, int K1, int N1,
+                                                             const float* __restrict__ W2, const float* __restrict__ b2, int N2,
+                                                             const float* __restrict__ W3, const float* __restrict__ b3, int N3,
+                                                             const float* __restrict__ W4, const float* __restrict__ b4,
+                                                             const float* __restrict__ stdp, const float* __restrict__ eps, int A,
+                                                             uint32_t k0, uint32_t k1, uint32_t step,
+                                                             float* actions, float* mu_out, float* logp) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
+  float* Xs = fsm;
+  float* H1 = Xs + FA_ROWS * ldx;
+  float* H2 = H1 + FA_ROWS * ld1;
+  float* H3 = H2 + FA_ROWS * ld2;
+  float* sMu = H3 + FA_ROWS * ld3;          // [16][MAX_A]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * FA_ROWS;
+  // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
+  for (int i = tid; i < FA_ROWS * (K1 / 4); i += 256) {
+    const int r = i / (K1 / 4), c4 = i % (K1 / 4);
+    const int gr = min(row0 + r, n - 1);
+    *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
+  }
+  __syncthreads();
+  fa_layer<8>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
+  __syncthreads();
+  fa_layer<4>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
+  __syncthreads();
+  fa_layer<2>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);       // 256 -> 128
+  __syncthreads();
+  // head: mu[r][j] = W4[j] . H3[r] + b4[j]
+  if (tid < FA_ROWS * A) {
+    const int r = tid / A, j = tid % A;
+    float m = 0.f;
+    for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4[j * N3 + k], m);
+    sMu[r * MAX_A + j] = m + b4[j];
+  }
+  __syncthreads();
+  if (tid < FA_ROWS && row0 + tid < n) {
+    const int e = row0 + tid;
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+      const float m = sMu[tid * MAX_A + j];
+      const float sg = m * 0.f + stdp[j];
+      float z;
+      if (eps) z = eps[(size_t)e * A + j];
+      else {
+        uint32_t o[4];
+        philox4p(k0, k1, (uint32_t)e, step, (uint32_t)j, 7u, o);
+        const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+        const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
+        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+      }
+      const float a = m + sg * z;
+      actions[(size_t)e * A + j] = a;
+      mu_out[(size_t)e * A + j] = m;
+      const float d = a - m;
+      lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - LOG_SQRT_2PI;
+    }
+    logp[e] = lp;
+  }
+}
+
 // critic head only (bootstrap value of compute_returns, ppo.py:116)
 __global__ void __launch_bounds__(256) hx_value_head_kernel(const float* __restrict__ h3c, int hw, const float* __restrict__ W4c,
                                                             const float* __restrict__ b4c, int n, float* values) {
@@ -796,6 +909,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   for (int j = 0; j < A; ++j) sd[j] = cfg->init_noise_std;
   HX_CHECK(hipMemcpyAsync(s->params + s->std_off, sd.data(), sd.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
   HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
   s->prof = false; s->ev_used = 0;
@@ -920,10 +1034,21 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     // large batch (chunk * N rows -> full-size tiles) on the second stream, where it fills the CUs that the
     // latency-bound env-step kernels (128 waves) leave idle.
     HX_CHECK(hipEventRecord(s->ev_priv, st));                 // slot t's privileged rows are in the storage
-    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
-    hipLaunchKernelGGL(hx_actor_head_kernel, dim3((count + 15) / 16), dim3(256), A * hw * sizeof(float), st, aa[2], hw,
-                       s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
-                       s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
+    const Layer* La = s->L;
+    const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
+    if (fused_ok) {
+      const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
+      hipLaunchKernelGGL(hx_actor_fused_kernel, dim3((count + FA_ROWS - 1) / FA_ROWS), dim3(256), shm, st, so, s->cfg.obs_ld, count,
+                         s->params + La[0].w, s->params + La[0].b, La[0].in_ld, La[0].out, s->params + La[1].w, s->params + La[1].b, La[1].out,
+                         s->params + La[2].w, s->params + La[2].b, La[2].out, s->params + La[3].w, s->params + La[3].b,
+                         s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,
+                         s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
+    } else {
+      mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
+      hipLaunchKernelGGL(hx_actor_head_kernel, dim3((count + 15) / 16), dim3(256), A * hw * sizeof(float), st, aa[2], hw,
+                         s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
+                         s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
+    }
     if (t + 1 - s->crit_done >= HX_CRITIC_CHUNK) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
   } else {
     mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
