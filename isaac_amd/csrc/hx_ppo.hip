@@ -11,6 +11,7 @@
 //   minibatch workspace       : gathered rows + one activation buffer per hidden layer, [M][width].
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -172,29 +173,36 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   const int nkb = (K + 15) / 16;
-  f32x4v bcur[NT], bnxt[NT];
+  // weights are streamed from L2 with TWO k-blocks in flight per wave (one was L2-latency bound: 80 us per call)
+  f32x4v b0[NT], b1[NT], b2[NT];
   auto loadB = [&](int kb, f32x4v* dst) {
     const int k = kb * 16 + 4 * kq;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4v v = {0.f, 0.f, 0.f, 0.f};
-      if (k < K) v = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
+      if (kb < nkb && k < K) v = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
       dst[t] = v;
     }
   };
-  loadB(0, bcur);
-  for (int kb = 0; kb < nkb; ++kb) {
-    if (kb + 1 < nkb) loadB(kb + 1, bnxt);
+  auto step = [&](int kb, const f32x4v* bc) {
     const int k = kb * 16 + 4 * kq;
     f32x4v a = {0.f, 0.f, 0.f, 0.f};
     if (k < K) a = *reinterpret_cast<const f32x4v*>(Xs + r16 * ldx + k);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bcur[t][i], acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bcur[t] = bnxt[t];
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bc[t][i], acc[t], 0, 0, 0);
+  };
+  loadB(0, b0);
+  loadB(1, b1);
+  int kb = 0;
+  for (; kb + 2 < nkb; kb += 3) {
+    loadB(kb + 2, b2); step(kb, b0);
+    loadB(kb + 3, b0); step(kb + 1, b1);
+    loadB(kb + 4, b1); step(kb + 2, b2);
   }
+  if (kb < nkb) step(kb, b0);
+  if (kb + 1 < nkb) step(kb + 1, b1);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = n_wave0 + t * 16 + r16;
@@ -825,11 +833,20 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
   {
-    // the deferred critic is background work: lowest priority, so the rollout's critical path (actor GEMMs, env-step
-    // kernel) is dispatched first whenever both have workgroups waiting
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    HX_CHECK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least));
+    // The deferred critic is background work: lowest stream priority, so the rollout's critical path (actor kernel,
+    // env-step kernel) is dispatched first whenever both have workgroups waiting.  Confining it to a subset of the
+    // CUs (hipExtStreamCreateWithCUMask) was measured and is WORSE (profiles/r01_critic_cu_mask.txt): the env-step
+    // kernel's slow-down during critic bursts is not a CU-occupancy effect, and a narrower critic only finishes later.
+    // HX_CRITIC_CU_WORD=<hex 32-bit word, repeated for each group of 32 CUs> keeps the experiment reproducible.
+    if (const char* e = getenv("HX_CRITIC_CU_WORD")) {
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = (uint32_t)strtoul(e, nullptr, 16);
+      HX_CHECK(hipExtStreamCreateWithCUMask(&s->stream2, 8, mask));
+    } else {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      HX_CHECK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least));
+    }
   }
   HX_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HX_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
