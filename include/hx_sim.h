@@ -143,6 +143,12 @@ int hx_sim_create(const hx_sim_cfg* cfg, const float* shape_friction_h, const fl
 void hx_sim_destroy(hx_sim* s);
 int hx_sim_reset_all(hx_sim* s, const float* pack /*nullable*/);
 int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const float* pack /*nullable*/);
+/* hx_sim_step with zero-copy hand-over: the new observation rows ([N][HX_OBS_LD] / [N][HX_PRIV_LD]) and, if rew_dst is
+ * not NULL, reward / done / extras["time_outs"] of the step are written straight into the caller's buffers (the
+ * learner's rollout storage, what RolloutStorage.add_transitions copies in the reference, rollout_storage.py:87-100).
+ * HX_BUF_OBS / HX_BUF_PRIV then point at obs_dst / priv_dst until the next step. */
+int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
+                   float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst);
 int hx_sim_buffer(hx_sim* s, int which, void** dptr);
 int hx_sim_get_state(hx_sim* s, float* root13_h /*[N][13]*/, float* q_h /*[N][10]*/, float* qd_h /*[N][10]*/);
 int hx_sim_set_state(hx_sim* s, const float* root13_h, const float* q_h, const float* qd_h);

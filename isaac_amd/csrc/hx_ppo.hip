@@ -1038,8 +1038,9 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
   if (env0 < 0 || count <= 0 || env0 + count > N) { hx_set_error("hx_ppo_act: env range out of bounds"); return -2; }
   float* so = s->s_obs + ((size_t)t * N + env0) * s->cfg.obs_ld;
   float* sp = s->s_priv + ((size_t)t * N + env0) * s->cfg.priv_ld;
-  HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
-  HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)count * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // rows already in place when the env step wrote them straight into the storage (hx_sim_step_ex)
+  if (obs != so) HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (priv != sp) HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)count * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
   float* aa[3]; float* ac[3];
   for (int l = 0; l < 3; ++l) { aa[l] = s->act_a[l] + (size_t)env0 * s->cfg.actor_hidden[l]; ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l]; }
   const int hw = s->cfg.actor_hidden[2];
@@ -1315,21 +1316,34 @@ extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
 // One shard: whole-batch calls (critic chain forked on the learner's second stream).  Several shards: every
 // shard advances on its own stream; one shard's env-step kernel overlaps the other shards' GEMMs.
 extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps) {
+  const int N = p->cfg.num_envs, T = p->cfg.num_steps;
   for (int t = 0; t < steps; ++t) {
     for (int h = 0; h < nshards; ++h) {
       void *obs, *priv, *rew, *rst, *tov;
       int rc = hx_sim_buffer(sims[h], HX_BUF_OBS, &obs); if (rc) return rc;
       rc = hx_sim_buffer(sims[h], HX_BUF_PRIV, &priv); if (rc) return rc;
       float* act = nullptr;
-      if (nshards == 1) rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act);
-      else rc = hx_ppo_act_range(p, (const float*)obs, (const float*)priv, nullptr, env0[h], count[h], hx_sim_stream(sims[h]), &act);
-      if (rc) return rc;
-      rc = hx_sim_step(sims[h], act, nullptr); if (rc) return rc;
-      hx_sim_buffer(sims[h], HX_BUF_REW, &rew); hx_sim_buffer(sims[h], HX_BUF_RESET, &rst); hx_sim_buffer(sims[h], HX_BUF_TIMEOUT_VISIBLE, &tov);
-      if (nshards == 1) rc = hx_ppo_process_step(p, (const float*)rew, (const uint8_t*)rst, (const uint8_t*)tov);
-      else rc = hx_ppo_process_step_range(p, (const float*)rew, (const uint8_t*)rst, (const uint8_t*)tov, env0[h], count[h],
-                                          hx_sim_stream(sims[h]), h == nshards - 1);
-      if (rc) return rc;
+      if (nshards == 1) {
+        // whole batch, zero-copy: the env writes observation t+1, reward, done and time-out of step t straight into
+        // the rollout storage (slot t+1 rows / slot t scalars); 3 launches per step: actor, env step, stack
+        const int slot = p->step;
+        if (slot >= T) { hx_set_error("Rollout buffer overflow"); return -10; }
+        rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act); if (rc) return rc;
+        float* od = nullptr; float* pd = nullptr;
+        if (slot + 1 < T) { od = p->s_obs + (size_t)(slot + 1) * N * p->cfg.obs_ld; pd = p->s_priv + (size_t)(slot + 1) * N * p->cfg.priv_ld; }
+        rc = hx_sim_step_ex(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
+                            p->s_timeouts + (size_t)slot * N);
+        if (rc) return rc;
+        p->step += 1;
+      } else {
+        rc = hx_ppo_act_range(p, (const float*)obs, (const float*)priv, nullptr, env0[h], count[h], hx_sim_stream(sims[h]), &act);
+        if (rc) return rc;
+        rc = hx_sim_step(sims[h], act, nullptr); if (rc) return rc;
+        hx_sim_buffer(sims[h], HX_BUF_REW, &rew); hx_sim_buffer(sims[h], HX_BUF_RESET, &rst); hx_sim_buffer(sims[h], HX_BUF_TIMEOUT_VISIBLE, &tov);
+        rc = hx_ppo_process_step_range(p, (const float*)rew, (const uint8_t*)rst, (const uint8_t*)tov, env0[h], count[h],
+                                       hx_sim_stream(sims[h]), h == nshards - 1);
+        if (rc) return rc;
+      }
     }
   }
   return 0;

@@ -559,26 +559,52 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   }
 }
 
-// Frame stacking (hector_env.py:246-254 + clip of legged_robot.py:104-107), coalesced along the row:
-// dst[e][0:(S-1)*F] = reset ? 0 : src[e][F:S*F] ;  dst[e][(S-1)*F : S*F] = clip(frame[:,e]).
-__global__ void __launch_bounds__(256) hx_stack_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                       const float* __restrict__ frame, const unsigned char* __restrict__ reset,
-                                                       int n, int F, int ld, float clip, const unsigned char* timeout,
-                                                       unsigned char* timeout_visible, const int* num_reset) {
+// Frame stacking for BOTH observation streams (hector_env.py:246-254 + clip of legged_robot.py:104-107), one
+// workgroup per env, coalesced along the rows:
+//   dst[e][0:(S-1)*F] = reset ? 0 : src[e][F:S*F] ;  dst[e][(S-1)*F : S*F] = clip(frame[:,e]).
+// dst may be the learner's rollout storage (zero-copy hand-over, hx_sim_step_ex); the same launch refreshes
+// extras["time_outs"], hands reward / done / time-out to the learner's slot and recycles the reset counter.
+struct StackArgs {
+  const float* obs_src; float* obs_dst; const float* obs_frame;
+  const float* priv_src; float* priv_dst; const float* priv_frame;
+  const unsigned char* reset; const unsigned char* timeout; unsigned char* timeout_visible;
+  const int* num_reset; int* num_reset_next;
+  const float* rew; float* rew_out; unsigned char* done_out; unsigned char* timeout_out;
+  int n; float clip;
+};
+__global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
   const int e = blockIdx.x;
-  const int keep = (HX_FRAME_STACK - 1) * F;
-  const bool rst = reset[e] != 0;
-  const float* s = src + (size_t)e * ld;
-  float* d = dst + (size_t)e * ld;
-  for (int k = threadIdx.x; k < ld; k += blockDim.x) {
-    float v = 0.f;
-    if (k < keep) v = rst ? 0.f : s[k + F];
-    else if (k < keep + F) v = fminf(fmaxf(frame[(size_t)(k - keep) * n + e], -clip), clip);
-    d[k] = v;
+  const bool rst = a.reset[e] != 0;
+  {
+    const int F = HX_OBS_FRAME, ld = HX_OBS_LD, keep = (HX_FRAME_STACK - 1) * F;
+    const float* s = a.obs_src + (size_t)e * ld;
+    float* d = a.obs_dst + (size_t)e * ld;
+    for (int k = threadIdx.x; k < ld; k += blockDim.x) {
+      float v = 0.f;
+      if (k < keep) v = rst ? 0.f : s[k + F];
+      else if (k < keep + F) v = fminf(fmaxf(a.obs_frame[(size_t)(k - keep) * a.n + e], -a.clip), a.clip);
+      d[k] = v;
+    }
   }
-  // extras["time_outs"] is rebound only inside reset_idx, i.e. when at least one env reset this step
-  // (legged_robot.py:172-173,208-209)
-  if (timeout_visible && threadIdx.x == 0 && *num_reset > 0) timeout_visible[e] = timeout[e];
+  {
+    const int F = HX_PRIV_FRAME, ld = HX_PRIV_LD, keep = (HX_FRAME_STACK - 1) * F;
+    const float* s = a.priv_src + (size_t)e * ld;
+    float* d = a.priv_dst + (size_t)e * ld;
+    for (int k = threadIdx.x; k < ld; k += blockDim.x) {
+      float v = 0.f;
+      if (k < keep) v = rst ? 0.f : s[k + F];
+      else if (k < keep + F) v = fminf(fmaxf(a.priv_frame[(size_t)(k - keep) * a.n + e], -a.clip), a.clip);
+      d[k] = v;
+    }
+  }
+  if (threadIdx.x == 0) {
+    // extras["time_outs"] is rebound only inside reset_idx, i.e. when at least one env reset this step
+    // (legged_robot.py:172-173,208-209)
+    unsigned char tv = a.timeout_visible[e];
+    if (*a.num_reset > 0) { tv = a.timeout[e]; a.timeout_visible[e] = tv; }
+    if (a.rew_out) { a.rew_out[e] = a.rew[e]; a.done_out[e] = rst ? 1 : 0; a.timeout_out[e] = tv; }
+    if (e == 0) *a.num_reset_next = 0;          // the other counter of the ping-pong pair: free until the next step
+  }
 }
 
 // ================================================================= host side
@@ -596,6 +622,8 @@ struct hx_sim {
   SimPtrs p;
   float *obs[2], *priv[2];
   int cur;
+  float *obs_cur, *priv_cur;      // where the current observation rows live (own buffer or the learner's storage)
+  int* num_reset2[2]; int parity;
   unsigned char* timeout_visible;
   long long step_counter;
   uint32_t rng_step;
@@ -641,12 +669,14 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
   rc |= dalloc(s, &s->p.rew, n);
   rc |= dalloc(s, &s->p.reset, n);
   rc |= dalloc(s, &s->p.timeout, n);
-  rc |= dalloc(s, &s->p.num_reset, 1);
+  rc |= dalloc(s, &s->num_reset2[0], 1); rc |= dalloc(s, &s->num_reset2[1], 1);
+  s->p.num_reset = s->num_reset2[0]; s->parity = 0;
   rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS + 2);
   rc |= dalloc(s, &s->p.stat_cnt, 1);
   rc |= dalloc(s, &s->timeout_visible, n);
   for (int i = 0; i < 2; ++i) { rc |= dalloc(s, &s->obs[i], n * HX_OBS_LD); rc |= dalloc(s, &s->priv[i], n * HX_PRIV_LD); }
   if (rc) return -3;
+  s->obs_cur = s->obs[0]; s->priv_cur = s->priv[0];
   // initial state: actor creation pose, identity orientation, everything else zero; last_feet_z = 0.05 (hector_env.py:48)
   std::vector<float> st((size_t)S_STATE_SIZE * n, 0.f);
   for (size_t e = 0; e < n; ++e) {
@@ -675,7 +705,9 @@ extern "C" void hx_sim_destroy(hx_sim* s) {
   delete s;
 }
 
-static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode) {
+struct StepOut { float* obs; float* priv; float* rew; unsigned char* done; unsigned char* timeout; };
+
+static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode, const StepOut* out) {
   const int n = s->cfg.num_envs;
   StepArgs A;
   A.mode = mode;
@@ -684,28 +716,45 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   A.k0 = (uint32_t)(s->seed & 0xffffffffu);
   A.k1 = (uint32_t)(s->seed >> 32);
   A.rng_step = s->rng_step++;
-  HX_CHECK(hipMemsetAsync(s->p.num_reset, 0, sizeof(int), s->stream));
+  // reset counter: ping-pong pair; the stack kernel of step t zeroes the counter step t+1 will use
+  s->p.num_reset = s->num_reset2[s->parity];
   hipLaunchKernelGGL(hx_env_step_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
-  const int nxt = s->cur ^ 1;
-  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, s->obs[s->cur], s->obs[nxt], s->p.obs_frame, s->p.reset,
-                     n, HX_OBS_FRAME, HX_OBS_LD, s->cfg.clip_observations, s->p.timeout, s->timeout_visible, s->p.num_reset);
-  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, s->priv[s->cur], s->priv[nxt], s->p.priv_frame, s->p.reset,
-                     n, HX_PRIV_FRAME, HX_PRIV_LD, s->cfg.clip_observations, (const unsigned char*)nullptr, (unsigned char*)nullptr, (const int*)nullptr);
-  s->cur = nxt;
+  // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
+  float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
+  if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }
+  if (out && out->obs) { od = out->obs; pd = out->priv; } else s->cur ^= 1;
+  StackArgs k{};
+  k.obs_src = s->obs_cur; k.obs_dst = od; k.obs_frame = s->p.obs_frame;
+  k.priv_src = s->priv_cur; k.priv_dst = pd; k.priv_frame = s->p.priv_frame;
+  k.reset = s->p.reset; k.timeout = s->p.timeout; k.timeout_visible = s->timeout_visible;
+  k.num_reset = s->num_reset2[s->parity]; k.num_reset_next = s->num_reset2[s->parity ^ 1];
+  k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
+  k.n = n; k.clip = s->cfg.clip_observations;
+  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
+  s->obs_cur = od; s->priv_cur = pd;
+  s->parity ^= 1;
   HX_CHECK(hipGetLastError());
   return 0;
 }
 
-extern "C" int hx_sim_reset_all(hx_sim* s, const float* pack) { return launch_step(s, nullptr, pack, 1); }
+extern "C" int hx_sim_reset_all(hx_sim* s, const float* pack) { return launch_step(s, nullptr, pack, 1, nullptr); }
 extern "C" int hx_sim_step(hx_sim* s, const float* actions, const float* pack) {
   if (!actions) { hx_set_error("hx_sim_step: actions is NULL"); return -2; }
-  return launch_step(s, actions, pack, 0);
+  return launch_step(s, actions, pack, 0, nullptr);
+}
+// Zero-copy form: the new observation rows and the step's reward / done / time-out flags are written straight into
+// buffers of the caller (the learner's rollout storage); any of the three scalar outputs may be NULL together.
+extern "C" int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
+                              float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst) {
+  if (!actions) { hx_set_error("hx_sim_step_ex: actions is NULL"); return -2; }
+  StepOut o{obs_dst, priv_dst, rew_dst, done_dst, timeout_dst};
+  return launch_step(s, actions, pack, 0, &o);
 }
 
 extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
   switch (which) {
-    case HX_BUF_OBS: *dptr = s->obs[s->cur]; break;
-    case HX_BUF_PRIV: *dptr = s->priv[s->cur]; break;
+    case HX_BUF_OBS: *dptr = s->obs_cur; break;
+    case HX_BUF_PRIV: *dptr = s->priv_cur; break;
     case HX_BUF_REW: *dptr = s->p.rew; break;
     case HX_BUF_RESET: *dptr = s->p.reset; break;
     case HX_BUF_TIMEOUT: *dptr = s->p.timeout; break;
@@ -718,7 +767,7 @@ extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
     case HX_BUF_EPISODE_SUMS: *dptr = s->p.ep_sums; break;
     case HX_BUF_FEET_AIR_TIME: *dptr = s->p.st + (size_t)S_AIR * s->cfg.num_envs; break;
     case HX_BUF_FEET_HEIGHT: *dptr = s->p.st + (size_t)S_FEET_H * s->cfg.num_envs; break;
-    case HX_BUF_NUM_RESET: *dptr = s->p.num_reset; break;
+    case HX_BUF_NUM_RESET: *dptr = s->num_reset2[s->parity ^ 1]; break;
     default: hx_set_error("hx_sim_buffer: unknown id"); return -2;
   }
   return 0;
