@@ -54,3 +54,9 @@ def load_env():
     cfg_mod = importlib.import_module("humanoid.envs.custom.hector_config")
     helpers = importlib.import_module("humanoid.utils.helpers")
     return env_mod, cfg_mod, helpers
+
+
+def load_terrain():
+    """reference humanoid/utils/terrain.py (Terrain, HumanoidTerrain) over the stub `isaacgym.terrain_utils`."""
+    load_env()
+    return importlib.import_module("humanoid.utils.terrain")
