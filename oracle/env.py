@@ -87,11 +87,14 @@ def unif(lo, hi, u):
 
 class HectorEnvOracle:
     def __init__(self, n, shape_friction, base_mass, env_origins, init_pack, add_noise=True,
-                 start_xy=None, phys_dtype=np.float64):
+                 start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False):
+        """terrain: oracle.terrain.HeightField or None (plane).  custom_origins: True for heightfield/trimesh
+        (legged_robot.py:688), which adds U[-1,1] to the reset xy (:381-384)."""
         self.n = n
+        self.custom_origins = custom_origins
         m0 = P.load_model()["bodies"][0]["mass"]
         self.phys = P.HectorPhysics(n, base_mass_added=np.asarray(base_mass, np.float64) - m0,
-                                    shape_friction=shape_friction, dtype=phys_dtype)
+                                    shape_friction=shape_friction, dtype=phys_dtype, terrain=terrain)
         self.state = P.State(n, phys_dtype)
         if start_xy is not None:
             # actor creation pose (legged_robot.py:653-655): origin + U[-1,1]^2, z of the origin; the first
@@ -244,6 +247,9 @@ class HectorEnvOracle:
         base_init = np.array([0, 0, 0.55, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], F)
         self.root[ids] = base_init
         self.root[ids, :3] += self.env_origins[ids]
+        if self.custom_origins:
+            o = RP["reset_xy"]
+            self.root[ids, :2] += unif(-1.0, 1.0, pack[o:o + 2].T[ids])
         self._push_root(ids)
         self._resample_commands(ids, pack, "cmd_b")
         self.last_last_actions[ids] = 0

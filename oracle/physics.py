@@ -126,8 +126,9 @@ class State:
 
 
 class HectorPhysics:
-    def __init__(self, n, base_mass_added=None, shape_friction=None, dtype=np.float64, model=None):
+    def __init__(self, n, base_mass_added=None, shape_friction=None, dtype=np.float64, model=None, terrain=None):
         self.n = n
+        self.terrain = terrain      # None = ground plane z=0; else oracle.terrain.HeightField
         self.dtype = dtype
         self.model = model or load_model()
         B = self.model["bodies"]
@@ -243,11 +244,16 @@ class HectorPhysics:
         point_rec = []
         for body, pts in self.contacts:
             Rb = R[body]
-            nrm_b = Rb[:, 2, :]                      # world z axis in body coords = R^T e_z
             for r in pts:
-                rw = np.einsum("nij,j->ni", Rb, r)
-                z = p[body][:, 2] + rw[:, 2]
-                pen = -z
+                pw = p[body] + np.einsum("nij,j->ni", Rb, r)
+                if self.terrain is None:
+                    nrm_b = Rb[:, 2, :]                  # world z axis in body coords = R^T e_z
+                    pen = -pw[:, 2]
+                else:
+                    # distance to the plane of the terrain triangle under the point, along its normal
+                    h, nrm_w = self.terrain.query(pw[:, 0], pw[:, 1])
+                    nrm_b = np.einsum("nji,nj->ni", Rb, nrm_w).astype(dtp)
+                    pen = ((h - pw[:, 2]) * nrm_w[:, 2]).astype(dtp)
                 vb = v[body][:, 3:] + np.cross(v[body][:, :3], r)     # point velocity, body coords
                 vn = np.einsum("ni,ni->n", vb, nrm_b)
                 fn0 = CONTACT_KN * pen - c_n * vn

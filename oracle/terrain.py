@@ -273,7 +273,9 @@ class HeightField:
     gives the mesh, legged_robot.py:561-562,578-579); outside the grid the border row/column continues."""
 
     def __init__(self, height_field_raw, horizontal_scale, vertical_scale, border_size):
-        self.h = np.asarray(height_field_raw, np.float64) * vertical_scale
+        # heights are held as float32 numbers, the precision of the mesh vertices the reference hands to the
+        # simulator (convert_heightfield_to_trimesh returns float32) and of the device copy
+        self.h = (np.asarray(height_field_raw, np.float64) * vertical_scale).astype(np.float32).astype(np.float64)
         self.hs = float(horizontal_scale)
         self.x0 = self.y0 = -float(border_size)
 

@@ -31,13 +31,19 @@ RP_SIZE = 75
 
 
 def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_counter_init=0, add_noise=True,
-             full_stack_steps=(0, 1, 14, 15, 16)):
+             full_stack_steps=(0, 1, 14, 15, 16), terrain=None):
+    """terrain=None: ground plane.  terrain=dict(mesh_type=, num_rows=, num_cols=, border_size=): the reference's
+    own HumanoidTerrain (humanoid/utils/terrain.py) lays out the map, the env takes its origins from it
+    (legged_robot.py:687-697) and every reset adds U[-1,1] to xy (:381-384)."""
     env_mod, cfg_mod, helpers = loader.load_env()
     from isaacgym import gymapi, torch_utils
     import isaacgym.torch_utils  # noqa: F401
 
     cfg = cfg_mod.HectorCfg()
-    cfg.terrain.mesh_type = "plane"          # first slice (heightfield is a next row)
+    cfg.terrain.mesh_type = "plane"
+    if terrain is not None:
+        for k, v in terrain.items():
+            setattr(cfg.terrain, k, v)
     cfg.env.num_envs = n_envs
     cfg.noise.add_noise = add_noise
     cfg.seed = seed
@@ -67,7 +73,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         N = n_envs
         # creation-time draws (start xy, friction buckets) are creation inputs, not step packs; the
         # constructor's reset_idx(all)+compute_observations made exactly the last five draws
-        creation_draws = len(log) - (5 if add_noise else 4)
+        creation_draws = len(log) - (5 if add_noise else 4) - (1 if terrain is not None else 0)
 
         # wrap methods to leave markers with the env ids they act on
         orig_resample, orig_reset_dofs = env._resample_commands, env._reset_dofs
@@ -109,6 +115,10 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
                     r = next(it)
                     assert r[0] == "rand" and r[1].shape == (len(ids), 10)
                     pack[RP["reset_q"]:RP["reset_q"] + 10, ids] = r[1].numpy().T
+                    if terrain is not None:          # custom origins: xy offset of the reset pose
+                        r = next(it)
+                        assert r[0] == "rand" and r[1].shape == (len(ids), 2)
+                        pack[RP["reset_xy"]:RP["reset_xy"] + 2, ids] = r[1].numpy().T
                     state = "reset"
                 elif e[0] == "rand" and e[1].shape == (N, 2):
                     pack[RP["push"]:RP["push"] + 2] = e[1].numpy().T
@@ -126,7 +136,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         # but before the markers were installed: re-derive the init pack from the raw log by position
         init_entries = log[creation_draws:]
         # order: rand(N,10) reset dofs ; 3x rand(N,1) resample ; randn(N,41)
-        ie = [("mark_reset", torch.arange(N)), init_entries[0], ("mark_resample", torch.arange(N))] + init_entries[1:]
+        k0 = 2 if terrain is not None else 1
+        ie = [("mark_reset", torch.arange(N))] + init_entries[:k0] + [("mark_resample", torch.arange(N))] + init_entries[k0:]
         packs = [build_pack(ie, True)]
         log.clear()
 
@@ -188,6 +199,13 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         res["p_gains"] = env.p_gains[0].numpy().copy()
         res["d_gains"] = env.d_gains[0].numpy().copy()
         res["default_dof_pos"] = env.default_dof_pos[0].numpy().copy()
+        if terrain is not None:
+            res["terrain_heights"] = np.asarray(env.terrain.heightsamples).copy()
+            res["terrain_params"] = np.array([cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale, cfg.terrain.border_size])
+            res["terrain_levels"] = env.terrain_levels.numpy().copy()
+            res["terrain_types"] = env.terrain_types.numpy().copy()
+            res["terrain_origins"] = env.terrain_origins.numpy().copy()
+            res["terrain_level_stat"] = np.array(float(env.extras["episode"]["terrain_level"])) if "episode" in env.extras and "terrain_level" in env.extras["episode"] else np.array(np.nan)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **res)
         print(name, "steps", n_steps, "resets", int(res["reset"].sum()), "timeouts", int(res["timeout"].sum()),
@@ -206,3 +224,8 @@ if __name__ == "__main__":
     #    the global push (counter % 400 == 0); observation noise off so stacks are exact
     generate("env_rollout_b", N, 40, seed=7, action_std=0.3,
              ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390, add_noise=False)
+    # C: rough terrain (the reference's default mesh_type): tile map from the reference's HumanoidTerrain,
+    #    env origins on the tiles, reset xy offsets, contact against slopes / blocks / stairs
+    generate("env_rollout_c", N, 100, seed=5, action_std=0.6,
+             ep_len_init=[0, 2350, 0, 0, 2380, 0, 0, 0],
+             terrain=dict(mesh_type="trimesh", num_rows=2, num_cols=4, border_size=3.0))

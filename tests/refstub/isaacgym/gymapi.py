@@ -90,6 +90,7 @@ class Gym:
         self.state = None
         self.torque_checks = 0
         self.substep_hook = None
+        self.terrain_hf = None
 
     # ---- sim / asset creation
     def create_sim(self, *a):
@@ -97,6 +98,27 @@ class Gym:
 
     def add_ground(self, sim, params):
         self.plane = params
+
+    def add_heightfield(self, sim, heightsamples, params):
+        """reference legged_robot.py:553-569"""
+        from oracle.terrain import HeightField
+        assert params.column_scale == params.row_scale and params.transform.p.x == params.transform.p.y
+        self.terrain_hf = HeightField(np.asarray(heightsamples), params.column_scale, params.vertical_scale,
+                                      -params.transform.p.x)
+
+    def add_triangle_mesh(self, sim, vertices, triangles, params):
+        """reference legged_robot.py:571-585: flattened float32 vertices / uint32 triangles of
+        convert_heightfield_to_trimesh.  The grid is recovered from the vertex list (row 0 lies in the flat
+        border, so its x is exactly 0 and the first x > 0 marks the row length)."""
+        from oracle.terrain import HeightField
+        v = np.asarray(vertices, np.float64).reshape(-1, 3)
+        assert v.shape[0] == params.nb_vertices and np.asarray(triangles).size == 3 * params.nb_triangles
+        cols = int(np.argmax(v[:, 0] > 1e-6))
+        rows = v.shape[0] // cols
+        assert rows * cols == v.shape[0] and 2 * (rows - 1) * (cols - 1) == params.nb_triangles
+        hs = round(float(v[cols, 0] - v[0, 0]), 6)          # float32 vertex spacing -> the configured scale
+        assert params.transform.p.x == params.transform.p.y
+        self.terrain_hf = HeightField(v[:, 2].reshape(rows, cols), hs, 1.0, -params.transform.p.x)
 
     def load_asset(self, sim, root, file, options):
         return "asset"
@@ -156,7 +178,7 @@ class Gym:
         n = self.n
         m0 = self.model["bodies"][0]["mass"]
         self.phys = _phys.HectorPhysics(n, base_mass_added=np.array(self.base_mass) - m0,
-                                        shape_friction=np.array(self.shape_friction))
+                                        shape_friction=np.array(self.shape_friction), terrain=self.terrain_hf)
         self.state = _phys.State(n)
         self.state.root_pos[:] = np.array(self.start_pos)
         self.root_t = torch.zeros(n, 13)

@@ -11,12 +11,24 @@ from oracle.env import REWARD_ORDER, REWARD_SCALE, HectorEnvOracle
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40)])
+def make_oracle_env(fx, **kw):
+    """HectorEnvOracle seeded with a fixture's creation data (terrain included when the fixture has one)."""
+    n, _, _, _, noise = (int(x) for x in fx["meta"])
+    terrain = None
+    if "terrain_heights" in fx:
+        from oracle.terrain import HeightField
+        hs, vs, border = fx["terrain_params"]
+        terrain = HeightField(fx["terrain_heights"], hs, vs, border)
+    return HectorEnvOracle(n, fx["init_shape_friction"], fx["init_base_mass"], fx["init_env_origins"], fx["packs"][0],
+                           add_noise=bool(noise), start_xy=fx["init_start_pos"], terrain=terrain,
+                           custom_origins=terrain is not None, **kw)
+
+
+@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100)])
 def test_oracle_env_reproduces_reference(name, steps):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
-    env = HectorEnvOracle(n, fx["init_shape_friction"], fx["init_base_mass"], fx["init_env_origins"], fx["packs"][0],
-                          add_noise=bool(noise), start_xy=fx["init_start_pos"])
+    env = make_oracle_env(fx)
     np.testing.assert_allclose(env.obs_buf, fx["init_obs_full"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(env.priv_buf, fx["init_priv_full"], rtol=0, atol=1e-6)
     assert list(fx["reward_names"]) == REWARD_ORDER          # alphabetical dir() order (helpers.py:47)
@@ -43,6 +55,21 @@ def test_oracle_env_reproduces_reference(name, steps):
             np.testing.assert_allclose(priv, fx["full_priv"][full[t + 1]], rtol=0, atol=1e-4)
     if name == "env_rollout_b":
         assert fx["timeout"].sum() == 3 and fx["reset"].sum() >= 3          # the fixture does exercise time-outs
+
+
+def test_terrain_fixture_places_robots_on_the_reference_tiles():
+    """Fixture C (mesh_type='trimesh'): env origins come from the tile map by (level, type) with
+    type = floor(i / (N / num_cols)) -- legged_robot.py:687-697 -- and robots stand on non-flat tiles."""
+    fx = np.load(os.path.join(GOLD, "env_rollout_c.npz"))
+    n = int(fx["meta"][0])
+    types = np.floor(np.arange(n) / (n / fx["terrain_origins"].shape[1])).astype(int)
+    assert np.array_equal(fx["terrain_types"], types)
+    assert np.array_equal(fx["init_env_origins"], fx["terrain_origins"][fx["terrain_levels"], types])
+    assert fx["init_env_origins"][:, 2].max() > 1.0                  # pyramid tops
+    assert np.abs(fx["init_start_pos"][:, :2] - fx["init_env_origins"][:, :2]).max() <= 1.0
+    assert fx["reset"].sum() >= 4 and fx["timeout"].sum() >= 2
+    assert np.abs(fx["packs"][1:, 29:31]).sum() > 0                  # reset xy offsets were drawn
+    assert float(fx["terrain_level_stat"]) == pytest.approx(fx["terrain_levels"].mean())
 
 
 def test_fixture_exercises_events():
