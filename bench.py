@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x3
 GEMM_KERNELS = ["fwd_128x128", "fwd_64x128", "dgrad_128x128", "dgrad_64x128", "wgrad_128x128_splitk"]
 
 
-def cpu_baseline(sample_envs=4096, sample_steps=6):
+def cpu_baseline(sample_envs=4096, sample_steps=6, terrain="trimesh"):
     """The numpy oracle (oracle/env.py + oracle/physics.py + oracle/ppo.py: the CPU restatement, kind="port")
     timed on this box's host cores for a bounded sample of the same iteration: `sample_steps` rollout steps of
     `sample_envs` robots (policy forward, env step with 10 substeps, store), GAE and the 2x4-minibatch update."""
@@ -40,7 +40,19 @@ def cpu_baseline(sample_envs=4096, sample_steps=6):
     rng = np.random.default_rng(0)
     n, T = sample_envs, sample_steps
     pack = lambda: np.concatenate([rng.uniform(size=(34, n)), rng.standard_normal((41, n))]).astype(np.float32)
-    env = HectorEnvOracle(n, rng.uniform(0.1, 1.0, n), 8.15528 + rng.uniform(-2, 4, n), np.zeros((n, 3)), pack())
+    hf, origins = None, np.zeros((n, 3))
+    if terrain != "plane":                # the same 20 x 20 tile map layout as the product's default config (untimed set-up)
+        import types
+        from oracle.terrain import HeightField, HumanoidTerrainOracle
+        tc = types.SimpleNamespace(mesh_type=terrain, horizontal_scale=0.1, vertical_scale=0.005, border_size=25, curriculum=False,
+                                   selected=False, terrain_length=8.0, terrain_width=8.0, num_rows=20, num_cols=20,
+                                   terrain_proportions=[0.1, 0.1, 0.2, 0.1, 0.1, 0.2, 0.2])
+        np.random.seed(5)
+        ter = HumanoidTerrainOracle(tc, n)
+        hf = HeightField(ter.heightsamples, 0.1, 0.005, 25)
+        origins = ter.env_origins[rng.integers(0, 20, n), np.floor(np.arange(n) / (n / 20)).astype(int)]
+    env = HectorEnvOracle(n, rng.uniform(0.1, 1.0, n), 8.15528 + rng.uniform(-2, 4, n), origins, pack(),
+                          start_xy=origins, terrain=hf, custom_origins=hf is not None)
     alg = PPOOracle(ActorCriticOracle.default_init(rng), n, T)
     t0 = time.perf_counter()
     obs, priv = env.obs_buf, env.priv_buf
@@ -57,7 +69,7 @@ def cpu_baseline(sample_envs=4096, sample_steps=6):
     except Exception:
         threads = os.cpu_count()
     return {"value": n * T / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{T} rollout steps x {n} envs + GAE + full 2x4-minibatch update, numpy float32/64 oracle, "
+            "sample": f"{T} rollout steps x {n} envs (terrain {terrain}) + GAE + full 2x4-minibatch update, numpy float32/64 oracle, "
                       f"{dt:.1f} s wall; host has {os.cpu_count()} logical cores"}
 
 
@@ -68,6 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--shards", type=int, default=1, help="env shards per GPU driven round-robin on separate streams (1 = off; measured slower than the deferred-critic overlap, see DESIGN.md)")
+    ap.add_argument("--terrain", default="trimesh", choices=["trimesh", "heightfield", "plane"],
+                    help="terrain.mesh_type; 'trimesh' is the reference's default for the hector task (hector_config.py:45)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -94,6 +108,7 @@ def main():
 
     env_cfg, train_cfg = HectorCfg(), HectorCfgPPO()
     env_cfg.env.num_envs = args.envs
+    env_cfg.terrain.mesh_type = args.terrain
     env_cfg.seed = set_seed(train_cfg.seed + comm.rank)
     if args.shards > 1:
         env = PipelinedHectorEnv(env_cfg, sim_device=f"cuda:{local}", headless=True, num_shards=args.shards)
@@ -124,7 +139,7 @@ def main():
                "config": {"workload": f"hector {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
                                       "update 2 epochs x 4 minibatches, fp32 HIP sim + MLP actor [512,256,128] / critic [768,256,128]",
                           "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
-                          "terrain": "plane", "env_shards": args.shards, "collection_s": runner.last_perf.get("collection_time"),
+                          "terrain": args.terrain, "env_shards": args.shards, "collection_s": runner.last_perf.get("collection_time"),
                           "learn_s": runner.last_perf.get("learn_time")}}
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])
@@ -137,7 +152,7 @@ def main():
                                "whole_iteration_mfma_frac": value / world * FLOP_PER_ENV_STEP / (PEAK_F32_MFMA_TFLOPS * 1e12)}
         if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(terrain=args.terrain)
             except Exception as e:                        # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e!r}"}

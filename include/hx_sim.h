@@ -140,6 +140,15 @@ int hx_version(void);
 int hx_sim_create(const hx_sim_cfg* cfg, const float* shape_friction_h, const float* base_mass_h,
                   const float* env_origins_h /*[N][3]*/, const float* start_pos_h /*[N][3]*/,
                   uint64_t seed, void* hip_stream /*NULL: library creates one*/, hx_sim** out);
+/* Rough terrain -- replaces gym.add_heightfield / gym.add_triangle_mesh (reference legged_robot.py:553-585, called
+ * from hector_env.py:120-127) for the grid a `HumanoidTerrain` lays out (humanoid/utils/terrain.py:189-234).
+ * heights_h: host int16 [rows][cols] row-major in units of vertical_scale (Terrain.heightsamples); node (i, j) lies
+ * at world (x0 + i*horizontal_scale, y0 + j*horizontal_scale) -- the reference passes x0 = y0 = -border_size.
+ * Collision surface: two triangles per cell split along (i,j)-(i+1,j+1), as convert_heightfield_to_trimesh emits
+ * them (no slope-threshold vertex shift); outside the grid the border continues.  Call before hx_sim_reset_all;
+ * heights_h == NULL returns to the ground plane z = 0 (gym.add_ground, legged_robot.py:541-551). */
+int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t rows, int32_t cols, float horizontal_scale,
+                       float vertical_scale, float x0, float y0);
 void hx_sim_destroy(hx_sim* s);
 int hx_sim_reset_all(hx_sim* s, const float* pack /*nullable*/);
 int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const float* pack /*nullable*/);

@@ -103,8 +103,15 @@ template <typename F, int... Is> HXD void static_for_impl(F&& f, std::integer_se
 }
 template <int N, typename F> HXD void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// Terrain: each robot keeps a HX_PATCH x HX_PATCH window of the height grid (metres, fp32) in LDS, centred on its
+// base at the start of the env step; `patch == nullptr` selects the ground plane z = 0.
+#define HX_PATCH 16
 struct DynParams {
   float dt, gz, kn, dn, veps, lim_k, lim_d, mu;
+  const float* patch;     // LDS, [HX_PATCH][HX_PATCH] row-major (row = x index), or nullptr
+  float px0, py0;         // world x / y of patch node (0, 0)
+  float inv_hs;           // 1 / horizontal_scale
+  float zmax;             // highest node of the patch: points above it cannot touch
 };
 
 #define HX_LEG_NJ 5
@@ -162,17 +169,46 @@ HXD SI base_inertia(float s) {
   return r;
 }
 
+// Height and unit normal of the terrain triangle under world (x, y): every grid cell is split along its
+// (i,j)-(i+1,j+1) diagonal (the split of convert_heightfield_to_trimesh); oracle/terrain.py HeightField.query.
+HXD float terrain_query(const DynParams& P, float x, float y, V3& nw) {
+  const float u = (x - P.px0) * P.inv_hs, w = (y - P.py0) * P.inv_hs;
+  const int i = min(max((int)floorf(u), 0), HX_PATCH - 2), j = min(max((int)floorf(w), 0), HX_PATCH - 2);
+  const float fu = fminf(fmaxf(u - (float)i, 0.f), 1.f), fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
+  const float* c = P.patch + i * HX_PATCH + j;
+  const float h00 = c[0], h01 = c[1], h10 = c[HX_PATCH], h11 = c[HX_PATCH + 1];
+  const bool upper = fw > fu;
+  const float gu = upper ? h11 - h01 : h10 - h00;
+  const float gw = upper ? h01 - h00 : h11 - h10;
+  const float nx = -gu * P.inv_hs, ny = -gw * P.inv_hs;
+  const float inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.0f);
+  nw = mk(nx * inv, ny * inv, inv);
+  return h00 + fu * gu + fw * gw;
+}
+
 // Accumulate the contact terms of `npts` corner points (LDS, xyz triples) on a body with spatial velocity v
-// (body coords), world z-axis in body coords nb, world height of the body origin pz.
+// (body coords), body->world rotation Rb and world position pb of the body origin.
 // a_true == nullptr: f0 += explicit spatial force, B += implicit 6x6.
 // a_true != nullptr: returns the implicit-consistent net force (body coords)  sum_c [f0_c - K_c Xc a].
-HXD V3 contact_points(const DynParams& P, const float* pts, int npts, SV v, V3 nb, float pz, SV& f0, SI& B, const SV* a_true) {
+// Plane: normal = world z, penetration = -z.  Terrain: normal of the triangle under the point, penetration =
+// distance to that triangle's plane.
+HXD V3 contact_points(const DynParams& P, const float* pts, int npts, SV v, const M3& Rb, V3 pb, SV& f0, SI& B, const SV* a_true) {
   const float c_n = P.dn + P.kn * P.dt;
   V3 net = mk(0.f, 0.f, 0.f);
+  const V3 zb = row(Rb, 2);          // world z in body coords
 #pragma unroll 1
   for (int k = 0; k < npts; ++k) {
     const V3 r = mk(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
-    const float pen = -(pz + dot(nb, r));
+    const float z = pb.z + dot(zb, r);
+    V3 nb = zb;
+    float pen = -z;
+    if (P.patch != nullptr) {
+      if (!__any(z < P.zmax)) continue;
+      V3 nw;
+      const float h = terrain_query(P, pb.x + dot(row(Rb, 0), r), pb.y + dot(row(Rb, 1), r), nw);
+      pen = (h - z) * nw.z;
+      nb = mulT(Rb, nw);
+    }
     const V3 vp = v.v + cross(v.w, r);
     const float vn = dot(vp, nb);
     const float fn0 = P.kn * pen - c_n * vn;
@@ -263,12 +299,11 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
                      const float* kd, const float* tau_lim, float mass_scale, float* tau_out, bool want_forces, LegForces& F) {
   SV v[HX_LEG_NJ + 1];       // index 0 = base, 1..5 = leg bodies
   float cs_c[HX_LEG_NJ + 1], cs_s[HX_LEG_NJ + 1];
-  V3 nb_base, nb_thigh, nb_toe;
-  float pz_base, pz_thigh = 0.f, pz_toe = 0.f;
+  M3 R_thigh, R_toe;           // body -> world of the two leg bodies that carry collision shapes
+  V3 p_thigh, p_toe;
   const M3 R0 = quat_to_mat(S.quat);
   // ---- pass 1: kinematics down the leg
-  nb_base = row(R0, 2);
-  pz_base = S.pos.z;
+  const V3 nb_base = row(R0, 2);
   v[0].w = mulT(R0, S.angvel);
   v[0].v = mulT(R0, S.linvel);
   {
@@ -288,8 +323,8 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
       if (K == 2) v[L + 1].w.z += S.qd[L];
       pc = pc + mul(Rc, r);
       for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
-      if (L == 2) { nb_thigh = row(Rc, 2); pz_thigh = pc.z; }
-      if (L == 4) { nb_toe = row(Rc, 2); pz_toe = pc.z; }
+      if (L == 2) { R_thigh = Rc; p_thigh = pc; }
+      if (L == 4) { R_toe = Rc; p_toe = pc; }
     });
   }
 
@@ -309,13 +344,12 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
       pA = pA + accP;
     }
     if (L == 2 || L == 4) {
-      const V3 nb = (L == 2) ? nb_thigh : nb_toe;
-      const float pz = (L == 2) ? pz_thigh : pz_toe;
+      const M3& Rb = (L == 2) ? R_thigh : R_toe;
       SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
       SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-      contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], nb, pz, f0, B, nullptr);
+      contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], Rb, (L == 2) ? p_thigh : p_toe, f0, B, nullptr);
       IA.A = IA.A + B.A; IA.H = IA.H + B.H; IA.M = IA.M + B.M;
-      SV g; g.w = mk(0, 0, 0); g.v = P.gz * nb;
+      SV g; g.w = mk(0, 0, 0); g.v = P.gz * row(Rb, 2);
       pA = pA - f0 + mulSI(B, g);
     }
     // joint-space terms: PD torque (reference legged_robot.py:339-355) + soft limits, linearly implicit
@@ -368,7 +402,7 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
   {
     SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
     SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-    contact_points(P, C.basept + 12 * leg, 4, v[0], nb_base, pz_base, f0, B, nullptr);
+    contact_points(P, C.basept + 12 * leg, 4, v[0], R0, S.pos, f0, B, nullptr);
     accI.A = accI.A + B.A; accI.H = accI.H + B.H; accI.M = accI.M + B.M;
     accP = accP - f0 + mulSI(B, g0);
   }
@@ -423,21 +457,15 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
     SV dmy; SI dmyB;
     {
       SV at = a[0]; at.v = at.v + g0.v;
-      const V3 part = contact_points(P, C.basept + 12 * leg, 4, v[0], nb_base, pz_base, dmy, dmyB, &at);
+      const V3 part = contact_points(P, C.basept + 12 * leg, 4, v[0], R0, S.pos, dmy, dmyB, &at);
       F.base = mul(R0, part + xchg(part));
     }
-    M3 Rc = R0;
-    static_for<HX_LEG_NJ>([&](auto ic) {
-      constexpr int L = decltype(ic)::value;
-      constexpr int K = LegAxis<L>::value;
-      for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(cs_c[L + 1], cs_s[L + 1], row(Rc, i)));
-      if (L == 2 || L == 4) {
-        const V3 nb = (L == 2) ? nb_thigh : nb_toe;
-        SV at = a[L + 1]; at.v = at.v + P.gz * nb;     // true spatial acceleration
-        const V3 net = contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], nb, (L == 2) ? pz_thigh : pz_toe, dmy, dmyB, &at);
-        if (L == 2) F.thigh = mul(Rc, net); else F.toe = mul(Rc, net);
-      }
-    });
+    {
+      SV at = a[3]; at.v = at.v + P.gz * row(R_thigh, 2);     // true spatial acceleration
+      F.thigh = mul(R_thigh, contact_points(P, C.thigh_pts(), 8, v[3], R_thigh, p_thigh, dmy, dmyB, &at));
+      at = a[5]; at.v = at.v + P.gz * row(R_toe, 2);
+      F.toe = mul(R_toe, contact_points(P, C.toe_pts(), 8, v[5], R_toe, p_toe, dmy, dmyB, &at));
+    }
   }
   // ---- integrate (semi-implicit Euler); the base update is identical on both lanes
   {

@@ -42,6 +42,11 @@ struct SimPtrs {
   int* num_reset;     // [1]
   float* stat_sum;    // [HX_NUM_REWARDS + 2] sums over envs that reset: per-term episode sums, episode return, episode length
   int* stat_cnt;      // [1]
+  // terrain height grid (metres), row-major [t_rows][t_cols], node (i, j) at world (t_x0 + i hs, t_y0 + j hs);
+  // nullptr = ground plane
+  const float* terrain;
+  int t_rows, t_cols;
+  float t_inv_hs, t_hs, t_x0, t_y0;
 };
 
 // ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
@@ -121,12 +126,36 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
                                                          const float* __restrict__ pack, StepArgs A) {
   // lane pair (2e, 2e+1) = (left leg, right leg) of robot e; 32 robots per 64-lane workgroup
   __shared__ float lds_const[HX_LDS_CONST_FLOATS];
+  __shared__ float lds_patch[32 * HX_PATCH * HX_PATCH];
+  __shared__ int lds_patch_org[32][2];
   dyn_stage_constants(lds_const, threadIdx.x, 64);
-  __syncthreads();
   const hx_sim_cfg& cfg = *cfgp;
   const int n = cfg.num_envs;
   const int e = (blockIdx.x * 64 + threadIdx.x) >> 1;
   const int leg = threadIdx.x & 1;
+  const bool use_terrain = (p.terrain != nullptr) && (A.mode == 0);
+  if (use_terrain) {
+    // window of the height grid around each robot's base, fetched cooperatively: one wave instruction covers
+    // four 64-byte rows of one robot's window
+    if (leg == 0) {
+      const int ec = min(e, n - 1);
+      const float bx = p.st[(size_t)S_ROOT_POS * n + ec], by = p.st[(size_t)(S_ROOT_POS + 1) * n + ec];
+      const int ci = (int)floorf((bx - p.t_x0) * p.t_inv_hs + 0.5f) - HX_PATCH / 2;
+      const int cj = (int)floorf((by - p.t_y0) * p.t_inv_hs + 0.5f) - HX_PATCH / 2;
+      lds_patch_org[threadIdx.x >> 1][0] = min(max(ci, 0), p.t_rows - HX_PATCH);
+      lds_patch_org[threadIdx.x >> 1][1] = min(max(cj, 0), p.t_cols - HX_PATCH);
+    }
+    __syncthreads();
+    for (int r = 0; r < 32; ++r) {
+      const int oi = lds_patch_org[r][0], oj = lds_patch_org[r][1];
+#pragma unroll
+      for (int k = 0; k < HX_PATCH * HX_PATCH / 64; ++k) {
+        const int idx = k * 64 + threadIdx.x;
+        lds_patch[r * HX_PATCH * HX_PATCH + idx] = p.terrain[(size_t)(oi + idx / HX_PATCH) * p.t_cols + (oj + idx % HX_PATCH)];
+      }
+    }
+  }
+  __syncthreads();
   if (e >= n) return;                      // both lanes of a pair leave together
   const bool writer = (leg == 0);          // env-level results are computed by both lanes, stored by one
   LegConst C; C.t = lds_const + leg * HX_LEGC_STRIDE; C.basept = lds_const + 2 * HX_LEGC_STRIDE;
@@ -166,6 +195,17 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     DynParams P;
     P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
     P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
+    P.patch = nullptr; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.zmax = 0.f;
+    if (use_terrain) {
+      const int r = threadIdx.x >> 1;
+      P.patch = lds_patch + r * HX_PATCH * HX_PATCH;
+      P.px0 = p.t_x0 + (float)lds_patch_org[r][0] * p.t_hs;
+      P.py0 = p.t_y0 + (float)lds_patch_org[r][1] * p.t_hs;
+      P.inv_hs = p.t_inv_hs;
+      float zm = -3.0e38f;
+      for (int k = 0; k < HX_PATCH * HX_PATCH / 2; ++k) zm = fmaxf(zm, P.patch[leg * (HX_PATCH * HX_PATCH / 2) + k]);
+      P.zmax = fmaxf(zm, xchg(zm));
+    }
     float target[5], kpl[5], kdl[5], tll[5];
     for (int j = 0; j < 5; ++j) {
       const float aj = leg ? act[5 + j] : act[j];
@@ -694,6 +734,23 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
   if (dalloc(s, &s->cfg_d, 1)) return -3;
   HX_CHECK(hipMemcpy(s->cfg_d, &s->cfg, sizeof(hx_sim_cfg), hipMemcpyHostToDevice));
   *out = s;
+  return 0;
+}
+
+extern "C" int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t rows, int32_t cols, float horizontal_scale,
+                                  float vertical_scale, float x0, float y0) {
+  if (!s) { hx_set_error("hx_sim_set_terrain: null sim"); return -2; }
+  if (!heights_h) { s->p.terrain = nullptr; return 0; }
+  if (rows < HX_PATCH || cols < HX_PATCH || !(horizontal_scale > 0.f)) { hx_set_error("hx_sim_set_terrain: grid smaller than the contact window or bad scale"); return -2; }
+  // metres in fp32, rounded from the double product exactly like the float32 mesh vertices of the reference
+  std::vector<float> h((size_t)rows * cols);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((double)heights_h[i] * (double)vertical_scale);
+  float* d = nullptr;
+  HX_CHECK(hipMalloc((void**)&d, h.size() * sizeof(float)));
+  s->allocs.push_back(d);
+  HX_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  s->p.terrain = d; s->p.t_rows = rows; s->p.t_cols = cols;
+  s->p.t_hs = horizontal_scale; s->p.t_inv_hs = 1.0f / horizontal_scale; s->p.t_x0 = x0; s->p.t_y0 = y0;
   return 0;
 }
 

@@ -8,9 +8,8 @@ that do `env_cfg.env.num_envs = ...` or subclass `HectorCfg` keep working:
 tests/test_configs.py checks every leaf value against the reference's `class_to_dict` output captured in
 tests/golden/configs.json.
 
-One deliberate difference: `terrain.mesh_type` for hector defaults to 'plane' here.  The reference's
-default 'trimesh' needs the procedural heightfield terrain, which SURVEY.md 8(f)-1 schedules as the next
-row; the reference itself supports 'plane' (hector_env.py:123-124).  Asking for another mesh type raises.
+No deliberate differences: hector's default `terrain.mesh_type` is the reference's 'trimesh' (procedural tile map,
+isaac_amd/envs/terrain.py); 'heightfield' and 'plane' are accepted as in the reference (hector_env.py:120-131).
 """
 import inspect
 
@@ -256,7 +255,7 @@ class HectorCfg(LeggedRobotCfg):
         fix_base_link = False
 
     class terrain(LeggedRobotCfg.terrain):
-        mesh_type = 'plane'          # reference default: 'trimesh' (see module docstring)
+        mesh_type = 'trimesh'
         curriculum = False
         measure_heights = False
         static_friction = 0.6

@@ -92,11 +92,15 @@ class HectorFreeEnv(VecEnv):
         self.obs_scales = cfg.normalization.obs_scales
         self.reward_scales = class_to_dict(cfg.rewards.scales)
         self.command_ranges = class_to_dict(cfg.commands.ranges)
-        if cfg.terrain.mesh_type not in ("plane", None, "none"):
-            raise NotImplementedError(
-                f"terrain.mesh_type={cfg.terrain.mesh_type!r}: only 'plane' is built in this round "
-                "(heightfield/trimesh terrain is the next row of SURVEY.md 8f)")
-        cfg.terrain.curriculum = False
+        mesh_type = cfg.terrain.mesh_type
+        if mesh_type not in ("plane", "heightfield", "trimesh"):
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
+        rough = mesh_type in ("heightfield", "trimesh")
+        if not rough:
+            cfg.terrain.curriculum = False
+        elif cfg.terrain.curriculum:
+            raise NotImplementedError("terrain.curriculum=True (legged_robot.py:399-419) is not built; the hector task "
+                                      "trains with curriculum=False (hector_config.py:47)")
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = math.ceil(self.max_episode_length_s / self.dt)
         cfg.domain_rand.push_interval = math.ceil(cfg.domain_rand.push_interval_s / self.dt)
@@ -120,15 +124,28 @@ class HectorFreeEnv(VecEnv):
         assert self.feet_indices == [5, 10] and self.knee_indices == [4, 9]
         assert sorted(self.termination_contact_indices) == [0, 3, 8] == sorted(self.penalised_contact_indices)
 
-        # ---- env origins: grid (legged_robot.py:698-708)
+        # ---- create_sim (hector_env.py:114-133): terrain first, then the robots
         n = self.total_envs
-        self.env_origins = self._grid_origins(cfg, n)
-        self.custom_origins = False
-        if creation is not None:          # tests: replay a recorded creation (friction, base mass, origins, start pose)
+        self.custom_origins = rough
+        self.terrain = None
+        terrain_grid = None
+        if creation is not None:          # tests / shards: replay a recorded creation (friction, base mass, origins, start pose, terrain)
             friction, mass, start = (np.asarray(creation[k], np.float32) for k in ("friction", "mass", "start"))
             self.env_origins = np.asarray(creation["origins"], np.float32)
+            if rough:
+                terrain_grid = creation["terrain"]      # dict(heights int16 [R][C], horizontal_scale, vertical_scale, border_size)
+                self.terrain_levels, self.terrain_types = creation.get("terrain_levels"), creation.get("terrain_types")
         else:
+            if rough:
+                from .terrain import HumanoidTerrain
+                self.terrain = HumanoidTerrain(cfg.terrain, n)
+                terrain_grid = dict(heights=self.terrain.heightsamples, horizontal_scale=cfg.terrain.horizontal_scale,
+                                    vertical_scale=cfg.terrain.vertical_scale, border_size=cfg.terrain.border_size)
+                self.env_origins = self._terrain_origins(cfg, n, self.terrain)
+            else:
+                self.env_origins = self._grid_origins(cfg, n)
             friction, mass, start = creation_randomisation(cfg, n, self.env_origins)
+        self._terrain_grid = terrain_grid
         if env_range is not None:
             sl = slice(self.env_lo, self.env_hi)
             friction, mass, start, self.env_origins = friction[sl], mass[sl], start[sl], self.env_origins[sl]
@@ -185,7 +202,7 @@ class HectorFreeEnv(VecEnv):
         base_init = cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel
         for k in range(13):
             c.base_init_state[k] = base_init[k]
-        c.custom_origins = 0
+        c.custom_origins = int(rough)
         # _prepare_reward_function (legged_robot.py:517-540): drop zero scales, multiply by dt
         unknown = [k for k, v in self.reward_scales.items() if v != 0 and k not in capi.REWARD_NAMES and k != "termination"]
         if unknown:
@@ -212,12 +229,35 @@ class HectorFreeEnv(VecEnv):
                                    seed | (0x5EED << 32), stream, capi.C.byref(h)), "hx_sim_create")
         self._h = h
         self._L = L
+        if rough:                         # _create_heightfield / _create_trimesh (legged_robot.py:553-585)
+            hts = np.ascontiguousarray(terrain_grid["heights"], np.int16)
+            self.height_samples = hts
+            capi.check(L.hx_sim_set_terrain(h, hts.ctypes.data, hts.shape[0], hts.shape[1],
+                                            float(terrain_grid["horizontal_scale"]), float(terrain_grid["vertical_scale"]),
+                                            -float(terrain_grid["border_size"]), -float(terrain_grid["border_size"])),
+                       "hx_sim_set_terrain")
         self.stream = L.hx_sim_stream(h)
         self.common_step_counter = 0
         self.extras = {}
         self._keep = []
         # constructor tail: reset_idx(all) + compute_observations (hector_env.py:50-51)
         self._reset_all(init_pack)
+
+    def _terrain_origins(self, cfg, n, terrain):
+        """legged_robot.py:687-697: a random level per robot, tile type by robot index."""
+        max_init_level = cfg.terrain.max_init_terrain_level
+        if not cfg.terrain.curriculum:
+            max_init_level = cfg.terrain.num_rows - 1
+        try:
+            import torch
+            levels = torch.randint(0, max_init_level + 1, (n,)).numpy()
+        except ImportError:                                   # pragma: no cover
+            levels = np.random.randint(0, max_init_level + 1, n)
+        self.terrain_levels = levels.astype(np.int64)
+        self.terrain_types = np.floor(np.arange(n) / (n / cfg.terrain.num_cols)).astype(np.int64)
+        self.max_terrain_level = cfg.terrain.num_rows
+        self.terrain_origins = terrain.env_origins.astype(np.float32)
+        return self.terrain_origins[self.terrain_levels, self.terrain_types].copy()
 
     @staticmethod
     def _grid_origins(cfg, n):
@@ -333,6 +373,8 @@ class HectorFreeEnv(VecEnv):
         cnt = capi.C.c_int32(0)
         capi.check(self._L.hx_sim_episode_stats(self._h, capi.ptr(mean), capi.C.byref(cnt)), "episode_stats")
         info = {"rew_" + k: float(mean[capi.REWARD_NAMES.index(k)]) for k in self.reward_names}
+        if self.cfg.terrain.mesh_type == "trimesh" and getattr(self, "terrain_levels", None) is not None:
+            info["terrain_level"] = float(np.mean(self.terrain_levels))           # legged_robot.py:203-204
         self.last_episode_return, self.last_episode_length = float(mean[capi.NUM_REWARDS]), float(mean[capi.NUM_REWARDS + 1])
         return info, cnt.value
 
@@ -365,9 +407,19 @@ class PipelinedHectorEnv(VecEnv):
         assert n % num_shards == 0
         per = n // num_shards
         # draw the creation-time randomisation ONCE for the whole batch, in the reference's order
-        probe_origins = HectorFreeEnv._grid_origins(cfg, n)
+        creation = {}
+        if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            from .terrain import HumanoidTerrain
+            self.terrain = HumanoidTerrain(cfg.terrain, n)
+            creation["terrain"] = dict(heights=self.terrain.heightsamples, horizontal_scale=cfg.terrain.horizontal_scale,
+                                       vertical_scale=cfg.terrain.vertical_scale, border_size=cfg.terrain.border_size)
+            probe = HectorFreeEnv.__new__(HectorFreeEnv)
+            probe_origins = probe._terrain_origins(cfg, n, self.terrain)
+            creation["terrain_levels"], creation["terrain_types"] = probe.terrain_levels, probe.terrain_types
+        else:
+            probe_origins = HectorFreeEnv._grid_origins(cfg, n)
         friction, mass, start = creation_randomisation(cfg, n, probe_origins)
-        creation = dict(friction=friction, mass=mass, start=start, origins=probe_origins)
+        creation.update(friction=friction, mass=mass, start=start, origins=probe_origins)
         self.shards = [HectorFreeEnv(cfg, sim_params, physics_engine, sim_device, headless, creation=creation,
                                      env_range=(i * per, (i + 1) * per)) for i in range(num_shards)]
         s0 = self.shards[0]

@@ -26,8 +26,7 @@ def test_hector_cfg_matches_reference():
     ref = json.load(open(GOLD))
     mine = json.loads(json.dumps(class_to_dict(HectorCfg())))
     d = _diff(mine, ref["HectorCfg"])
-    # the one documented deviation: plane terrain until the heightfield row is built (configs.py docstring)
-    assert d == ["/terrain/mesh_type: 'plane' != 'trimesh'"], d
+    assert d == [], d
 
 
 def test_hector_cfg_ppo_matches_reference():

@@ -27,13 +27,19 @@ def make_env(fx):
     cfg.env.num_envs = n
     cfg.noise.add_noise = bool(noise)
     cfg.seed = seed
+    cfg.terrain.mesh_type = "plane"
     creation = dict(friction=fx["init_shape_friction"], mass=fx["init_base_mass"], origins=fx["init_env_origins"],
                     start=fx["init_start_pos"])
+    if "terrain_heights" in fx:           # fixture C: the tile map the reference's HumanoidTerrain laid out
+        hs, vs, border = (float(x) for x in fx["terrain_params"])
+        cfg.terrain.mesh_type = "trimesh"
+        creation["terrain"] = dict(heights=fx["terrain_heights"], horizontal_scale=hs, vertical_scale=vs, border_size=border)
+        creation["terrain_levels"], creation["terrain_types"] = fx["terrain_levels"], fx["terrain_types"]
     env = HectorFreeEnv(cfg, sim_device="cuda:0", creation=creation, init_pack=fx["packs"][0])
     return env, n, steps, sc0
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c"])
 def test_constructor_reset_and_first_observation(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -45,7 +51,7 @@ def test_constructor_reset_and_first_observation(hxlib, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c"])
 def test_teacher_forced_steps(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -121,6 +127,7 @@ def test_pipelined_shards_equal_single_env(hxlib):
         cfg = HectorCfg()
         cfg.env.num_envs = n
         cfg.seed = set_seed(11)
+        cfg.terrain.mesh_type = "plane"
         env = PipelinedHectorEnv(cfg, num_shards=2) if sharded else HectorFreeEnv(cfg)
         rec = []
         for t in range(6):
@@ -137,3 +144,93 @@ def test_pipelined_shards_equal_single_env(hxlib):
         np.testing.assert_array_equal(o0, o1)
         np.testing.assert_array_equal(r0, r1)
         np.testing.assert_array_equal(d0, d1)
+
+
+# ---------------------------------------------------------------------------------------------- rough terrain
+def _rough_setup(n, seed):
+    """n robots scattered over a small HumanoidTerrain map (all tile kinds), HIP env + oracle env on the same data."""
+    from isaac_amd.envs.terrain import HumanoidTerrain
+    from oracle.env import HectorEnvOracle
+    from oracle.terrain import HeightField
+
+    class T(HectorCfg.terrain):
+        mesh_type, num_rows, num_cols, curriculum, border_size = "trimesh", 3, 10, True, 2.0
+    np.random.seed(seed)
+    ter = HumanoidTerrain(T, n)                 # curriculum layout: every tile kind, three difficulties
+    rng = np.random.default_rng(seed)
+    hf = HeightField(ter.heightsamples, 0.1, 0.005, 2.0)
+    origins = np.zeros((n, 3), np.float32)
+    origins[:, 0] = rng.uniform(1.0, 23.0, n)
+    origins[:, 1] = rng.uniform(1.0, 79.0, n)
+    origins[:, 2] = hf.query(origins[:, 0], origins[:, 1])[0] - 0.05        # start with the feet slightly in the ground
+    fr, ms = rng.uniform(0.3, 1.0, n).astype(np.float32), (8.15528 + rng.uniform(-2, 4, n)).astype(np.float32)
+    pack = lambda: np.concatenate([rng.uniform(size=(34, n)), rng.standard_normal((41, n))]).astype(np.float32)
+    p0 = pack()
+    p0[29:31] = 0.5                             # reset xy offset 0: stand exactly on the chosen spot
+    cfg = HectorCfg()
+    cfg.env.num_envs = n
+    cfg.terrain.mesh_type = "trimesh"
+    grid = dict(heights=ter.heightsamples, horizontal_scale=0.1, vertical_scale=0.005, border_size=2.0)
+    env = HectorFreeEnv(cfg, sim_device="cuda:0", init_pack=p0,
+                        creation=dict(friction=fr, mass=ms, origins=origins, start=origins.copy(), terrain=grid))
+    orc = HectorEnvOracle(n, fr, ms, origins, p0, start_xy=origins.copy(), terrain=hf, custom_origins=True)
+    return env, orc, rng, pack, hf
+
+
+def test_terrain_contact_matches_oracle(hxlib):
+    """Robots standing / stepping on slopes, blocks, rough ground and stairs: every env step teacher-forced from the
+    oracle's state must agree with it (same criteria as the plane fixtures), and feet must actually load the terrain."""
+    n = 64
+    env, orc, rng, pack, hf = _rough_setup(n, 4)
+    np.testing.assert_allclose(env.obs_buf.numpy(), orc.obs_buf, atol=1e-5)
+    obs_err, rew_err, loaded, tilted = [], [], 0, 0
+    for t in range(25):
+        if t > 0:
+            s = orc.state
+            root = np.concatenate([s.root_pos, s.root_quat, s.root_linvel, s.root_angvel], 1).astype(np.float32)
+            env.set_state(root, s.q.astype(np.float32), s.qd.astype(np.float32))
+        a, pk = (0.3 * rng.standard_normal((n, 10))).astype(np.float32), pack()
+        obs, priv, rew, done, _ = env.step(a, pack=pk)
+        o2, p2, r2, d2 = orc.step(a, pk)
+        alive = ~(d2 | done.numpy().astype(bool))
+        assert np.array_equal(done.numpy().astype(bool), d2), f"reset flags differ at step {t}"
+        obs_err.append(float(np.abs(obs.numpy()[alive][:, -41:] - o2[alive][:, -41:]).max()))
+        rew_err.append(float(np.abs(rew.numpy() - r2).max()))
+        cf = orc.phys.contact_force[:, [5, 10]]
+        loaded += int((cf[..., 2] > 20.0).sum())
+        tilted += int((np.abs(cf[..., :2]).max(-1) > 0.3 * np.abs(cf[..., 2]) + 1.0).sum())
+        np.testing.assert_allclose(env.contact_forces[alive][:, [5, 10]], cf[alive], rtol=0, atol=25.0)
+    print("terrain teacher-forced obs err: median %.2e p90 %.2e max %.2e ; rew %.2e ; loaded feet %d, on inclines %d"
+          % (np.median(obs_err), np.quantile(obs_err, 0.9), max(obs_err), max(rew_err), loaded, tilted))
+    # max over 64 robots that start 5 cm inside the ground (violent first steps): fp32-vs-float64 round-off level
+    assert np.median(obs_err) < 3e-4 and np.quantile(obs_err, 0.9) < 2e-3 and max(obs_err) < 2e-2
+    assert max(rew_err) < 2e-4
+    assert loaded > 500 and tilted > 20
+    env.close()
+
+
+def test_loaded_feet_rest_on_the_surface(hxlib):
+    """Property check without the oracle's dynamics: while robots stand and sway on the tiles (zero actions, 0.4 s),
+    every foot that carries load sits ON the height field under it -- toe origin 4 cm above its sole, so the gap to
+    the surface is a few centimetres (more only where a sole bridges a stair edge) and never clearly negative."""
+    n = 256
+    env, orc, rng, pack, hf = _rough_setup(n, 9)
+    zero = np.zeros((n, 10), np.float32)
+    ever_reset = np.zeros(n, bool)
+    gaps = []
+    for t in range(40):
+        _, _, _, done, _ = env.step(zero)
+        ever_reset |= done.numpy().astype(bool)
+        if t < 10:
+            continue                                                    # let the initial 5 cm penetration resolve
+        bodies = env._buf(capi.BUF_BODY_STATE, (4, 13, n)).numpy()          # L_calf, L_toe, R_calf, R_toe
+        cf = env.contact_forces
+        for k, body in ((1, 5), (3, 10)):
+            sel = (~ever_reset) & (cf[:, body, 2] > 20.0)
+            gaps.append(bodies[k, 2, sel] - hf.query(bodies[k, 0, sel], bodies[k, 1, sel])[0])
+    gaps = np.concatenate(gaps)
+    print("loaded-foot gap to the surface: n=%d min %.3f median %.3f p95 %.3f max %.3f"
+          % (len(gaps), gaps.min(), np.median(gaps), np.quantile(gaps, 0.95), gaps.max()))
+    assert len(gaps) > 2000
+    assert gaps.min() > -0.03 and 0.01 < np.median(gaps) < 0.06 and np.quantile(gaps, 0.95) < 0.10
+    env.close()
