@@ -112,6 +112,7 @@ struct DynParams {
   float px0, py0;         // world x / y of patch node (0, 0)
   float inv_hs;           // 1 / horizontal_scale
   float zmax;             // highest node of the patch: points above it cannot touch
+  float zmax_near;        // highest node of the central (HX_PATCH/2 + 1)^2 nodes: the bound for points over that part
 };
 
 #define HX_LEG_NJ 5
@@ -171,8 +172,7 @@ HXD SI base_inertia(float s) {
 
 // Height and unit normal of the terrain triangle under world (x, y): every grid cell is split along its
 // (i,j)-(i+1,j+1) diagonal (the split of convert_heightfield_to_trimesh); oracle/terrain.py HeightField.query.
-HXD float terrain_query(const DynParams& P, float x, float y, V3& nw) {
-  const float u = (x - P.px0) * P.inv_hs, w = (y - P.py0) * P.inv_hs;
+HXD float terrain_query(const DynParams& P, float u, float w, V3& nw) {
   const int i = min(max((int)floorf(u), 0), HX_PATCH - 2), j = min(max((int)floorf(w), 0), HX_PATCH - 2);
   const float fu = fminf(fmaxf(u - (float)i, 0.f), 1.f), fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
   const float* c = P.patch + i * HX_PATCH + j;
@@ -204,8 +204,13 @@ HXD V3 contact_points(const DynParams& P, const float* pts, int npts, SV v, cons
     float pen = -z;
     if (P.patch != nullptr) {
       if (!__any(z < P.zmax)) continue;
+      // patch coordinates of the point; over the central part of the window the tighter bound applies
+      const float u = (pb.x + dot(row(Rb, 0), r) - P.px0) * P.inv_hs, w = (pb.y + dot(row(Rb, 1), r) - P.py0) * P.inv_hs;
+      const float lo = (float)(HX_PATCH / 4), hi = (float)(HX_PATCH - HX_PATCH / 4);
+      const bool near = (u >= lo) && (u <= hi) && (w >= lo) && (w <= hi);
+      if (!__any(z < (near ? P.zmax_near : P.zmax))) continue;
       V3 nw;
-      const float h = terrain_query(P, pb.x + dot(row(Rb, 0), r), pb.y + dot(row(Rb, 1), r), nw);
+      const float h = terrain_query(P, u, w, nw);
       pen = (h - z) * nw.z;
       nb = mulT(Rb, nw);
     }

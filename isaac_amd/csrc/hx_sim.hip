@@ -195,16 +195,23 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     DynParams P;
     P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
     P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
-    P.patch = nullptr; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.zmax = 0.f;
+    P.patch = nullptr; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.zmax = 0.f; P.zmax_near = 0.f;
     if (use_terrain) {
       const int r = threadIdx.x >> 1;
       P.patch = lds_patch + r * HX_PATCH * HX_PATCH;
       P.px0 = p.t_x0 + (float)lds_patch_org[r][0] * p.t_hs;
       P.py0 = p.t_y0 + (float)lds_patch_org[r][1] * p.t_hs;
       P.inv_hs = p.t_inv_hs;
-      float zm = -3.0e38f;
-      for (int k = 0; k < HX_PATCH * HX_PATCH / 2; ++k) zm = fmaxf(zm, P.patch[leg * (HX_PATCH * HX_PATCH / 2) + k]);
+      float zm = -3.0e38f, zn = -3.0e38f;
+      for (int k = 0; k < HX_PATCH * HX_PATCH / 2; ++k) {
+        const int idx = leg * (HX_PATCH * HX_PATCH / 2) + k, i = idx / HX_PATCH, j = idx % HX_PATCH;
+        const float hv = P.patch[idx];
+        zm = fmaxf(zm, hv);
+        // nodes HX_PATCH/4 .. HX_PATCH - HX_PATCH/4 bound every point with patch coordinates in that closed range
+        if (i >= HX_PATCH / 4 && i <= HX_PATCH - HX_PATCH / 4 && j >= HX_PATCH / 4 && j <= HX_PATCH - HX_PATCH / 4) zn = fmaxf(zn, hv);
+      }
       P.zmax = fmaxf(zm, xchg(zm));
+      P.zmax_near = fmaxf(zn, xchg(zn));
     }
     float target[5], kpl[5], kdl[5], tll[5];
     for (int j = 0; j < 5; ++j) {
