@@ -342,7 +342,7 @@ class PPO:
     def prof_end(self):
         out = np.zeros(15, np.float64)
         capi.check(self._L.hx_ppo_prof(self._h, 0, capi.ptr(out), None), "prof")
-        names = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, rollout)",
+        names = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
                  "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)", "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
                  "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"]
         ks = [dict(name=names[k], ms=float(out[3 * k]), launches=int(out[3 * k + 1]), flops=float(out[3 * k + 2]))

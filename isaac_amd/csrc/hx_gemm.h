@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
   constexpr int B_ELEMS = B_KM ? BN * (HX_BK + HX_KPAD) : HX_BK * BN;
   constexpr int A_LOADS = BM * HX_BK / 4 / 256;   // float4 per thread per tile
   constexpr int B_LOADS = BN * HX_BK / 4 / 256;
+  constexpr bool PIPE_HALVES = (EPI == EPI_BIAS_ELU || EPI == EPI_BIAS);   // forward products only (see the main loop)
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
 
   // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
@@ -136,6 +137,87 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
       else { const int k = idx / (BN / 4), n4 = idx % (BN / 4); *reinterpret_cast<f32x4*>(Bs + k * BN + n4 * 4) = rb[i]; }
     }
   };
+  // fragments of one HALF of a K tile (HX_BK/2 deep = KB8 blocks of 8): A and B operands of 4 MFMA steps per block
+  constexpr int KB8 = HX_BK / 16;
+  struct Frags { f32x4 a[KB8][TM], b[KB8][TN]; };
+  auto read_frags = [&](int buf, int half, Frags& f) {
+    const float* As = lds + buf * (A_ELEMS + B_ELEMS);
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int q = 0; q < KB8; ++q) {
+      const int kb = half * KB8 + q;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WTM + i * 32 + r32;
+        if (A_KM) f.a[q][i] = *reinterpret_cast<const f32x4*>(As + row * (HX_BK + HX_KPAD) + kb * 8 + 4 * h);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f.a[q][i][j] = As[(kb * 8 + 4 * h + j) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * WTN + i * 32 + r32;
+        if (B_KM) f.b[q][i] = *reinterpret_cast<const f32x4*>(Bs + row * (HX_BK + HX_KPAD) + kb * 8 + 4 * h);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) f.b[q][i][j] = Bs[(kb * 8 + 4 * h + j) * BN + row];
+        }
+      }
+    }
+  };
+  auto mfma_half = [&](const Frags& f) {
+#pragma unroll
+    for (int q = 0; q < KB8; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][a][j], f.b[q][b][j], acc[a][b], 0, 0, 0);
+  };
+  auto bias_grad = [&](int buf) {
+    if (EPI == EPI_SLAB && !A_KM) {
+      // bias gradient = column sums of dZ = row sums over k of the A tile; done once per tile row
+      const float* As = lds + buf * (A_ELEMS + B_ELEMS);
+      if (g.dbias != nullptr && tile_n == 0 && tid < BM) {
+#pragma unroll
+        for (int k = 0; k < HX_BK; ++k) dbacc += As[k * BM + tid];
+      }
+    }
+  };
+
+  // Main loop, software-pipelined over HALF tiles so that the matrix pipe always has register-resident operands on
+  // both sides of the one barrier per K tile:
+  //   top:    ds_read  second-half fragments of tile kt            (latency hidden by the first-half MFMAs)
+  //           MFMA     first half of tile kt                       (fragments read before the previous barrier)
+  //           ds_write tile kt+1 (staged in registers one iteration ago) into the other LDS buffer
+  //           global   loads of tile kt+2 -> staging registers     (a whole iteration to arrive)
+  //           barrier
+  //           ds_read  first-half fragments of tile kt+1           (latency hidden by the second-half MFMAs)
+  //           MFMA     second half of tile kt
+  // The buffer written in iteration kt was last read before the barrier of iteration kt-1, so one barrier suffices.
+  if (PIPE_HALVES && nk > 0) {
+    Frags f0, f1;
+    load_tile(0);
+    store_tile(0);
+    if (nk > 1) load_tile(1);
+    __syncthreads();
+    read_frags(0, 0, f0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      read_frags(cur, 1, f1);
+      bias_grad(cur);
+      mfma_half(f0);
+      if (kt + 1 < nk) store_tile(cur ^ 1);
+      if (kt + 2 < nk) load_tile(kt + 2);
+      __syncthreads();
+      if (kt + 1 < nk) read_frags(cur ^ 1, 0, f0);
+      mfma_half(f1);
+    }
+  }
+
   auto compute = [&](int buf) {
     const float* As = lds + buf * (A_ELEMS + B_ELEMS);
     const float* Bs = As + A_ELEMS;
@@ -183,7 +265,9 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
     }
   };
 
-  if (nk > 0) {
+  // Plain double-buffered loop (two barriers' worth of exposed LDS latency per K tile, but fewer live registers):
+  // measured faster for the backward products (tools/gemm_bench.py, profiles/r01_e_gemm_loops.txt).
+  if (!PIPE_HALVES && nk > 0) {
     load_tile(0);
     store_tile(0);
     __syncthreads();

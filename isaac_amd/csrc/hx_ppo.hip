@@ -734,7 +734,9 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launc
 static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
-  if (M >= 16384) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
+  // K a multiple of 32: 128x128 tiles, BK 32.  The two input layers (K = 616 / 1052) would pad 24 / 4 k-steps per tile
+  // at BK 32; 64-row BK 16 tiles waste less and measured 3-6 % faster there (profiles/r01_e_gemm_loops.txt).
+  if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
@@ -747,7 +749,19 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   GemmArgs g{};
   g.A = dZ; g.lda = out; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = Mrows;
   const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
-  int splits = (1024 + tiles - 1) / tiles;
+  // Split-K grid = ONE full wave of workgroups: 3 resident per CU (144 VGPRs -> 3 waves per SIMD; 32 KB LDS), never
+  // more.  All workgroups of a split-K launch do the same work in lockstep, so a grid of 1026 blocks on 768 slots ran
+  // a second, nearly empty round: the big layer went 1081 -> 901 us when the grid stopped exceeding the slot count
+  // (profiles/r01_e_wgrad_blocks.txt).  HX_WGRAD_BLOCKS overrides the target for experiments.
+  static int target_blocks = -1;
+  if (target_blocks < 0) {
+    const char* e = getenv("HX_WGRAD_BLOCKS");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    target_blocks = e ? atoi(e) : 3 * cus;
+  }
+  int splits = target_blocks / tiles;
+  if (splits < 1) splits = 1;
   int max_splits = Mrows / 256; if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
   int kchunk = rup((Mrows + splits - 1) / splits, 32);
@@ -789,7 +803,14 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
   const size_t nx = (size_t)rows * in_ld, ny = (size_t)rows * out, nw = (size_t)out * in_ld;
   HX_CHECK(hipMalloc(&X, nx * 4)); HX_CHECK(hipMalloc(&W, nw * 4)); HX_CHECK(hipMalloc(&Y, ny * 4));
   const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
-  int splits = (1024 + tiles - 1) / tiles; int max_splits = rows / 256; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
+  static int target_blocks = -1, round_up = 1;
+  if (target_blocks < 0) {
+    const char* e = getenv("HX_WGRAD_BLOCKS");
+    target_blocks = e ? atoi(e) : 1024;
+    round_up = getenv("HX_WGRAD_FLOOR") ? 0 : 1;
+  }
+  int splits = round_up ? (target_blocks + tiles - 1) / tiles : target_blocks / tiles;
+  if (splits < 1) splits = 1; int max_splits = rows / 256; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
   int kchunk = rup((rows + splits - 1) / splits, 32); splits = (rows + kchunk - 1) / kchunk;
   HX_CHECK(hipMalloc(&slab, (size_t)splits * nw * 4)); HX_CHECK(hipMalloc(&bslab, (size_t)splits * out * 4));
   HX_CHECK(hipMemset(X, 0x3d, nx * 4)); HX_CHECK(hipMemset(W, 0x3c, nw * 4)); HX_CHECK(hipMemset(Y, 0x3b, ny * 4));
