@@ -163,6 +163,11 @@ int hx_sim_get_state(hx_sim* s, float* root13_h /*[N][13]*/, float* q_h /*[N][10
 int hx_sim_set_state(hx_sim* s, const float* root13_h, const float* q_h, const float* qd_h);
 int hx_sim_set_episode_length(hx_sim* s, const int32_t* ep_len_h);
 int hx_sim_set_step_counter(hx_sim* s, int64_t common_step_counter);
+/* play-style access (reference humanoid/scripts/play.py:136-140,160-175): overwrite `env.commands` [N][4]
+ * (vx, vy, yaw rate, heading) before a step, and read `env.base_lin_vel` / `env.base_ang_vel` [N][3] (base frame,
+ * legged_robot.py:132-133) after it.  Host pointers; both synchronise the simulator's stream. */
+int hx_sim_set_commands(hx_sim* s, const float* commands_h);
+int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h);
 /* over the envs that reset since the last call: mean of episode_sum / max_episode_length_s per reward term
  * (legged_robot.py:198-201), then mean episode return and mean episode length (on_policy_runner.py:140-154) */
 int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS + 2]*/, int32_t* count_h);

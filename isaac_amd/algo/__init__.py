@@ -1,3 +1,3 @@
 from .ppo import PPO, ActorCritic  # noqa: F401
 from .on_policy_runner import OnPolicyRunner  # noqa: F401
-from ..envs.vec_env import VecEnv  # noqa: F401
+from .vec_env import VecEnv  # noqa: F401

@@ -97,6 +97,18 @@ class ActorCritic:
             flat = self._flatten(sd)
             capi.check(capi.lib().hx_ppo_set_params_h(self._alg._h, capi.ptr(flat)), "set_params")
 
+    def load_actor_from_onnx(self, path):
+        """Replace the actor's weights with those of an exported actor (reference play.py:89-98 and the shipped
+        humanoid/locomotion_net*.onnx); critic and std keep their values."""
+        from ..utils.onnx_io import actor_state_dict
+        sd = self.state_dict()
+        new = actor_state_dict(path)
+        for k, v in new.items():
+            if k not in sd or sd[k].shape != v.shape:
+                raise ValueError(f"{path}: tensor {k} {v.shape} does not fit this actor ({sd.get(k, np.zeros(0)).shape})")
+            sd[k] = v
+        self.load_state_dict(sd)
+
     @property
     def std(self):
         return self.state_dict()["std"]

@@ -90,6 +90,8 @@ def lib():
     L.hx_sim_set_state.argtypes = [vp, vp, vp, vp]
     L.hx_sim_set_episode_length.argtypes = [vp, vp]
     L.hx_sim_set_step_counter.argtypes = [vp, C.c_int64]
+    L.hx_sim_set_commands.argtypes = [vp, vp]
+    L.hx_sim_get_base_velocities.argtypes = [vp, vp, vp]
     L.hx_sim_set_terrain.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]
     L.hx_sim_episode_stats.argtypes = [vp, vp, vp]
     L.hx_sim_stream.argtypes = [vp]

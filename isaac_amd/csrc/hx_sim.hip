@@ -698,9 +698,15 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
   s->cur = 0;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    HX_CHECK(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, greatest));   // the rollout's critical path
+    if (const char* e = getenv("HX_SIM_CU_WORD")) {      // experiment hook: confine this simulator's stream to a CU subset
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = (uint32_t)strtoul(e, nullptr, 16);
+      HX_CHECK(hipExtStreamCreateWithCUMask(&s->stream, 8, mask));
+    } else {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      HX_CHECK(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, greatest));   // the rollout's critical path
+    }
     s->own_stream = true;
   }
   const size_t n = cfg->num_envs;
@@ -858,6 +864,26 @@ extern "C" int hx_sim_set_state(hx_sim* s, const float* root_h, const float* q_h
     for (int j = 0; j < 10; ++j) { st[(size_t)(S_Q + j) * n + e] = q_h[e * 10 + j]; st[(size_t)(S_QD + j) * n + e] = qd_h[e * 10 + j]; }
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int hx_sim_set_commands(hx_sim* s, const float* cmd_h) {
+  const size_t n = s->cfg.num_envs;
+  std::vector<float> c(4 * n);
+  for (size_t e = 0; e < n; ++e)
+    for (int k = 0; k < 4; ++k) c[(size_t)k * n + e] = cmd_h[e * 4 + k];
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(s->p.st + (size_t)S_CMD * n, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h) {
+  const size_t n = s->cfg.num_envs;
+  std::vector<float> v(6 * n);
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(v.data(), s->p.st + (size_t)S_BLV * n, v.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < n; ++e)
+    for (int k = 0; k < 3; ++k) { lin_h[e * 3 + k] = v[(size_t)k * n + e]; ang_h[e * 3 + k] = v[(size_t)(3 + k) * n + e]; }
   return 0;
 }
 

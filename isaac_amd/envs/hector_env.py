@@ -17,6 +17,7 @@ import numpy as np
 
 from .. import capi
 from ..devarray import DeviceArray, device_pointer
+from ..cfgtools import class_to_dict  # noqa: F401  (kept importable from here)
 from .vec_env import VecEnv
 
 DOF_NAMES = ["L_hip_joint", "L_hip_roll_joint", "L_thigh_joint", "L_calf_joint", "L_toe_joint",
@@ -27,19 +28,6 @@ BASE_MASS = 8.15528                                    # collapsed base link (to
 
 # physics model constants (DESIGN.md "Physics model"); mirrored in oracle/physics.py
 PHYS = dict(contact_kn=4.0e4, contact_dn=4.0e2, friction_veps=2.0e-2, limit_k=2.0e3, limit_d=2.0e1)
-
-
-def class_to_dict(obj):
-    """reference humanoid/utils/helpers.py:43-58 -- dir() order == alphabetical (decides reward order)."""
-    if not hasattr(obj, "__dict__"):
-        return obj
-    out = {}
-    for key in dir(obj):
-        if key.startswith("_"):
-            continue
-        val = getattr(obj, key)
-        out[key] = [class_to_dict(i) for i in val] if isinstance(val, list) else class_to_dict(val)
-    return out
 
 
 def creation_randomisation(cfg, num_envs, env_origins):
@@ -357,6 +345,26 @@ class HectorFreeEnv(VecEnv):
     @property
     def commands(self):
         return self._buf(capi.BUF_COMMANDS, (4, self.num_envs)).numpy().T
+
+    @commands.setter
+    def commands(self, value):
+        """`env.commands[:, 0] = 0.5` of the reference (play.py:136-140) becomes read-modify-assign:
+        c = env.commands; c[:, 0] = 0.5; env.commands = c."""
+        capi.check(self._L.hx_sim_set_commands(self._h, capi.ptr(capi.farr(np.asarray(value, np.float32).reshape(self.num_envs, 4)))),
+                   "hx_sim_set_commands")
+
+    def _base_velocities(self):
+        lin, ang = np.empty((self.num_envs, 3), np.float32), np.empty((self.num_envs, 3), np.float32)
+        capi.check(self._L.hx_sim_get_base_velocities(self._h, capi.ptr(lin), capi.ptr(ang)), "hx_sim_get_base_velocities")
+        return lin, ang
+
+    @property
+    def base_lin_vel(self):
+        return self._base_velocities()[0]
+
+    @property
+    def base_ang_vel(self):
+        return self._base_velocities()[1]
 
     @property
     def torques(self):

@@ -1,26 +1,2 @@
-"""VecEnv protocol (reference humanoid/algo/vec_env.py:37-61): what the runner may touch on an env."""
-from abc import ABC, abstractmethod
-
-
-class VecEnv(ABC):
-    num_envs: int
-    num_obs: int
-    num_privileged_obs: int
-    num_actions: int
-    max_episode_length: int
-
-    @abstractmethod
-    def step(self, actions):
-        """-> (obs, privileged_obs, rewards, dones, infos)"""
-
-    @abstractmethod
-    def reset(self):
-        """-> (obs, privileged_obs)"""
-
-    @abstractmethod
-    def get_observations(self):
-        pass
-
-    @abstractmethod
-    def get_privileged_observations(self):
-        pass
+"""VecEnv protocol; defined in isaac_amd/algo/vec_env.py (where the reference keeps it: humanoid/algo/vec_env.py)."""
+from ..algo.vec_env import VecEnv  # noqa: F401

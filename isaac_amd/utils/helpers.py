@@ -12,7 +12,7 @@ import random
 
 import numpy as np
 
-from ..envs.hector_env import class_to_dict  # noqa: F401  (re-exported, helpers.py:43)
+from ..cfgtools import class_to_dict  # noqa: F401  (re-exported, helpers.py:43)
 
 
 class SimParams:
@@ -112,6 +112,10 @@ def get_args(argv=None):
     p.add_argument("--num_envs", type=int)
     p.add_argument("--seed", type=int)
     p.add_argument("--max_iterations", type=int)
+    # play script only (no reference counterpart: the reference edits constants in play.py)
+    p.add_argument("--onnx", type=str, default=None, help="play: load the actor from this ONNX file instead of a checkpoint")
+    p.add_argument("--play_steps", type=int, default=1200, help="play: env steps to roll (reference stop_state_log)")
+    p.add_argument("--play_out", type=str, default=None, help="play: directory for traces and exported policies")
     # flags isaacgym.gymutil.parse_arguments provides
     p.add_argument("--sim_device", type=str, default="cuda:0")
     p.add_argument("--pipeline", type=str, default="gpu")
@@ -136,6 +140,16 @@ def get_args(argv=None):
         args.sim_device = f"cuda:{lr}"
         args.rl_device = f"cuda:{lr}"
     return args
+
+
+def export_policy_as_onnx(actor_critic, path, name="locomotion_net.onnx"):
+    """The `torch.onnx.export(actor, obs, "locomotion_net.onnx", opset_version=11, input_names=['obs'],
+    output_names=['action'])` of reference play.py:89-98, written without the onnx package (utils/onnx_io.py)."""
+    from .onnx_io import save_actor
+    os.makedirs(path, exist_ok=True)
+    sd = actor_critic.state_dict()
+    layers = [(sd[f"actor.{2 * i}.weight"], sd[f"actor.{2 * i}.bias"]) for i in range(len(actor_critic.actor_hidden_dims) + 1)]
+    return save_actor(os.path.join(path, name), layers)
 
 
 def export_policy_as_jit(actor_critic, path):
