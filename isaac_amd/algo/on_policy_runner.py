@@ -174,6 +174,9 @@ class OnPolicyRunner:
                  f"{'Value function loss:':>{pad}} {locs['mean_value_loss']:.4f}",
                  f"{'Surrogate loss:':>{pad}} {locs['mean_surrogate_loss']:.4f}",
                  f"{'Mean action noise std:':>{pad}} {mean_std:.2f}"]
+        if locs["n_ep"] > 0:
+            lines += [f"{'Mean reward:':>{pad}} {self.env.last_episode_return:.2f}",
+                      f"{'Mean episode length:':>{pad}} {self.env.last_episode_length:.2f}"]
         for k, v in locs["ep_info"].items():
             lines.append(f"{'Mean episode ' + k + ':':>{pad}} {v:.4f}")
         lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}",
