@@ -165,7 +165,13 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
 // hx_gemm.h a float4 per lane (k = 4*(l>>4) .. +3 of a 16-deep block) feeds 4 MFMAs.  C/D: col = l&15, row = 4*(l>>4)+reg.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define FA_ROWS 16
-template <int NT>   // NT = 16-column tiles per wave
+#ifndef FA_RING1
+#define FA_RING1 3     // measured: ring 2 -> 80 us, 3 -> 74 us, 6/8 -> 92 us per call (profiles/r01_g_actor_ring.txt)
+#endif
+#ifndef FA_RING2
+#define FA_RING2 3
+#endif
+template <int NT, int NBUF>   // NT = 16-column tiles per wave; NBUF = register ring of weight k-blocks (NBUF-1 in flight)
 __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                          const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane) {
   const int r16 = lane & 15, kq = lane >> 4;
@@ -173,8 +179,11 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   const int nkb = (K + 15) / 16;
-  // weights are streamed from L2 with TWO k-blocks in flight per wave (one was L2-latency bound: 80 us per call)
-  f32x4v b0[NT], b1[NT], b2[NT];
+  // Weights are streamed from L2 straight into B fragments.  One wave per SIMD owns the whole 512-entry register file,
+  // so the ring depth is free to choose: one block in flight 80 us per call, two 74 us, five to seven 92 us -- all 256
+  // workgroups stream the same 1.9 MB in lockstep, and beyond two blocks in flight the extra requests only queue at
+  // the L2 (profiles/r01_g_actor_ring.txt).
+  f32x4v ring[NBUF][NT];
   auto loadB = [&](int kb, f32x4v* dst) {
     const int k = kb * 16 + 4 * kq;
 #pragma unroll
@@ -193,16 +202,15 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bc[t][i], acc[t], 0, 0, 0);
   };
-  loadB(0, b0);
-  loadB(1, b1);
-  int kb = 0;
-  for (; kb + 2 < nkb; kb += 3) {
-    loadB(kb + 2, b2); step(kb, b0);
-    loadB(kb + 3, b0); step(kb + 1, b1);
-    loadB(kb + 4, b1); step(kb + 2, b2);
+#pragma unroll
+  for (int j = 0; j < NBUF - 1; ++j) loadB(j, ring[j]);
+  for (int kb = 0; kb < nkb; kb += NBUF) {
+#pragma unroll
+    for (int j = 0; j < NBUF; ++j) {
+      loadB(kb + j + NBUF - 1, ring[(j + NBUF - 1) % NBUF]);
+      if (kb + j < nkb) step(kb + j, ring[j]);
+    }
   }
-  if (kb < nkb) step(kb, b0);
-  if (kb + 1 < nkb) step(kb + 1, b1);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = n_wave0 + t * 16 + r16;
@@ -236,11 +244,11 @@ __global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __rest
     *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
   }
   __syncthreads();
-  fa_layer<8>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
+  fa_layer<8, FA_RING1>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
   __syncthreads();
-  fa_layer<4>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
+  fa_layer<4, FA_RING2>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
   __syncthreads();
-  fa_layer<2>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);       // 256 -> 128
+  fa_layer<2, FA_RING2>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);       // 256 -> 128
   __syncthreads();
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]
   if (tid < FA_ROWS * A) {
