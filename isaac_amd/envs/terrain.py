@@ -235,6 +235,10 @@ class HumanoidTerrain(Terrain):
     """Tile mix of the hector / humanoid tasks (reference humanoid/utils/terrain.py:189-234): by cumulative
     `terrain_proportions` -> flat, discrete obstacles, random uniform, slope up, slope down, stairs up, stairs down."""
 
+    def __init__(self, cfg, num_robots):
+        self.tile_log = []          # (kind, difficulty) per generated tile, in generation order
+        super().__init__(cfg, num_robots)
+
     def randomized_terrain(self):
         for k in range(self.cfg.num_sub_terrains):
             i, j = np.unravel_index(k, (self.cfg.num_rows, self.cfg.num_cols))
@@ -246,6 +250,7 @@ class HumanoidTerrain(Terrain):
         t = self._tile()
         block_h, rough_h, slope = difficulty * 0.2, difficulty * 0.14, difficulty * 0.45
         kind = int(np.searchsorted(np.asarray(self.proportions, np.float64), choice, side="right"))
+        self.tile_log.append((kind, float(difficulty)))       # diagnostics: (kind 0..6 as in the class docstring, difficulty)
         if kind == 1:
             discrete_obstacles_terrain(t, block_h, 1.0, 2.0, 20, platform_size=3.0)
         elif kind == 2:

@@ -72,8 +72,8 @@ def get_load_path(root, load_run=-1, checkpoint=-1):
         last_run = os.path.join(root, runs[-1])
     except Exception:
         raise ValueError("No runs in this directory: " + root)
-    load_run = last_run if load_run == -1 else os.path.join(root, load_run)
-    if checkpoint == -1:
+    load_run = last_run if load_run in (-1, "-1") else os.path.join(root, load_run)
+    if checkpoint in (-1, "-1"):
         models = [f for f in os.listdir(load_run) if "model" in f]
         models.sort(key=lambda m: "{0:0>15}".format(m))
         model = models[-1]
