@@ -31,6 +31,26 @@ PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x3
 GEMM_KERNELS = ["fwd_128x128", "fwd_64x128", "dgrad_128x128", "dgrad_64x128", "wgrad_128x128_splitk"]
 
 
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the committed PMC pass (profiles/*_traffic.json, written by
+    tools/collect_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
+    command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The counters cannot be read live
+    from inside the timed run, so the newest committed file for the default workload is reported; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        k = d["kernels"][kernel_name]
+        return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], {
+            "unit": "bytes per launch (fetch + write)", "fetch_bytes": k["fetch_bytes_per_launch"], "write_bytes": k["write_bytes_per_launch"],
+            "launches_sampled": k["launches_sampled"], "source": "profiles/" + os.path.basename(files[-1])}
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(sample_envs=4096, sample_steps=6, terrain="trimesh"):
     """The numpy oracle (oracle/env.py + oracle/physics.py + oracle/ppo.py: the CPU restatement, kind="port")
     timed on this box's host cores for a bounded sample of the same iteration: `sample_steps` rollout steps of
@@ -144,8 +164,10 @@ def main():
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+            traffic, traffic_detail = pmc_traffic(k["name"]) if (args.envs == 4096 and args.terrain == "trimesh" and args.shards == 1) else (None, None)
             out["roofline"] = {"bound": "mfma", "kernel": k["name"], "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_detail": traffic_detail,
                                "launches": k["launches"], "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
                                "flop_per_launch": k["flops"] / max(1, k["launches"]),
                                "all_gemm_kernels": prof["kernels"],

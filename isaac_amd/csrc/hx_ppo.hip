@@ -165,13 +165,7 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
 // hx_gemm.h a float4 per lane (k = 4*(l>>4) .. +3 of a 16-deep block) feeds 4 MFMAs.  C/D: col = l&15, row = 4*(l>>4)+reg.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define FA_ROWS 16
-#ifndef FA_RING1
-#define FA_RING1 3     // measured: ring 2 -> 80 us, 3 -> 74 us, 6/8 -> 92 us per call (profiles/r01_g_actor_ring.txt)
-#endif
-#ifndef FA_RING2
-#define FA_RING2 3
-#endif
-template <int NT, int NBUF>   // NT = 16-column tiles per wave; NBUF = register ring of weight k-blocks (NBUF-1 in flight)
+template <int NT>   // NT = 16-column tiles per wave
 __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                          const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane) {
   const int r16 = lane & 15, kq = lane >> 4;
@@ -179,11 +173,10 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   const int nkb = (K + 15) / 16;
-  // Weights are streamed from L2 straight into B fragments.  One wave per SIMD owns the whole 512-entry register file,
-  // so the ring depth is free to choose: one block in flight 80 us per call, two 74 us, five to seven 92 us -- all 256
-  // workgroups stream the same 1.9 MB in lockstep, and beyond two blocks in flight the extra requests only queue at
-  // the L2 (profiles/r01_g_actor_ring.txt).
-  f32x4v ring[NBUF][NT];
+  // weights are streamed from L2 with TWO k-blocks in flight per wave (one was L2-latency bound: 80 us per call).
+  // The loop is written out for three named buffers on purpose: a generic register-ring version of the same
+  // schedule compiled to 86 us instead of 74 us (profiles/r01_g_actor_ring.txt).
+  f32x4v b0[NT], b1[NT], b2[NT];
   auto loadB = [&](int kb, f32x4v* dst) {
     const int k = kb * 16 + 4 * kq;
 #pragma unroll
@@ -202,15 +195,16 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bc[t][i], acc[t], 0, 0, 0);
   };
-#pragma unroll
-  for (int j = 0; j < NBUF - 1; ++j) loadB(j, ring[j]);
-  for (int kb = 0; kb < nkb; kb += NBUF) {
-#pragma unroll
-    for (int j = 0; j < NBUF; ++j) {
-      loadB(kb + j + NBUF - 1, ring[(j + NBUF - 1) % NBUF]);
-      if (kb + j < nkb) step(kb + j, ring[j]);
-    }
+  loadB(0, b0);
+  loadB(1, b1);
+  int kb = 0;
+  for (; kb + 2 < nkb; kb += 3) {
+    loadB(kb + 2, b2); step(kb, b0);
+    loadB(kb + 3, b0); step(kb + 1, b1);
+    loadB(kb + 4, b1); step(kb + 2, b2);
   }
+  if (kb < nkb) step(kb, b0);
+  if (kb + 1 < nkb) step(kb + 1, b1);
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = n_wave0 + t * 16 + r16;
@@ -244,11 +238,11 @@ __global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __rest
     *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
   }
   __syncthreads();
-  fa_layer<8, FA_RING1>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
+  fa_layer<8>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
   __syncthreads();
-  fa_layer<4, FA_RING2>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
+  fa_layer<4>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
   __syncthreads();
-  fa_layer<2, FA_RING2>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);       // 256 -> 128
+  fa_layer<2>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);       // 256 -> 128
   __syncthreads();
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]
   if (tid < FA_ROWS * A) {
@@ -739,12 +733,15 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launc
 // Variant choice is from measurement (tools/gemm_bench.py, profiles/r01_gemm_variants*.txt): after the branch-free
 // epilogue all variants are within ~5 %; BK = 32 is best for the forward layers and 64-row BK = 32 tiles for dgrad
 // (short K = 128..256, where a shorter launch tail matters most).
-static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K) {
+static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K,
+                     bool background = false) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
   // K a multiple of 32: 128x128 tiles, BK 32.  The two input layers (K = 616 / 1052) would pad 24 / 4 k-steps per tile
   // at BK 32; 64-row BK 16 tiles waste less and measured 3-6 % faster there (profiles/r01_e_gemm_loops.txt).
-  if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
+  // Background launches (the deferred critic beside the rollout) always take the 128x128 kernel: with 2 resident
+  // workgroups per CU instead of 5 it disturbs the L2-bound actor kernel less (actor 88 -> 74 us per call).
+  if (M >= 16384 && (K % 32 == 0 || background)) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
@@ -1028,10 +1025,11 @@ extern "C" int hx_ppo_get_opt_state_h(hx_ppo* s, float* m, float* v, int64_t* st
 // hidden layers of one network: X[M][ld] -> act[0..2]
 static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr) {
   const Layer* L = s->L + net * 4;
+  const bool bg = (st != nullptr && st == s->stream2);
   if (!st) st = s->stream;
-  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld);
-  gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld);
-  gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld);
+  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld, bg);
+  gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld, bg);
+  gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld, bg);
 }
 
 #ifndef HX_CRITIC_CHUNK
