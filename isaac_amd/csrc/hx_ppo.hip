@@ -739,9 +739,12 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
   // K a multiple of 32: 128x128 tiles, BK 32.  The two input layers (K = 616 / 1052) would pad 24 / 4 k-steps per tile
   // at BK 32; 64-row BK 16 tiles waste less and measured 3-6 % faster there (profiles/r01_e_gemm_loops.txt).
-  // Background launches (the deferred critic beside the rollout) always take the 128x128 kernel: with 2 resident
-  // workgroups per CU instead of 5 it disturbs the L2-bound actor kernel less (actor 88 -> 74 us per call).
-  if (M >= 16384 && (K % 32 == 0 || background)) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
+  // Background launches (the deferred critic beside the rollout) take the 128x128 BK16 kernel: 37 KB of LDS per
+  // workgroup leaves room for an env-step workgroup (34 KB) next to three of them on a CU; with the 74 KB BK32 tiles
+  // the env-step kernel waited for LDS (440 us instead of 200 us on the steps a critic burst overlaps,
+  // profiles/r01_j_rollout_interference.txt).
+  if (background && M >= 16384) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
+  else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
