@@ -123,7 +123,8 @@ def main():
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     comm = init_comm()
-    local = comm.local_rank
+    ndev = max(1, capi.lib().hx_device_count())
+    local = comm.local_rank % ndev       # one rank per GPU under the driver; wraps only in the one-GPU gloo-staged rehearsal
     capi.check(capi.lib().hx_set_device(local), "hx_set_device")
 
     env_cfg, train_cfg = HectorCfg(), HectorCfgPPO()

@@ -56,8 +56,14 @@ class TorchComm(Comm):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("HX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # "gloo-staged": gloo collectives on host copies of the library's DEVICE buffers.  A functional rehearsal of the
+        # N > 1 path where RCCL cannot run (several ranks sharing one GPU); never the measured configuration.
+        self.staged = (backend == "gloo-staged")
+        if self.staged:
+            backend = "gloo"
         self.backend = backend
+        self.device_ptrs = (backend == "nccl") or self.staged      # do the library's pointers name device memory?
         if backend == "nccl":
             torch.cuda.set_device(self.local_rank)
             self.device = torch.device("cuda", self.local_rank)
@@ -80,7 +86,10 @@ class TorchComm(Comm):
         return out
 
     def alloc_grad_buffer(self, count):
-        """Flat fp32 buffer owned by torch so the collective can run on it in place."""
+        """Flat fp32 buffer owned by torch so the collective can run on it in place (None: the library keeps its own
+        device buffer and the collective is staged through the host)."""
+        if self.staged:
+            return None
         self._grad = self.torch.zeros(int(count), dtype=self.torch.float32, device=self.device)
         return self._grad.data_ptr()
 
@@ -93,6 +102,13 @@ class TorchComm(Comm):
             capi.check(capi.lib().hx_sync(stream), "hx_sync")
 
     def all_reduce_grads(self, ptr, count, stream):
+        if self.staged:
+            from . import capi
+            host = capi.download(ptr, np.float32, (int(count),), stream)
+            t = self.torch.from_numpy(host)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            capi.check(capi.lib().hx_memcpy_h2d(ptr, capi.ptr(np.ascontiguousarray(t.numpy())), int(count) * 4, stream), "h2d")
+            return
         assert self._grad is not None and ptr == self._grad.data_ptr() and count == self._grad.numel()
         self._sync_streams(stream)
         self.dist.all_reduce(self._grad, op=self.dist.ReduceOp.SUM)
@@ -102,7 +118,7 @@ class TorchComm(Comm):
     def all_reduce_moments(self, ptr, stream):
         """[sum, sum of squares, count] of the raw advantages (3 doubles) -> global moments on every rank."""
         import ctypes
-        if self.backend == "nccl":
+        if self.device_ptrs:
             from . import capi
             m = capi.download(ptr, np.float64, (3,), stream)
         else:                                   # gloo: the pointer is host memory (CPU tests of the orchestration)
@@ -110,7 +126,7 @@ class TorchComm(Comm):
         t = self.torch.from_numpy(m).to(self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         m = np.ascontiguousarray(t.cpu().numpy())
-        if self.backend == "nccl":
+        if self.device_ptrs:
             from . import capi
             capi.check(capi.lib().hx_memcpy_h2d(ptr, capi.ptr(m), 24, stream), "h2d")
         else:
