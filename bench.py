@@ -173,7 +173,7 @@ def main():
                                "flop_per_launch": k["flops"] / max(1, k["launches"]),
                                "all_gemm_kernels": prof["kernels"],
                                "whole_iteration_mfma_frac": value / world * FLOP_PER_ENV_STEP / (PEAK_F32_MFMA_TFLOPS * 1e12)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only; other ranks wait at the barrier below
             try:
                 out["cpu_baseline"] = cpu_baseline(terrain=args.terrain)
             except Exception as e:                        # the baseline must never take the GPU number down with it
