@@ -177,14 +177,14 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
   // The loop is written out for three named buffers on purpose: a generic register-ring version of the same
   // schedule compiled to 86 us instead of 74 us (profiles/r01_g_actor_ring.txt).
   f32x4v b0[NT], b1[NT], b2[NT];
+  // Branch-free on purpose: with a guard around each load hipcc loses track of the VM counter across the divergent
+  // regions and waits `vmcnt(0)` before every group of MFMAs, i.e. also for the blocks just requested (the stream
+  // then pays a full L2 round trip every third block: 74-86 us per call).  Out-of-range blocks re-read the last valid
+  // 16 bytes of the row instead; their A operand is zero (step() guards it), so they contribute nothing.
   auto loadB = [&](int kb, f32x4v* dst) {
-    const int k = kb * 16 + 4 * kq;
+    const int k = min(min(kb, nkb - 1) * 16 + 4 * kq, K - 4);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x4v v = {0.f, 0.f, 0.f, 0.f};
-      if (kb < nkb && k < K) v = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
-      dst[t] = v;
-    }
+    for (int t = 0; t < NT; ++t) dst[t] = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
   };
   auto step = [&](int kb, const f32x4v* bc) {
     const int k = kb * 16 + 4 * kq;
