@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--shards", type=int, default=1, help="env shards per GPU driven round-robin on separate streams (1 = off; measured slower than the deferred-critic overlap, see DESIGN.md)")
     ap.add_argument("--terrain", default="trimesh", choices=["trimesh", "heightfield", "plane"],
                     help="terrain.mesh_type; 'trimesh' is the reference's default for the hector task (hector_config.py:45)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="learner precision: f32 = the metric's configuration (BASELINE config 2); bf16 = BASELINE config 4 "
+                         "(forward/dgrad products on the bf16 matrix cores, fp32 master weights and wgrads) -- a different "
+                         "configuration, reported with dtype 'bf16' and never as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
@@ -135,7 +139,10 @@ def main():
         env = PipelinedHectorEnv(env_cfg, sim_device=f"cuda:{local}", headless=True, num_shards=args.shards)
     else:
         env = HectorFreeEnv(env_cfg, sim_device=f"cuda:{local}", headless=True)
-    runner = OnPolicyRunner(env, class_to_dict(train_cfg), log_dir=None, device=f"cuda:{local}", comm=comm)
+    tcfg = class_to_dict(train_cfg)
+    if args.dtype != "f32":
+        tcfg["algorithm"]["mlp_dtype"] = args.dtype          # extra PPO keyword of this build (hx_ppo_set_compute_dtype)
+    runner = OnPolicyRunner(env, tcfg, log_dir=None, device=f"cuda:{local}", comm=comm)
     T = runner.num_steps_per_env
 
     runner.learn(args.warmup, init_at_random_ep_len=True)          # untimed warm-up iterations
@@ -156,9 +163,10 @@ def main():
         value = env_steps / elapsed
         out = {"metric": "env-steps/sec (whole node), hector 4096 envs/GPU", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"hector {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
-                                      "update 2 epochs x 4 minibatches, fp32 HIP sim + MLP actor [512,256,128] / critic [768,256,128]",
+                                      "update 2 epochs x 4 minibatches, fp32 HIP sim + MLP actor [512,256,128] / critic [768,256,128]"
+                                      + ("" if args.dtype == "f32" else " (bf16 forward/dgrad MFMA, fp32 master weights)"),
                           "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
                           "terrain": args.terrain, "env_shards": args.shards, "collection_s": runner.last_perf.get("collection_time"),
                           "learn_s": runner.last_perf.get("learn_time")}}

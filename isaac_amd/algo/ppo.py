@@ -136,7 +136,12 @@ class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
                  use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cuda:0", stream=None,
-                 comm=None):
+                 comm=None, mlp_dtype="f32"):
+        """mlp_dtype: "f32" (default, the reference's precision) or "bf16" (BASELINE config 4: forward / dgrad products of
+        the update and the deferred critic on the bf16 matrix cores, fp32 master weights; hx_ppo_set_compute_dtype)."""
+        if mlp_dtype not in ("f32", "bf16"):
+            raise ValueError("mlp_dtype must be 'f32' or 'bf16'")
+        self.mlp_dtype = mlp_dtype
         self.device = device
         self.actor_critic = actor_critic
         self.desired_kl, self.schedule = desired_kl, schedule
@@ -184,6 +189,8 @@ class PPO:
         self.N, self.T, self.A = num_envs, num_transitions_per_env, action_shape[0]
         self.obs_ld, self.priv_ld = c.obs_ld, c.priv_ld
         ac._alg = self
+        if self.mlp_dtype == "bf16":
+            capi.check(self._L.hx_ppo_set_compute_dtype(h, 1), "hx_ppo_set_compute_dtype")
         ac.load_state_dict(ac._pending_state)
         self.storage = self          # `alg.storage.clear()` style calls land here
         self.step = 0

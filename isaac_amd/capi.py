@@ -114,6 +114,7 @@ def lib():
     L.hx_ppo_num_params.restype = C.c_int64
     L.hx_ppo_set_params_h.argtypes = [vp, vp]
     L.hx_ppo_get_params_h.argtypes = [vp, vp]
+    L.hx_ppo_set_compute_dtype.argtypes = [vp, C.c_int]
     L.hx_ppo_set_opt_state_h.argtypes = [vp, vp, vp, C.c_int64]
     L.hx_ppo_get_opt_state_h.argtypes = [vp, vp, vp, C.POINTER(C.c_int64)]
     L.hx_ppo_act.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]

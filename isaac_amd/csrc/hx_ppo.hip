@@ -19,6 +19,7 @@
 #include "../../include/hx_sim.h"
 #include "hx_common.h"
 #include "hx_gemm.h"
+#include "hx_gemm_bf16.h"
 
 #define MAX_A 16
 #ifndef HX_BK_UPD
@@ -694,6 +695,8 @@ struct hx_ppo {
   double* sumsq; SchedState* sched;
   int64_t adam_t;
   int mb_done, mb_total;
+  bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
+  float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
   uint32_t seed_lo, seed_hi, act_counter, perm_counter;
   // profiling
   bool prof; std::vector<hipEvent_t> ev; std::vector<int> ev_kid; size_t ev_used; double prof_flops[5]; long prof_launches[5];
@@ -730,11 +733,58 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launc
   }
 }
 
+// bf16-input variant (hx_gemm_bf16.h); reported to the profiler under the fp32 kernel ids 0 (forward) / 2 (dgrad)
+template <int EPI> static void launch_gemm_bf16(hx_ppo* s, GemmArgs& g, hipStream_t st) {
+  g.tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.N + 127) / 128;
+  const int blocks = g.tiles_m * g.tiles_n;
+  constexpr int kid = (EPI == EPI_ELU_GRAD) ? 2 : 0;
+  if (s && s->prof) {
+    while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
+  }
+  if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
+    (void)hipEventRecord(s->ev[s->ev_used], st);
+    hipLaunchKernelGGL((hx_gemm_bf16_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
+    (void)hipEventRecord(s->ev[s->ev_used + 1], st);
+    s->ev_kid[s->ev_used] = kid;
+    s->ev_used += 2;
+    s->prof_flops[kid] += 2.0 * g.M * g.N * g.K;
+    s->prof_launches[kid] += 1;
+  } else {
+    hipLaunchKernelGGL((hx_gemm_bf16_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
+  }
+}
+
+// W[out][ld_in] (first `in` columns) -> WT[in][out]
+__global__ void hx_transpose_kernel(const float* __restrict__ W, int out, int in, int ld_in, float* __restrict__ WT) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int o = by + r, i = bx + threadIdx.x;
+    t[r][threadIdx.x] = (o < out && i < in) ? W[(size_t)o * ld_in + i] : 0.f;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    const int i = bx + r, o = by + threadIdx.x;
+    if (i < in && o < out) WT[(size_t)i * out + o] = t[threadIdx.x][r];
+  }
+}
+static void refresh_transposes(hx_ppo* s, hipStream_t st) {
+  if (!s->bf16) return;
+  for (int net = 0; net < 2; ++net)
+    for (int l = 1; l <= 2; ++l) {
+      const Layer& L = s->L[net * 4 + l];
+      const int in = L.in_ld;      // hidden widths are multiples of 4: in_ld == fan-in
+      hipLaunchKernelGGL(hx_transpose_kernel, dim3((in + 31) / 32, (L.out + 31) / 32), dim3(32, 8), 0, st, s->params + L.w, L.out, in, L.in_ld,
+                         s->wT[net * 4 + l]);
+    }
+}
+
 // Variant choice is from measurement (tools/gemm_bench.py, profiles/r01_gemm_variants*.txt): after the branch-free
 // epilogue all variants are within ~5 %; BK = 32 is best for the forward layers and 64-row BK = 32 tiles for dgrad
 // (short K = 128..256, where a shorter launch tail matters most).
 static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K,
-                     bool background = false) {
+                     bool background = false, bool fp32_only = false) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
   // K a multiple of 32: 128x128 tiles, BK 32.  The two input layers (K = 616 / 1052) would pad 24 / 4 k-steps per tile
@@ -743,13 +793,16 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   // workgroup leaves room for an env-step workgroup (34 KB) next to three of them on a CU; with the 74 KB BK32 tiles
   // the env-step kernel waited for LDS (440 us instead of 200 us on the steps a critic burst overlaps,
   // profiles/r01_j_rollout_interference.txt).
-  if (background && M >= 16384) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
+  if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // critic forwards and the update's forwards; the rollout actor stays fp32
+  else if (background && M >= 16384) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
-static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K) {
+static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K,
+                       const float* WT = nullptr) {
   GemmArgs g{};
   g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = N; g.M = M; g.N = N; g.K = K; g.H = H; g.ldh = N;
+  if (s->bf16 && WT != nullptr) { g.B = WT; g.ldb = K; launch_gemm_bf16<EPI_ELU_GRAD>(s, g, st); return; }   // B = W^T[N][K], K-major
   launch_gemm<64, 128, 32, true, false, EPI_ELU_GRAD>(s, g, st);
 }
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab / bias_slab
@@ -784,6 +837,11 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.H = H; g.ldh = ldc;
+  if (mode == 5 || mode == 6) {      // bf16-input kernels: 5 = forward (bias + ELU), 6 = dgrad with B = W^T given K-major
+    if (mode == 5) launch_gemm_bf16<EPI_BIAS_ELU>(nullptr, g, st); else launch_gemm_bf16<EPI_ELU_GRAD>(nullptr, g, st);
+    HX_CHECK(hipGetLastError());
+    return 0;
+  }
   const int variant = mode / 10;     // 0: BK 16, 1: BK 32
   mode %= 10;
 #define HX_DISPATCH(BKV)                                                                                   \
@@ -824,13 +882,18 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
   HX_CHECK(hipMemset(X, 0x3d, nx * 4)); HX_CHECK(hipMemset(W, 0x3c, nw * 4)); HX_CHECK(hipMemset(Y, 0x3b, ny * 4));
   hipStream_t st; HX_CHECK(hipStreamCreate(&st));
   hipEvent_t e0, e1; HX_CHECK(hipEventCreate(&e0)); HX_CHECK(hipEventCreate(&e1));
+  const bool bf16_bench = (bk == 200);
   const int bm = bk / 100 ? 64 : 128; bk %= 100;
   auto run = [&]() {
     GemmArgs g{};
 #define HX_V(BMV, BKV, AK, BKM, EPI) launch_gemm<BMV, 128, BKV, AK, BKM, EPI>(nullptr, g, st)
 #define HX_PICK(AK, BKM, EPI) do { if (bm == 128) { if (bk == 16) HX_V(128, 16, AK, BKM, EPI); else HX_V(128, 32, AK, BKM, EPI); } \
                                    else { if (bk == 16) HX_V(64, 16, AK, BKM, EPI); else HX_V(64, 32, AK, BKM, EPI); } } while (0)
-    if (kind == 0) { g.A = X; g.lda = in_ld; g.B = W; g.ldb = in_ld; g.C = Y; g.ldc = out; g.M = rows; g.N = out; g.K = in_ld; g.bias = bslab;
+    if (bf16_bench && kind == 0) { g.A = X; g.lda = in_ld; g.B = W; g.ldb = in_ld; g.C = Y; g.ldc = out; g.M = rows; g.N = out; g.K = in_ld; g.bias = bslab;
+      launch_gemm_bf16<EPI_BIAS_ELU>(nullptr, g, st); }
+    else if (bf16_bench && kind == 1) { g.A = Y; g.lda = out; g.B = W; g.ldb = out; g.C = X; g.ldc = in_ld; g.M = rows; g.N = in_ld; g.K = out; g.H = X; g.ldh = in_ld;
+      launch_gemm_bf16<EPI_ELU_GRAD>(nullptr, g, st); }      // W buffer read as W^T[in_ld][out]: same byte count
+    else if (kind == 0) { g.A = X; g.lda = in_ld; g.B = W; g.ldb = in_ld; g.C = Y; g.ldc = out; g.M = rows; g.N = out; g.K = in_ld; g.bias = bslab;
       HX_PICK(true, true, EPI_BIAS_ELU); }
     else if (kind == 1) { g.A = Y; g.lda = out; g.B = W; g.ldb = in_ld; g.C = X; g.ldc = in_ld; g.M = rows; g.N = in_ld; g.K = out; g.H = X; g.ldh = in_ld;
       HX_PICK(true, false, EPI_ELU_GRAD); }
@@ -1012,7 +1075,27 @@ static int download_flat(hx_ppo* s, const float* src, float* flat) {
   unpack_padded(s, pad, flat);
   return 0;
 }
-extern "C" int hx_ppo_set_params_h(hx_ppo* s, const float* flat) { return upload_flat(s, s->params, flat); }
+extern "C" int hx_ppo_set_params_h(hx_ppo* s, const float* flat) {
+  const int rc = upload_flat(s, s->params, flat);
+  if (rc == 0) refresh_transposes(s, s->stream);
+  return rc;
+}
+
+extern "C" int hx_ppo_set_compute_dtype(hx_ppo* s, int dtype) {
+  if (dtype != 0 && dtype != 1) { hx_set_error("hx_ppo_set_compute_dtype: 0 = f32, 1 = bf16 forward/dgrad"); return -2; }
+  if (dtype == 1 && s->wT[1] == nullptr) {
+    for (int net = 0; net < 2; ++net)
+      for (int l = 1; l <= 2; ++l) {
+        const Layer& L = s->L[net * 4 + l];
+        if (L.in_ld % 4 != 0 || L.out % 4 != 0) { hx_set_error("bf16 mode needs hidden widths that are multiples of 4"); return -2; }
+        int rc = palloc(s, &s->wT[net * 4 + l], (size_t)L.in_ld * L.out); if (rc) return rc;
+      }
+  }
+  s->bf16 = (dtype == 1);
+  refresh_transposes(s, s->stream);
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
 extern "C" int hx_ppo_get_params_h(hx_ppo* s, float* flat) { return download_flat(s, s->params, flat); }
 extern "C" int hx_ppo_set_opt_state_h(hx_ppo* s, const float* m, const float* v, int64_t step) {
   int rc = upload_flat(s, s->m, m); if (rc) return rc;
@@ -1026,13 +1109,13 @@ extern "C" int hx_ppo_get_opt_state_h(hx_ppo* s, float* m, float* v, int64_t* st
 }
 
 // hidden layers of one network: X[M][ld] -> act[0..2]
-static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr) {
+static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr, bool fp32_only = false) {
   const Layer* L = s->L + net * 4;
   const bool bg = (st != nullptr && st == s->stream2);
   if (!st) st = s->stream;
-  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld, bg);
-  gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld, bg);
-  gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld, bg);
+  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld, bg, fp32_only);
+  gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld, bg, fp32_only);
+  gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld, bg, fp32_only);
 }
 
 #ifndef HX_CRITIC_CHUNK
@@ -1092,14 +1175,14 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
                          s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,
                          s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
     } else {
-      mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
+      mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st, true);
       hipLaunchKernelGGL(hx_actor_head_kernel, dim3((count + 15) / 16), dim3(256), A * hw * sizeof(float), st, aa[2], hw,
                          s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
                          s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
     }
     if (t + 1 - s->crit_done >= HX_CRITIC_CHUNK) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
   } else {
-    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
+    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st, true);
     mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);
     hipLaunchKernelGGL(hx_act_head_kernel, dim3((count + 15) / 16), dim3(256), (A + 1) * hw * sizeof(float), st,
                        aa[2], ac[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
@@ -1241,7 +1324,7 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       k = ++rt.nseg;
       rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (L[l].out + 255) / 256;
       ++rt.nseg;
-      if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out);
+      if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out, s->wT[net * 4 + l]);
     }
   }
   rt.block0[rt.nseg] = blocks;
@@ -1264,6 +1347,7 @@ extern "C" int hx_ppo_minibatch_step(hx_ppo* s, float inv_world) {
   const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)s->adam_t));
   hipLaunchKernelGGL(hx_adam_kernel, dim3((unsigned)((s->padded + 255) / 256)), dim3(256), 0, st, s->params, s->grads, s->m, s->v, s->padded,
                      inv_world, s->sumsq, c.max_grad_norm, s->sched, bc1, bc2s);
+  refresh_transposes(s, st);
   HX_CHECK(hipGetLastError());
   s->mb_done += 1;
   return 0;
@@ -1318,7 +1402,7 @@ extern "C" int hx_ppo_set_lr(hx_ppo* s, float lr) {
 
 extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* out) {
   if (rows > s->Mmax) { hx_set_error("hx_ppo_inference: rows > workspace"); return -2; }
-  mlp_hidden_fwd(s, 0, obs, s->cfg.obs_ld, rows, s->act_a);
+  mlp_hidden_fwd(s, 0, obs, s->cfg.obs_ld, rows, s->act_a, nullptr, true);
   const int A = s->cfg.num_actions;
   hipLaunchKernelGGL(hx_mean_head_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, s->stream, s->act_a[2], s->cfg.actor_hidden[2],
                      s->params + s->L[3].w, s->params + s->L[3].b, rows, A, out);

@@ -26,24 +26,37 @@ def elu(z):
     return np.where(z > 0, z, np.expm1(np.minimum(z, 0))).astype(F)
 
 
+def bf16_round(x):
+    """fp32 -> bf16 (round to nearest even) -> fp32: the rounding the product's bf16 mode applies to the operands of its
+    hidden-layer forward and dgrad products (no reference counterpart -- the reference is fp32; BASELINE config 4)."""
+    u = np.ascontiguousarray(x, F).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(F)
+
+
 class MLP:
-    """weights[i]: [out,in] (torch nn.Linear layout), biases[i]: [out]."""
+    """weights[i]: [out,in] (torch nn.Linear layout), biases[i]: [out].
+    bf16=True emulates the product's mixed-precision mode: operands of the HIDDEN layers' forward products and of the
+    dgrads through hidden layers are rounded to bf16, accumulation / bias / ELU / output layer / wgrads stay fp32."""
 
     def __init__(self, weights, biases):
         self.W = [np.asarray(w, F).copy() for w in weights]
         self.b = [np.asarray(b, F).copy() for b in biases]
 
-    def forward(self, x, keep=False):
+    def forward(self, x, keep=False, bf16=False):
         hs = [np.asarray(x, F)]
         h = hs[0]
         L = len(self.W)
         for i in range(L):
-            z = (h @ self.W[i].T + self.b[i]).astype(F)
+            if bf16 and i < L - 1:
+                z = (bf16_round(h) @ bf16_round(self.W[i]).T + self.b[i]).astype(F)
+            else:
+                z = (h @ self.W[i].T + self.b[i]).astype(F)
             h = elu(z) if i < L - 1 else z
             hs.append(h)
         return (h, hs) if keep else h
 
-    def backward(self, hs, dout):
+    def backward(self, hs, dout, bf16=False):
         """dout = dLoss/d(output).  Returns (dW list, db list)."""
         L = len(self.W)
         dW, db = [None] * L, [None] * L
@@ -52,7 +65,10 @@ class MLP:
             dW[i] = (dz.T @ hs[i]).astype(F)
             db[i] = dz.sum(0).astype(F)
             if i > 0:
-                dh = (dz @ self.W[i]).astype(F)
+                if bf16 and i < L - 1:
+                    dh = (bf16_round(dz) @ bf16_round(self.W[i])).astype(F)
+                else:
+                    dh = (dz @ self.W[i]).astype(F)
                 h = hs[i]
                 dz = (dh * np.where(h > 0, F(1), h + F(1))).astype(F)
         return dW, db
@@ -104,14 +120,17 @@ class ActorCriticOracle:
         var = sigma * sigma
         return np.sum(-((a - mu) ** 2) / (F(2) * var) - np.log(sigma) - LOG_SQRT_2PI, -1).astype(F)
 
-    def evaluate(self, priv):
-        return self.critic.forward(priv)
+    def evaluate(self, priv, bf16=False):
+        return self.critic.forward(priv, bf16=bf16)
 
 
 class PPOOracle:
     def __init__(self, ac, num_envs, num_steps, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2,
                  gamma=0.994, lam=0.9, value_loss_coef=1.0, entropy_coef=0.001, learning_rate=1e-5,
-                 max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01):
+                 max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, bf16=False):
+        """bf16=True: emulate the product's mixed-precision mode (hx_ppo_set_compute_dtype 1): critic forwards and the
+        update's forward / dgrad products through hidden layers use bf16-rounded operands; the rollout actor is fp32."""
+        self.bf16 = bf16
         self.ac = ac
         self.N, self.T = num_envs, num_steps
         self.epochs, self.nmb = num_learning_epochs, num_mini_batches
@@ -146,7 +165,7 @@ class PPOOracle:
     # ---- rollout side (ppo.py:91-113)
     def act(self, obs, priv, eps):
         a, mu, sigma = self.ac.act(obs, eps)
-        v = self.ac.evaluate(priv)[:, 0]
+        v = self.ac.evaluate(priv, bf16=self.bf16)[:, 0]
         self._tr = dict(obs=np.asarray(obs, F), priv=np.asarray(priv, F), a=a, v=v,
                         logp=self.ac.log_prob(a, mu, sigma), mu=mu, sigma=sigma)
         return a
@@ -165,7 +184,7 @@ class PPOOracle:
 
     # ---- GAE (rollout_storage.py:122-136)
     def compute_returns(self, last_priv):
-        last_values = self.ac.evaluate(last_priv)[:, 0]
+        last_values = self.ac.evaluate(last_priv, bf16=self.bf16)[:, 0]
         adv = np.zeros(self.N, F)
         for s in reversed(range(self.T)):
             nv = last_values if s == self.T - 1 else self.values[s + 1]
@@ -189,10 +208,10 @@ class PPOOracle:
         logp_old, adv = flat(self.logp)[idx], flat(self.advantages)[idx]
         mu_old, sig_old = flat(self.mu)[idx], flat(self.sigma)[idx]
 
-        mu, hs_a = ac.actor.forward(obs, keep=True)
+        mu, hs_a = ac.actor.forward(obs, keep=True, bf16=self.bf16)
         sigma = (mu * F(0) + ac.std).astype(F)
         logp = ac.log_prob(a, mu, sigma)
-        v, hs_c = ac.critic.forward(priv, keep=True)
+        v, hs_c = ac.critic.forward(priv, keep=True, bf16=self.bf16)
         v = v[:, 0]
         entropy = np.sum(F(0.5) + LOG_SQRT_2PI + np.log(sigma), -1).astype(F)
 
@@ -223,8 +242,8 @@ class PPOOracle:
         dmu = (dlogp[:, None] * (a - mu) / (sigma * sigma)).astype(F)
         dsig = dlogp[:, None] * ((a - mu) ** 2 / sigma ** 3 - F(1) / sigma) - self.ecoef / (F(M) * sigma)
         dstd = dsig.sum(0).astype(F)
-        dWa, dba = ac.actor.backward(hs_a, dmu)
-        dWc, dbc = ac.critic.backward(hs_c, dv[:, None])
+        dWa, dba = ac.actor.backward(hs_a, dmu, bf16=self.bf16)
+        dWc, dbc = ac.critic.backward(hs_c, dv[:, None], bf16=self.bf16)
         grads = [dstd]
         for dW, db in ((dWa, dba), (dWc, dbc)):
             for x, y in zip(dW, db):

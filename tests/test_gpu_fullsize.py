@@ -118,3 +118,50 @@ def test_full_size_update_matches_oracle(hxlib):
         assert d.max() <= 4 * 2.0 * 1e-2 * 1e-2 + 8 * orc.lr, (k, d.max())      # at most lr-sized noise per Adam step
         assert np.mean(d > 5e-6) < 2e-3, (k, float(np.mean(d > 5e-6)))
     alg.close()
+
+
+def test_bf16_mode_matches_emulating_oracle(hxlib):
+    """BASELINE config 4 (hx_ppo_set_compute_dtype 1): N = 4096, T = 16, 4 minibatches of 16 384 rows.  The oracle rounds
+    the operands of the same products to bf16 (oracle/ppo.py bf16=True).  What remains is fp32 summation order PLUS the
+    occasional activation that sits on a bf16 rounding boundary and rounds the other way in the next layer (one such
+    flip moves a value by ~1e-4): values 1e-3, advantages 5e-3, losses 2e-3 relative.  Against the fp32 oracle the
+    values differ by O(1e-2), i.e. the mode really is bf16."""
+    from oracle.ppo import ActorCriticOracle, PPOOracle
+    seed, Tb = 12, 16
+    init = ActorCriticOracle.default_init(np.random.default_rng(seed))
+    ac = ActorCritic(615, 1050, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[768, 256, 128], init_noise_std=1.0)
+    ac.load_state_dict(init.state_dict())
+    kw = dict(num_learning_epochs=1, num_mini_batches=4, learning_rate=1e-4)
+    alg = PPO(ac, clip_param=0.2, gamma=0.994, lam=0.9, value_loss_coef=1.0, entropy_coef=0.001, max_grad_norm=1.0,
+              use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, mlp_dtype="bf16", **kw)
+    alg.init_storage(N, Tb, [615], [1050], [10])
+    orc = PPOOracle(ActorCriticOracle.default_init(np.random.default_rng(seed)), N, Tb, bf16=True, **kw)
+    ref32 = ActorCriticOracle.default_init(np.random.default_rng(seed))
+    rng = np.random.default_rng(4)
+    for t in range(Tb):
+        o = rng.standard_normal((N, 615)).astype(np.float32)
+        p = rng.standard_normal((N, 1050)).astype(np.float32)
+        e = rng.standard_normal((N, 10)).astype(np.float32)
+        a = alg.act(o, p, eps=e).numpy()
+        np.testing.assert_allclose(a, orc.act(o, p, e), rtol=0, atol=1e-4)          # rollout actor stays fp32
+        r = rng.uniform(0, 0.05, N).astype(np.float32)
+        d = rng.uniform(size=N) < 0.02
+        alg.process_env_step(r, d.astype(np.uint8), {"time_outs": np.zeros(N, np.uint8)})
+        orc.process_env_step(r, d, np.zeros(N, bool))
+    alg.compute_returns(p)
+    orc.compute_returns(p)
+    vals = alg.buffer(1, (Tb, N)).numpy()
+    np.testing.assert_allclose(vals, orc.values, rtol=0, atol=1e-3)
+    v32 = ref32.evaluate(p)[:, 0]
+    assert 1e-4 < np.abs(vals[-1] - v32).max() < 5e-2                               # bf16, not fp32
+    np.testing.assert_allclose(alg.buffer(6, (Tb, N)).numpy(), orc.advantages, rtol=0, atol=5e-3)
+    perm = np.random.default_rng(3).permutation(Tb * N).astype(np.int32)
+    vl, sl = alg.update(perm=perm)
+    vl2, sl2 = orc.update(perm)
+    assert abs(vl - vl2) < 2e-3 * max(1.0, abs(vl2)) and abs(sl - sl2) < 2e-3, (vl, vl2, sl, sl2)
+    assert abs(alg.learning_rate / orc.lr - 1) < 1e-6
+    sd = ac.state_dict()
+    for k, v in orc.ac.state_dict().items():
+        d = np.abs(sd[k] - v)
+        assert np.mean(d > 5e-5) < 2e-2, (k, float(np.mean(d > 5e-5)), d.max())
+    alg.close()

@@ -83,3 +83,49 @@ def test_gemm_modes_bk32(hxlib, mode, M, N, K):
     real = hxlib.hx_ppo_gemm_test
     shim = types.SimpleNamespace(hx_ppo_gemm_test=lambda m, *a: real(m + 10, *a))
     _run(shim, mode - 10, M, N, K, np.random.default_rng(mode + M + N + K))
+
+
+# ---------------------------------------------------------------------------------------------- bf16-input kernels
+def _bf16_round(x):
+    """fp32 -> bf16 round-to-nearest-even -> fp32 (what v_cvt_pk_bf16_f32 does), in numpy."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+@pytest.mark.parametrize("mode,M,N,K", [(5, 256, 256, 64), (5, 4096, 512, 616), (5, 1000, 768, 1052), (5, 61, 130, 20),
+                                        (6, 512, 256, 128), (6, 1000, 512, 256), (6, 33, 132, 8)])
+def test_bf16_gemm_modes(hxlib, mode, M, N, K):
+    """hx_gemm_bf16.h: operands rounded to bf16 (RNE) on load, fp32 accumulation.  Against float64 numpy on the
+    SAME rounded operands the only difference is fp32 summation order: same bound as the fp32 kernels."""
+    rng = np.random.default_rng(M + N + K)
+    if mode == 5:           # forward: Y = elu(X W^T + b), X [M][K], W [N][K]
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32)
+        z = _bf16_round(A).astype(np.float64) @ _bf16_round(B).astype(np.float64).T + bias
+        ref = np.where(z > 0, z, np.expm1(np.minimum(z, 0)))
+        H = None
+    else:                   # dgrad: dX = (dZ W) * elu'(H), dZ [M][K], W^T given K-major as [N][K]
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        H = rng.standard_normal((M, N)).astype(np.float32)
+        H = np.where(H > 0, H, np.expm1(np.minimum(H, 0))).astype(np.float32)
+        bias = None
+        ref = (_bf16_round(A).astype(np.float64) @ _bf16_round(B).astype(np.float64).T) * np.where(H > 0, 1.0, H.astype(np.float64) + 1.0)
+    dA, dB = capi.DeviceBuffer.from_host(A), capi.DeviceBuffer.from_host(B)
+    dC = capi.DeviceBuffer(M * N * 4)
+    dbias = capi.DeviceBuffer.from_host(bias) if bias is not None else None
+    dH = capi.DeviceBuffer.from_host(H) if H is not None else None
+    capi.check(hxlib.hx_ppo_gemm_test(mode, M, N, K, dA.ptr, K, dB.ptr, K, dbias.ptr if dbias else None, dC.ptr, N,
+                                      dH.ptr if dH else None, None), "gemm_test")
+    out = dC.download(np.float32, (M, N))
+    scale = np.abs(ref).max() + 1.0
+    err = np.abs(out - ref).max()
+    assert err <= 5e-5 * scale * max(1.0, np.sqrt(K) / 16), (mode, M, N, K, err, scale)
+    # and the rounding itself is the bf16 one: against the unrounded product the error is ~2^-9 relative per operand
+    if mode == 5:
+        z32 = A.astype(np.float64) @ B.astype(np.float64).T + bias
+        full = np.where(z32 > 0, z32, np.expm1(np.minimum(z32, 0)))
+        rel = np.abs(out - full).max() / scale
+        assert 1e-5 < rel < 2e-2, rel
