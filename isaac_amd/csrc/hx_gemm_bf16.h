@@ -159,3 +159,155 @@ __global__ void __launch_bounds__(256) hx_gemm_bf16_kernel(GemmArgs g) {
       }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-gradient product in the same mixed precision:  dW[M,N] = A[K,M]^T B[K,N]  (split-K, partial slabs)
+//   A = dZ [rows][out]  (M-major),  B = X [rows][in]  (N-major), both fp32 in HBM, K = sample rows.
+// The 32x32x16 operand wants 8 k-values of ONE row per lane, but here k is the slow index of both operands.  A dot
+// product does not care in which order its k terms are visited, so the LDS image packs k PAIRS: word [p][m] holds
+// (bf16 x[2p][m], bf16 x[2p+1][m]).  A thread that loaded the 4(k) x 4(m) block {4kb .. 4kb+3} x {4mb .. 4mb+3}
+// (four coalesced float4 loads) owns two complete rows of four words and stores them with two ds_write_b128 --
+// consecutive lanes write consecutive 16 bytes -- and a lane's fragment for MFMA step s is the four words
+// [8s + 4h + q][row], q = 0..3 (two ds_read2_b32, consecutive lanes read consecutive words): no bank conflicts on
+// either side, and A and B use the same k <-> (lane half, element) assignment.
+// The bias gradient (column sums of dZ) is accumulated from the fp32 staging registers, not from the rounded tile.
+__global__ void __launch_bounds__(256) hx_wgrad_bf16_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BKP = HXB_BK / 2;            // BKP = k pairs per tile
+  constexpr int OPW = BKP * BM;                                  // words per operand tile
+  __shared__ __attribute__((aligned(16))) unsigned lds[2 * 2 * OPW];     // 2 buffers x (A, B) = 64 KB
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  int logical;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+  const int split = logical / tiles_mn;
+  const int t = logical % tiles_mn;
+  const int tile_m = t / g.tiles_n, tile_n = t % g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_begin = split * g.kchunk, k_end = min(g.K, k_begin + g.kchunk);
+  const int nk = (k_end - k_begin + HXB_BK - 1) / HXB_BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, r32 = lane & 31;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[2][4], rb[2][4];                       // [block][k offset 0..3]
+  const bool want_db = (g.dbias != nullptr) && (tile_n == 0);
+  f32x4 dbacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+  auto load_tile = [&](int kt) {
+    const int k0 = k_begin + kt * HXB_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int kb = idx >> 5, mb = idx & 31;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gk = k0 + 4 * kb + j;
+        f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+        if (gk < k_end && m0 + 4 * mb < g.M) va = *reinterpret_cast<const f32x4*>(g.A + (size_t)gk * g.lda + m0 + 4 * mb);
+        if (gk < k_end && n0 + 4 * mb < g.N) vb = *reinterpret_cast<const f32x4*>(g.B + (size_t)gk * g.ldb + n0 + 4 * mb);
+        ra[i][j] = va; rb[i][j] = vb;
+      }
+    }
+  };
+  auto pack = [](float lo, float hi) -> unsigned {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = {(__bf16)lo, (__bf16)hi};
+    return *reinterpret_cast<const unsigned*>(&p);
+  };
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto store_tile = [&](int buf) {
+    unsigned* As = lds + buf * 2 * OPW;
+    unsigned* Bs = As + OPW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int kb = idx >> 5, mb = idx & 31;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const f32x4 a0 = ra[i][2 * pr], a1 = ra[i][2 * pr + 1], b0 = rb[i][2 * pr], b1 = rb[i][2 * pr + 1];
+        const u32x4 wa = {pack(a0[0], a1[0]), pack(a0[1], a1[1]), pack(a0[2], a1[2]), pack(a0[3], a1[3])};
+        const u32x4 wb = {pack(b0[0], b1[0]), pack(b0[1], b1[1]), pack(b0[2], b1[2]), pack(b0[3], b1[3])};
+        *reinterpret_cast<u32x4*>(As + (2 * kb + pr) * BM + 4 * mb) = wa;
+        *reinterpret_cast<u32x4*>(Bs + (2 * kb + pr) * BN + 4 * mb) = wb;
+      }
+      if (want_db) dbacc[i] = dbacc[i] + ((ra[i][0] + ra[i][1]) + (ra[i][2] + ra[i][3]));
+    }
+  };
+  auto compute = [&](int buf) {
+    const unsigned* As = lds + buf * 2 * OPW;
+    const unsigned* Bs = As + OPW;
+#pragma unroll
+    for (int s = 0; s < HXB_BK / 16; ++s) {
+      union Frag { unsigned w[4]; bf16x8 v; } fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          fa[i].w[q] = As[(8 * s + 4 * h + q) * BM + wm * 64 + i * 32 + r32];
+          fb[i].w[q] = Bs[(8 * s + 4 * h + q) * BN + wn * 64 + i * 32 + r32];
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a].v, fb[b].v, acc[a][b], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const bool more = (kt + 1 < nk);
+      if (more) load_tile(kt + 1);
+      compute(kt & 1);
+      if (more) store_tile((kt + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: partial slab of this split (fp32), same C/D layout as every other kernel here
+  float* Cb = g.C + (size_t)split * g.M * g.ldc;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = n0 + wn * 64 + b * 32 + r32;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < g.M) Cb[(size_t)row * g.ldc + col] = acc[a][b][e];
+      }
+    }
+  if (want_db) {
+    // 16 threads (the kb groups) hold partial sums for the same four columns: reduce through LDS, fixed order
+    float* red = reinterpret_cast<float*>(lds);          // [16][128]; all tile reads are behind the last barrier
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int kb = idx >> 5, mb = idx & 31;
+      *reinterpret_cast<f32x4*>(red + kb * BM + 4 * mb) = dbacc[i];
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M) {
+      float sum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) sum += red[kb * BM + tid];
+      g.dbias[(size_t)split * g.M + m0 + tid] = sum;
+    }
+  }
+}

@@ -827,7 +827,21 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   if (splits > max_splits) splits = max_splits;
   int kchunk = rup((Mrows + splits - 1) / splits, 32);
   splits = (Mrows + kchunk - 1) / kchunk;
+  if (s->bf16) {                        // K chunks in whole 64-deep tiles for the bf16 kernel
+    kchunk = rup(kchunk, 64);
+    splits = (Mrows + kchunk - 1) / kchunk;
+  }
   g.splits = splits; g.kchunk = kchunk; g.dbias = bias_slab;
+  if (s->bf16) {
+    g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
+    const int blocks = g.tiles_m * g.tiles_n * g.splits;
+    if (s->prof) { while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); } }
+    const bool timed = s->prof && s->ev_used + 2 <= s->ev.size();
+    if (timed) (void)hipEventRecord(s->ev[s->ev_used], st);
+    hipLaunchKernelGGL(hx_wgrad_bf16_kernel, dim3(blocks), dim3(256), 0, st, g);
+    if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], st); s->ev_kid[s->ev_used] = 4; s->ev_used += 2; s->prof_flops[4] += 2.0 * g.M * g.N * g.K; s->prof_launches[4] += 1; }
+    return splits;
+  }
   launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
   return splits;
 }
@@ -837,6 +851,13 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.H = H; g.ldh = ldc;
+  if (mode == 7) {                   // bf16 wgrad, single split, direct output; column sums of A -> `bias`
+    g.splits = 1; g.kchunk = rup(K, 64); g.dbias = const_cast<float*>(bias);
+    g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
+    hipLaunchKernelGGL(hx_wgrad_bf16_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st, g);
+    HX_CHECK(hipGetLastError());
+    return 0;
+  }
   if (mode == 5 || mode == 6) {      // bf16-input kernels: 5 = forward (bias + ELU), 6 = dgrad with B = W^T given K-major
     if (mode == 5) launch_gemm_bf16<EPI_BIAS_ELU>(nullptr, g, st); else launch_gemm_bf16<EPI_ELU_GRAD>(nullptr, g, st);
     HX_CHECK(hipGetLastError());

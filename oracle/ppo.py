@@ -37,7 +37,7 @@ def bf16_round(x):
 class MLP:
     """weights[i]: [out,in] (torch nn.Linear layout), biases[i]: [out].
     bf16=True emulates the product's mixed-precision mode: operands of the HIDDEN layers' forward products and of the
-    dgrads through hidden layers are rounded to bf16, accumulation / bias / ELU / output layer / wgrads stay fp32."""
+    dgrads / wgrads of hidden layers are rounded to bf16; accumulation, bias (and its gradient), ELU and the output layer stay fp32."""
 
     def __init__(self, weights, biases):
         self.W = [np.asarray(w, F).copy() for w in weights]
@@ -62,8 +62,11 @@ class MLP:
         dW, db = [None] * L, [None] * L
         dz = np.asarray(dout, F)
         for i in range(L - 1, -1, -1):
-            dW[i] = (dz.T @ hs[i]).astype(F)
-            db[i] = dz.sum(0).astype(F)
+            if bf16 and i < L - 1:
+                dW[i] = (bf16_round(dz).T @ bf16_round(hs[i])).astype(F)     # hidden-layer wgrads: rounded operands
+            else:
+                dW[i] = (dz.T @ hs[i]).astype(F)
+            db[i] = dz.sum(0).astype(F)                                      # bias gradients stay exact fp32 sums
             if i > 0:
                 if bf16 and i < L - 1:
                     dh = (bf16_round(dz) @ bf16_round(self.W[i])).astype(F)

@@ -129,3 +129,21 @@ def test_bf16_gemm_modes(hxlib, mode, M, N, K):
         full = np.where(z32 > 0, z32, np.expm1(np.minimum(z32, 0)))
         rel = np.abs(out - full).max() / scale
         assert 1e-5 < rel < 2e-2, rel
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 616, 2048), (768, 1052, 1000), (128, 256, 960), (100, 36, 77)])
+def test_bf16_wgrad(hxlib, M, N, K):
+    """hx_wgrad_bf16_kernel: dW[M][N] = round_bf16(dZ[K][M])^T round_bf16(X[K][N]) with fp32 accumulation (k-pair packed
+    LDS image); the bias gradient (column sums of dZ) comes from the unrounded fp32 values."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    ref = _bf16_round(A).astype(np.float64).T @ _bf16_round(B).astype(np.float64)
+    dA, dB = capi.DeviceBuffer.from_host(A), capi.DeviceBuffer.from_host(B)
+    dC = capi.DeviceBuffer(M * N * 4)
+    dbias = capi.DeviceBuffer.from_host(np.zeros(M, np.float32))
+    capi.check(hxlib.hx_ppo_gemm_test(7, M, N, K, dA.ptr, M, dB.ptr, N, dbias.ptr, dC.ptr, N, None, None), "gemm_test")
+    out = dC.download(np.float32, (M, N))
+    scale = np.abs(ref).max() + 1.0
+    assert np.abs(out - ref).max() <= 5e-5 * scale * max(1.0, np.sqrt(K) / 16)
+    np.testing.assert_allclose(dbias.download(np.float32, (M,)), A.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.sqrt(K))
