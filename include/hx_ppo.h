@@ -65,10 +65,11 @@ int hx_ppo_set_opt_state_h(hx_ppo* p, const float* exp_avg_h, const float* exp_a
 int hx_ppo_get_opt_state_h(hx_ppo* p, float* exp_avg_h, float* exp_avg_sq_h, int64_t* step);
 /* Precision of the learner's dense products (no reference counterpart: the reference is fp32 throughout).
  *   0  fp32 on v_mfma_f32_32x32x2_f32 everywhere (default; the configuration the parity tests and bench.py use)
- *   1  BASELINE config 4, "bf16 MLP on MFMA": forward and input-gradient (dgrad) products of batches >= 16 384 rows
- *      round their fp32 operands to bf16 on the way into LDS and run on v_mfma_f32_32x32x16_bf16 with fp32
- *      accumulation; master weights, Adam, the weight-gradient products, the loss head and the 4096-row rollout actor
- *      stay fp32.  The learner then keeps fp32 transposed copies of the hidden weights for the dgrads. */
+ *   1  BASELINE config 4, "bf16 MLP on MFMA": the forward, input-gradient and weight-gradient products of the hidden
+ *      layers round their fp32 operands to bf16 on the way into LDS and run on v_mfma_f32_32x32x16_bf16 with fp32
+ *      accumulation (the fused rollout actor rounds the same operands and keeps its fp32 MFMA, so rollout and update
+ *      agree); master weights, Adam, bias gradients, the output layers and the loss head stay fp32.  The learner then
+ *      keeps fp32 transposed copies of the hidden weights for the dgrads. */
 int hx_ppo_set_compute_dtype(hx_ppo* p, int dtype);
 
 int hx_ppo_act(hx_ppo* p, const float* obs, const float* priv, const float* eps /*[N][A], nullable*/, float** actions_out);

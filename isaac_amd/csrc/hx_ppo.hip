@@ -166,7 +166,12 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
 // hx_gemm.h a float4 per lane (k = 4*(l>>4) .. +3 of a 16-deep block) feeds 4 MFMAs.  C/D: col = l&15, row = 4*(l>>4)+reg.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define FA_ROWS 16
-template <int NT>   // NT = 16-column tiles per wave
+// operand rounding of the mixed-precision mode: fp32 -> bf16 (RNE) -> fp32, so that an fp32 MFMA on the rounded values
+// reproduces what the bf16 matrix cores compute in the update (up to summation order)
+__device__ __forceinline__ float hx_bf16r(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ f32x4v hx_bf16r4(f32x4v v) { return (f32x4v){hx_bf16r(v[0]), hx_bf16r(v[1]), hx_bf16r(v[2]), hx_bf16r(v[3])}; }
+
+template <int NT, bool BF, bool ROUND_OUT>   // NT = 16-column tiles per wave; BF: round the weight operand; ROUND_OUT: round what is stored
 __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                          const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane) {
   const int r16 = lane & 15, kq = lane >> 4;
@@ -187,7 +192,14 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
     for (int t = 0; t < NT; ++t) dst[t] = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
   };
-  auto step = [&](int kb, const f32x4v* bc) {
+  auto roundB = [&](f32x4v* b) {
+    if (BF) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b[t] = hx_bf16r4(b[t]);
+    }
+  };
+  auto step = [&](int kb, f32x4v* bc) {
+    roundB(bc);
     const int k = kb * 16 + 4 * kq;
     f32x4v a = {0.f, 0.f, 0.f, 0.f};
     if (k < K) a = *reinterpret_cast<const f32x4v*>(Xs + r16 * ldx + k);
@@ -211,10 +223,14 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
     const int col = n_wave0 + t * 16 + r16;
     const float bv = bias[col];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Hs[(kq * 4 + r) * ldh + col] = hx_elu(acc[t][r] + bv);
+    for (int r = 0; r < 4; ++r) {
+      const float o = hx_elu(acc[t][r] + bv);
+      Hs[(kq * 4 + r) * ldh + col] = ROUND_OUT ? hx_bf16r(o) : o;
+    }
   }
 }
 
+template <bool BF>
 __global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __restrict__ obs, int obs_ld, int n,
                                                              const float* __restrict__ W1, const float* __restrict__ b1, int K1, int N1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int N2,
@@ -236,14 +252,15 @@ __global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __rest
   for (int i = tid; i < FA_ROWS * (K1 / 4); i += 256) {
     const int r = i / (K1 / 4), c4 = i % (K1 / 4);
     const int gr = min(row0 + r, n - 1);
-    *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
+    const f32x4v v = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
+    *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = BF ? hx_bf16r4(v) : v;
   }
   __syncthreads();
-  fa_layer<8>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
+  fa_layer<8, BF, BF>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
   __syncthreads();
-  fa_layer<4>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
+  fa_layer<4, BF, BF>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
   __syncthreads();
-  fa_layer<2>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);       // 256 -> 128
+  fa_layer<2, BF, false>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);      // the head reads H3 unrounded, like the update's fp32 loss head       // 256 -> 128
   __syncthreads();
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]
   if (tid < FA_ROWS * A) {
@@ -793,7 +810,7 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   // workgroup leaves room for an env-step workgroup (34 KB) next to three of them on a CU; with the 74 KB BK32 tiles
   // the env-step kernel waited for LDS (440 us instead of 200 us on the steps a critic burst overlaps,
   // profiles/r01_j_rollout_interference.txt).
-  if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // critic forwards and the update's forwards; the rollout actor stays fp32
+  if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // every hidden-layer forward product in bf16 mode
   else if (background && M >= 16384) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
@@ -1039,7 +1056,8 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   for (int j = 0; j < A; ++j) sd[j] = cfg->init_noise_std;
   HX_CHECK(hipMemcpyAsync(s->params + s->std_off, sd.data(), sd.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
   s->prof = false; s->ev_used = 0;
@@ -1190,20 +1208,24 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
     if (fused_ok) {
       const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
-      hipLaunchKernelGGL(hx_actor_fused_kernel, dim3((count + FA_ROWS - 1) / FA_ROWS), dim3(256), shm, st, so, s->cfg.obs_ld, count,
-                         s->params + La[0].w, s->params + La[0].b, La[0].in_ld, La[0].out, s->params + La[1].w, s->params + La[1].b, La[1].out,
-                         s->params + La[2].w, s->params + La[2].b, La[2].out, s->params + La[3].w, s->params + La[3].b,
-                         s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,
-                         s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
+#define HX_FA_ARGS so, s->cfg.obs_ld, count, s->params + La[0].w, s->params + La[0].b, La[0].in_ld, La[0].out, s->params + La[1].w,          \
+                   s->params + La[1].b, La[1].out, s->params + La[2].w, s->params + La[2].b, La[2].out, s->params + La[3].w,              \
+                   s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,                     \
+                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0
+      // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
+      // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
+      if (s->bf16) hipLaunchKernelGGL(hx_actor_fused_kernel<true>, dim3((count + FA_ROWS - 1) / FA_ROWS), dim3(256), shm, st, HX_FA_ARGS);
+      else hipLaunchKernelGGL(hx_actor_fused_kernel<false>, dim3((count + FA_ROWS - 1) / FA_ROWS), dim3(256), shm, st, HX_FA_ARGS);
+#undef HX_FA_ARGS
     } else {
-      mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st, true);
+      mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
       hipLaunchKernelGGL(hx_actor_head_kernel, dim3((count + 15) / 16), dim3(256), A * hw * sizeof(float), st, aa[2], hw,
                          s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
                          s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
     }
     if (t + 1 - s->crit_done >= HX_CRITIC_CHUNK) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
   } else {
-    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st, true);
+    mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
     mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);
     hipLaunchKernelGGL(hx_act_head_kernel, dim3((count + 15) / 16), dim3(256), (A + 1) * hw * sizeof(float), st,
                        aa[2], ac[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
@@ -1423,7 +1445,7 @@ extern "C" int hx_ppo_set_lr(hx_ppo* s, float lr) {
 
 extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* out) {
   if (rows > s->Mmax) { hx_set_error("hx_ppo_inference: rows > workspace"); return -2; }
-  mlp_hidden_fwd(s, 0, obs, s->cfg.obs_ld, rows, s->act_a, nullptr, true);
+  mlp_hidden_fwd(s, 0, obs, s->cfg.obs_ld, rows, s->act_a);
   const int A = s->cfg.num_actions;
   hipLaunchKernelGGL(hx_mean_head_kernel, dim3((rows * A + 255) / 256), dim3(256), 0, s->stream, s->act_a[2], s->cfg.actor_hidden[2],
                      s->params + s->L[3].w, s->params + s->L[3].b, rows, A, out);

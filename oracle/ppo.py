@@ -113,8 +113,8 @@ class ActorCriticOracle:
                 d[f"{name}.{2 * i}.bias"] = b
         return d
 
-    def act(self, obs, eps):
-        mu = self.actor.forward(obs)
+    def act(self, obs, eps, bf16=False):
+        mu = self.actor.forward(obs, bf16=bf16)
         sigma = (mu * F(0) + self.std).astype(F)
         a = (mu + sigma * np.asarray(eps, F)).astype(F)
         return a, mu, sigma
@@ -131,8 +131,8 @@ class PPOOracle:
     def __init__(self, ac, num_envs, num_steps, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2,
                  gamma=0.994, lam=0.9, value_loss_coef=1.0, entropy_coef=0.001, learning_rate=1e-5,
                  max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.01, bf16=False):
-        """bf16=True: emulate the product's mixed-precision mode (hx_ppo_set_compute_dtype 1): critic forwards and the
-        update's forward / dgrad products through hidden layers use bf16-rounded operands; the rollout actor is fp32."""
+        """bf16=True: emulate the product's mixed-precision mode (hx_ppo_set_compute_dtype 1): every hidden-layer forward
+        (rollout actor and critic included), dgrad and wgrad product uses bf16-rounded operands."""
         self.bf16 = bf16
         self.ac = ac
         self.N, self.T = num_envs, num_steps
@@ -167,7 +167,7 @@ class PPOOracle:
 
     # ---- rollout side (ppo.py:91-113)
     def act(self, obs, priv, eps):
-        a, mu, sigma = self.ac.act(obs, eps)
+        a, mu, sigma = self.ac.act(obs, eps, bf16=self.bf16)
         v = self.ac.evaluate(priv, bf16=self.bf16)[:, 0]
         self._tr = dict(obs=np.asarray(obs, F), priv=np.asarray(priv, F), a=a, v=v,
                         logp=self.ac.log_prob(a, mu, sigma), mu=mu, sigma=sigma)

@@ -143,7 +143,7 @@ def test_bf16_mode_matches_emulating_oracle(hxlib):
         p = rng.standard_normal((N, 1050)).astype(np.float32)
         e = rng.standard_normal((N, 10)).astype(np.float32)
         a = alg.act(o, p, eps=e).numpy()
-        np.testing.assert_allclose(a, orc.act(o, p, e), rtol=0, atol=1e-4)          # rollout actor stays fp32
+        np.testing.assert_allclose(a, orc.act(o, p, e), rtol=0, atol=1e-3)          # rollout actor rounds like the update
         r = rng.uniform(0, 0.05, N).astype(np.float32)
         d = rng.uniform(size=N) < 0.02
         alg.process_env_step(r, d.astype(np.uint8), {"time_outs": np.zeros(N, np.uint8)})

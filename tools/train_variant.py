@@ -12,12 +12,14 @@ env_cfg, train_cfg = task_registry.get_cfgs("hector")
 for kv in sys.argv[3:]:
     k, v = kv.split("=")
     obj = env_cfg
+    if k.startswith("train."):            # e.g. train.algorithm.mlp_dtype=bf16
+        obj, k = train_cfg, k[len("train."):]
     parts = k.split(".")
     for p in parts[:-1]:
         obj = getattr(obj, p)
-    old = getattr(obj, parts[-1])
+    old = getattr(obj, parts[-1], "")
     setattr(obj, parts[-1], type(old)(eval(v)) if not isinstance(old, str) else v)
     print("override", k, "=", getattr(obj, parts[-1]))
 env, _ = task_registry.make_env(name="hector", args=args, env_cfg=env_cfg)
-runner, train_cfg = task_registry.make_alg_runner(env=env, name="hector", args=args)
+runner, train_cfg = task_registry.make_alg_runner(env=env, name=None, args=args, train_cfg=train_cfg)
 runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)
