@@ -28,7 +28,6 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_ENV_STEP = 16_772_066            # dense MLP flops, rollout 3 066 338 + update 13 705 728
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
-GEMM_KERNELS = ["fwd_128x128", "fwd_64x128", "dgrad_128x128", "dgrad_64x128", "wgrad_128x128_splitk"]
 
 
 def pmc_traffic(kernel_name):

@@ -572,15 +572,6 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   }
 }
 
-// dst[i] (+)= sum_s src[s][i]
-__global__ void hx_reduce_slabs_kernel(const float* __restrict__ src, int S, size_t count, size_t stride, float* dst, int accumulate) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += src[(size_t)k * stride + i];
-  dst[i] = accumulate ? dst[i] + s : s;
-}
-
 // stage 1 of the head-slab reduction: out[c][i] = sum of slabs [c*chunk, (c+1)*chunk) -- many workgroups
 __global__ void hx_slab_chunk_kernel(const float* __restrict__ slab, int S, int slab_w, int chunk, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
