@@ -165,3 +165,52 @@ def test_bf16_mode_matches_emulating_oracle(hxlib):
         d = np.abs(sd[k] - v)
         assert np.mean(d > 5e-5) < 2e-2, (k, float(np.mean(d > 5e-5)), d.max())
     alg.close()
+
+
+@pytest.mark.parametrize("n", [1, 33, 100])
+def test_ragged_batch_sizes(hxlib, n):
+    """Batch sizes that fill neither a wave (32 robots) nor a workgroup: the first n robots of a 128-robot batch,
+    simulated alone, give bit-identical observations / rewards / resets (lanes past the batch must not disturb it)."""
+    seed = 7
+    cr = _creation(seed, 128)
+    rng = np.random.default_rng(2)
+    acts = (0.6 * rng.standard_normal((8, 128, 10))).astype(np.float32)
+    ep = rng.integers(0, 2400, 128).astype(np.int32)
+    ep[:4] = 2397
+    full = _env(cr, 0, 128, seed)
+    ra = _roll(full, acts, ep)
+    full.close()
+    part = _env(cr, 0, n, seed)
+    rb = _roll(part, acts[:, :n], ep[:n])
+    part.close()
+    for (o1, p1, r1, d1), (o2, p2, r2, d2) in zip(ra, rb):
+        assert np.array_equal(o1[:n], o2) and np.array_equal(p1[:n], p2) and np.array_equal(r1[:n], r2) and np.array_equal(d1[:n], d2)
+
+
+def test_small_ragged_learner_runs(hxlib):
+    """N = 33 robots, T = 8, 3 minibatches of 88 rows: every learner kernel with row counts that are not multiples of
+    its tiles; compared with the oracle end to end."""
+    from oracle.ppo import ActorCriticOracle, PPOOracle
+    n, t = 33, 8
+    init = ActorCriticOracle.default_init(np.random.default_rng(3))
+    ac = ActorCritic(615, 1050, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[768, 256, 128], init_noise_std=1.0)
+    ac.load_state_dict(init.state_dict())
+    kw = dict(num_learning_epochs=2, num_mini_batches=3, learning_rate=1e-4)
+    alg = PPO(ac, gamma=0.994, lam=0.9, entropy_coef=0.001, schedule="adaptive", desired_kl=0.01, **kw)
+    alg.init_storage(n, t, [615], [1050], [10])
+    orc = PPOOracle(ActorCriticOracle.default_init(np.random.default_rng(3)), n, t, **kw)
+    rng = np.random.default_rng(8)
+    for _ in range(t):
+        o, p, e = rng.standard_normal((n, 615)).astype(np.float32), rng.standard_normal((n, 1050)).astype(np.float32), rng.standard_normal((n, 10)).astype(np.float32)
+        np.testing.assert_allclose(alg.act(o, p, eps=e).numpy(), orc.act(o, p, e), rtol=0, atol=5e-5)
+        r, d = rng.uniform(0, 0.05, n).astype(np.float32), rng.uniform(size=n) < 0.1
+        alg.process_env_step(r, d.astype(np.uint8), {})
+        orc.process_env_step(r, d)
+    alg.compute_returns(p)
+    orc.compute_returns(p)
+    np.testing.assert_allclose(alg.buffer(6, (t, n)).numpy(), orc.advantages, rtol=1e-4, atol=2e-4)
+    perm = rng.permutation(n * t).astype(np.int32)
+    vl, sl = alg.update(perm=perm)
+    vl2, sl2 = orc.update(perm)
+    assert abs(vl - vl2) < 1e-4 * max(1, abs(vl2)) and abs(sl - sl2) < 1e-4
+    alg.close()
