@@ -695,6 +695,7 @@ struct hx_ppo {
   // workspace
   int Mmax;
   float *obs_mb, *priv_mb, *row_mb;
+  float *obs_mb_all, *priv_mb_all, *row_mb_all; int mb_slots; unsigned long long mb_gathered;   // gathered rows kept per minibatch
   float *act_a[3], *act_c[3], *dz_a[3], *dz_c[3];
   float *slab, *bias_slab, *head_slab, *head_slab2; size_t slab_floats;
   size_t slab_off[8], bslab_off[8];     // per-layer regions so that all six wgrads finish before one reduce launch
@@ -1012,8 +1013,13 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   const int mbs = (int)(TN / cfg->num_mini_batches);
   s->Mmax = mbs > N ? mbs : N;
   const size_t Mm = s->Mmax;
-  rc |= palloc(s, &s->obs_mb, Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb, Mm * cfg->priv_ld);
-  rc |= palloc(s, &s->row_mb, Mm * (2 * A + 4));
+  // The reference reuses ONE permutation for every epoch (rollout_storage.py:149 draws it outside the epoch loop), so
+  // minibatch i holds the same rows in each epoch: with more than one epoch the gathered rows are kept per minibatch
+  // (a permuted copy of the rollout, 1.6 GB at 4096 envs) and gathered once per update instead of once per epoch.
+  s->mb_slots = (cfg->num_learning_epochs > 1 && cfg->num_mini_batches <= 64 && mbs >= N) ? cfg->num_mini_batches : 1;
+  rc |= palloc(s, &s->obs_mb_all, (size_t)s->mb_slots * Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, (size_t)s->mb_slots * Mm * cfg->priv_ld);
+  rc |= palloc(s, &s->row_mb_all, (size_t)s->mb_slots * Mm * (2 * A + 4));
+  s->obs_mb = s->obs_mb_all; s->priv_mb = s->priv_mb_all; s->row_mb = s->row_mb_all;
   for (int l = 0; l < 3; ++l) {
     rc |= palloc(s, &s->act_a[l], Mm * cfg->actor_hidden[l]); rc |= palloc(s, &s->dz_a[l], Mm * cfg->actor_hidden[l]);
     rc |= palloc(s, &s->act_c[l], Mm * cfg->critic_hidden[l]); rc |= palloc(s, &s->dz_c[l], Mm * cfg->critic_hidden[l]);
@@ -1301,6 +1307,7 @@ extern "C" int hx_ppo_update_begin(hx_ppo* s, const int32_t* perm) {
   // keep lr, clear the loss accumulators
   HX_CHECK(hipMemsetAsync(&s->sched->vloss_sum, 0, 2 * sizeof(float), s->stream));
   s->mb_done = 0;
+  s->mb_gathered = 0;
   s->mb_total = s->cfg.num_learning_epochs * s->cfg.num_mini_batches;
   (void)z;
   return 0;
@@ -1313,13 +1320,20 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   const int M = TN / c.num_mini_batches;
   const int mb = mb_index % c.num_mini_batches;       // the permutation is reused by every epoch (rollout_storage.py:149,165)
   hipStream_t st = s->stream;
-  GatherArgs ga{};
-  ga.idx = s->perm + (size_t)mb * M; ga.M = M;
-  ga.obs = s->s_obs; ga.obs_ld = c.obs_ld; ga.obs_mb = s->obs_mb;
-  ga.priv = s->s_priv; ga.priv_ld = c.priv_ld; ga.priv_mb = s->priv_mb;
-  ga.actions = s->s_actions; ga.mu = s->s_mu; ga.values = s->s_values; ga.returns = s->s_returns; ga.logp = s->s_logp; ga.adv = s->s_adv;
-  ga.A = A; ga.row_mb = s->row_mb;
-  hipLaunchKernelGGL(hx_gather_kernel, dim3(M), dim3(256), 0, st, ga);
+  const int slot = (s->mb_slots > 1) ? mb : 0;
+  s->obs_mb = s->obs_mb_all + (size_t)slot * s->Mmax * c.obs_ld;
+  s->priv_mb = s->priv_mb_all + (size_t)slot * s->Mmax * c.priv_ld;
+  s->row_mb = s->row_mb_all + (size_t)slot * s->Mmax * (2 * A + 4);
+  if (s->mb_slots == 1 || !((s->mb_gathered >> mb) & 1ull)) {
+    GatherArgs ga{};
+    ga.idx = s->perm + (size_t)mb * M; ga.M = M;
+    ga.obs = s->s_obs; ga.obs_ld = c.obs_ld; ga.obs_mb = s->obs_mb;
+    ga.priv = s->s_priv; ga.priv_ld = c.priv_ld; ga.priv_mb = s->priv_mb;
+    ga.actions = s->s_actions; ga.mu = s->s_mu; ga.values = s->s_values; ga.returns = s->s_returns; ga.logp = s->s_logp; ga.adv = s->s_adv;
+    ga.A = A; ga.row_mb = s->row_mb;
+    hipLaunchKernelGGL(hx_gather_kernel, dim3(M), dim3(256), 0, st, ga);
+    s->mb_gathered |= (1ull << mb);
+  }
   // forward
   mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a);
   mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c);
