@@ -596,13 +596,24 @@ __global__ void __launch_bounds__(256) hx_reduce_all_kernel(ReduceTable t) {
   int seg = 0;
 #pragma unroll
   for (int k = 1; k < HX_MAX_SEG; ++k) if (k < t.nseg && blockIdx.x >= t.block0[k]) seg = k;
-  const unsigned i = (blockIdx.x - t.block0[seg]) * 256u + threadIdx.x;
+  // four consecutive elements per thread (segment lengths are multiples of 4), four slabs in flight per step; the
+  // additions stay in slab order, so the sums are bit-identical to a one-element-at-a-time loop
+  const unsigned i = ((blockIdx.x - t.block0[seg]) * 256u + threadIdx.x) * 4u;
   if (i >= t.count[seg]) return;
-  const float* src = t.src[seg];
+  const float* src = t.src[seg] + i;
   const size_t stride = t.count[seg];
-  float s = 0.f;
-  for (int k = 0; k < t.S[seg]; ++k) s += src[(size_t)k * stride + i];
-  t.dst[seg][i] = s;
+  const int S = t.S[seg];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 4 <= S; k += 4) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 1) * stride);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 2) * stride);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (size_t)(k + 3) * stride);
+    s = s + v0; s = s + v1; s = s + v2; s = s + v3;
+  }
+  for (; k < S; ++k) s = s + *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
+  *reinterpret_cast<f32x4*>(t.dst[seg] + i) = s;
 }
 
 // scatter the head slab sums into the flat gradient buffer + statistics
@@ -948,6 +959,10 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
   if (cfg->num_actions > MAX_A) { hx_set_error("hx_ppo_create: num_actions > 16"); return -2; }
+  for (int l = 0; l < 3; ++l)
+    if (cfg->actor_hidden[l] % 4 != 0 || cfg->critic_hidden[l] % 4 != 0 || cfg->actor_hidden[l] <= 0 || cfg->critic_hidden[l] <= 0) {
+      hx_set_error("hx_ppo_create: hidden layer widths must be positive multiples of 4 (16-byte vector accesses)"); return -2;
+    }
   if (cfg->actor_hidden[2] != cfg->critic_hidden[2] || cfg->actor_hidden[2] % 64) { hx_set_error("hx_ppo_create: last hidden widths must match and be a multiple of 64"); return -2; }
   static_assert(HEAD_ROWS * 8 == 256, "loss head: 8 lanes per row");
   hx_ppo* s = new hx_ppo();
@@ -1368,9 +1383,9 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab);
       const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
       int k = rt.nseg;
-      rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 255) / 256;
+      rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
       k = ++rt.nseg;
-      rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (L[l].out + 255) / 256;
+      rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (L[l].out + 1023) / 1024;
       ++rt.nseg;
       if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out, s->wT[net * 4 + l]);
     }
