@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   float tau_leg[5];
   for (int j = 0; j < 5; ++j) tau_leg[j] = 0.f;
   LegForces F; F.base = mk(0, 0, 0); F.thigh = mk(0, 0, 0); F.toe = mk(0, 0, 0);
-  bool reset = false, time_out = false;
+  bool reset = false, time_out = false, blown = false;
   float rew_total = 0.f;
 
   if (A.mode == 0) {
@@ -223,6 +223,24 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
 #pragma unroll 1
     for (int sub = 0; sub < cfg.decimation; ++sub)
       dyn_substep(S, P, C, leg, target, kpl, kdl, tll, mass_scale, tau_leg, sub == cfg.decimation - 1, F);
+    // Blow-up guard (no reference counterpart; PhysX clamps internally).  A non-finite or runaway state would put NaNs
+    // into the observations and from there into every weight.  Such a robot is put back on its start pose with zero
+    // forces right here, so nothing downstream sees the bad numbers, and the step ends its episode as a fall.
+    {
+      float chk = S.pos.x + S.pos.y + S.pos.z + S.quat[0] + S.quat[1] + S.quat[2] + S.quat[3]
+                  + S.linvel.x + S.linvel.y + S.linvel.z + S.angvel.x + S.angvel.y + S.angvel.z;
+      for (int j = 0; j < 5; ++j) chk += S.q[j] + S.qd[j];
+      float bad = (fabsf(chk) < 1.0e6f) ? 0.f : 1.f;          // NaN fails the comparison
+      bad = fmaxf(bad, xchg(bad));
+      if (bad != 0.f) {
+        blown = true;
+        S.pos = mk(cfg.base_init_state[0] + LD(S_ORIGIN), cfg.base_init_state[1] + LD(S_ORIGIN + 1), cfg.base_init_state[2] + LD(S_ORIGIN + 2));
+        for (int k = 0; k < 4; ++k) S.quat[k] = cfg.base_init_state[3 + k];
+        S.linvel = mk(0, 0, 0); S.angvel = mk(0, 0, 0);
+        for (int j = 0; j < 5; ++j) { S.q[j] = cfg.default_dof_pos[leg * 5 + j]; S.qd[j] = 0.f; tau_leg[j] = 0.f; }
+        F.base = mk(0, 0, 0); F.thigh = mk(0, 0, 0); F.toe = mk(0, 0, 0);
+      }
+    }
   }
   // rigid_body_state of this leg's knee / foot (post-step pose; at construction: the actor creation pose)
   BodyOut bo[4];     // L_calf, L_toe, R_calf, R_toe
@@ -325,7 +343,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   if (A.mode == 0) {
     // ---- termination (legged_robot.py:155-160)
     const float nb = sqrtf(dot(f_base, f_base)), nl = sqrtf(dot(f_lthigh, f_lthigh)), nr = sqrtf(dot(f_rthigh, f_rthigh));
-    reset = (nb > 1.0f) || (nl > 1.0f) || (nr > 1.0f);
+    reset = (nb > 1.0f) || (nl > 1.0f) || (nr > 1.0f) || blown;
     time_out = (float)ep_len > cfg.max_episode_length;
     reset = reset || time_out;
 

@@ -234,3 +234,30 @@ def test_loaded_feet_rest_on_the_surface(hxlib):
     assert len(gaps) > 2000
     assert gaps.min() > -0.03 and 0.01 < np.median(gaps) < 0.06 and np.quantile(gaps, 0.95) < 0.10
     env.close()
+
+
+def test_blow_up_guard(hxlib):
+    """A robot whose physics state is non-finite (or absurd) is contained: that robot's episode ends this step, every
+    observation / reward stays finite, and the other robots are bit-identical to a run without the poisoned neighbours."""
+    fx = np.load(os.path.join(GOLD, "env_rollout_a.npz"))
+    outs = []
+    for poison in (False, True):
+        env, n, steps, sc0 = make_env(fx)
+        root, q, qd = env.get_state()
+        if poison:
+            root[3, 0] = np.nan
+            root[5, 7] = 3.0e9
+            qd[6, 2] = np.inf
+            env.set_state(root, q, qd)
+        rec = []
+        for t in range(3):
+            o, p, r, d, _ = env.step(fx["actions"][t], pack=fx["packs"][t + 1])
+            rec.append((o.numpy().copy(), p.numpy().copy(), r.numpy().copy(), d.numpy().copy()))
+        outs.append(rec)
+        env.close()
+    clean, bad = outs
+    assert bad[0][3][[3, 5, 6]].all() and not clean[0][3][[3, 5, 6]].any()          # the three robots were reset at once
+    others = [i for i in range(8) if i not in (3, 5, 6)]
+    for (o0, p0, r0, d0), (o1, p1, r1, d1) in zip(clean, bad):
+        assert np.isfinite(o1).all() and np.isfinite(p1).all() and np.isfinite(r1).all()
+        assert np.array_equal(o0[others], o1[others]) and np.array_equal(r0[others], r1[others]) and np.array_equal(d0[others], d1[others])
