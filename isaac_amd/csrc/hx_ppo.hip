@@ -676,6 +676,7 @@ __global__ void __launch_bounds__(256) hx_adam_kernel(float* __restrict__ p, con
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const float total = (float)sqrt(*sumsq);
+  if (!(total < 3.0e38f)) return;       // non-finite gradient (a NaN reward or observation upstream): skip the step, keep weights and moments
   const float coef = fminf(1.0f, max_norm / (total + 1e-6f));
   const float gi = g[i] * gscale * coef;
   const float mi = 0.9f * m[i] + (1.0f - 0.9f) * gi;

@@ -171,3 +171,24 @@ def test_collective_code_path_single_rank(hxlib):
     for k in sd0:
         np.testing.assert_array_equal(sd0[k], sd1[k], err_msg=k)
     torch.distributed.destroy_process_group()
+
+
+def test_non_finite_gradient_skips_the_step(hxlib):
+    """A NaN that reaches the loss (here: a NaN reward) must not reach the weights: the optimiser step is skipped."""
+    seed, T, N = 4, 4, 32
+    init, ac, alg = _make(seed, T, N, 1e-3, epochs=1, nmb=2)
+    rng = np.random.default_rng(0)
+    for t in range(T):
+        o, p = rng.standard_normal((N, 615)).astype(np.float32), rng.standard_normal((N, 1050)).astype(np.float32)
+        alg.act(o, p, eps=rng.standard_normal((N, 10)).astype(np.float32))
+        r = rng.uniform(0, 0.05, N).astype(np.float32)
+        if t == 2:
+            r[5] = np.nan
+        alg.process_env_step(r, np.zeros(N, np.uint8), {})
+    alg.compute_returns(p)
+    before = {k: v.copy() for k, v in ac.state_dict().items()}
+    alg.update()
+    after = ac.state_dict()
+    for k in before:
+        assert np.array_equal(before[k], after[k]) and np.isfinite(after[k]).all(), k
+    alg.close()
