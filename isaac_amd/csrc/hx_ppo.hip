@@ -25,6 +25,9 @@
 #ifndef HX_BK_UPD
 #define HX_BK_UPD 16      // K-depth of the LDS tile for the 61 440-row update GEMMs
 #endif
+#ifndef HX_WGRAD_MIN_CHUNK
+#define HX_WGRAD_MIN_CHUNK 256   // shortest K chunk of a split-K workgroup (rows)
+#endif
 #ifndef HX_BK_ROLL
 #define HX_BK_ROLL 16     // K-depth for the 4096-row rollout GEMMs
 #endif
@@ -844,7 +847,7 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   }
   int splits = target_blocks / tiles;
   if (splits < 1) splits = 1;
-  int max_splits = Mrows / 256; if (max_splits < 1) max_splits = 1;
+  int max_splits = Mrows / HX_WGRAD_MIN_CHUNK; if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
   int kchunk = rup((Mrows + splits - 1) / splits, 32);
   splits = (Mrows + kchunk - 1) / kchunk;
@@ -918,7 +921,7 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
     round_up = getenv("HX_WGRAD_FLOOR") ? 0 : 1;
   }
   int splits = round_up ? (target_blocks + tiles - 1) / tiles : target_blocks / tiles;
-  if (splits < 1) splits = 1; int max_splits = rows / 256; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1; int max_splits = rows / HX_WGRAD_MIN_CHUNK; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
   int kchunk = rup((rows + splits - 1) / splits, 32); splits = (rows + kchunk - 1) / kchunk;
   HX_CHECK(hipMalloc(&slab, (size_t)splits * nw * 4)); HX_CHECK(hipMalloc(&bslab, (size_t)splits * out * 4));
   HX_CHECK(hipMemset(X, 0x3d, nx * 4)); HX_CHECK(hipMemset(W, 0x3c, nw * 4)); HX_CHECK(hipMemset(Y, 0x3b, ny * 4));
