@@ -30,8 +30,9 @@ extern "C" {
 
 typedef struct hx_ppo_cfg {
   int32_t num_envs, num_steps;            /* N, T (num_steps_per_env) */
-  int32_t num_obs, num_priv, num_actions; /* 615, 1050, 10 */
-  int32_t actor_hidden[3], critic_hidden[3];
+  int32_t num_obs, num_priv, num_actions; /* 615, 1050, 10 for hector; any widths, 1 <= num_actions <= 32 */
+  int32_t actor_hidden[3], critic_hidden[3]; /* multiples of 4; the last width of each network a multiple of 64 (the two
+                                               may differ: hector_full has 128 / 768, hector_w_arm_config.py:213-214) */
   int32_t num_learning_epochs, num_mini_batches;
   float clip_param, gamma, lam, value_loss_coef, entropy_coef, learning_rate, max_grad_norm;
   int32_t use_clipped_value_loss;

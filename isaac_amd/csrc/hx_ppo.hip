@@ -21,7 +21,7 @@
 #include "hx_gemm.h"
 #include "hx_gemm_bf16.h"
 
-#define MAX_A 16
+#define MAX_A 32
 #ifndef HX_BK_UPD
 #define HX_BK_UPD 16      // K-depth of the LDS tile for the 61 440-row update GEMMs
 #endif
@@ -51,7 +51,7 @@ __device__ __forceinline__ void philox4p(uint32_t k0, uint32_t k1, uint32_t c0, 
 // Rollout head (ppo.py:91-101): mu = W4 h3a + b4, a = mu + std*eps, logp, V = w4c.h3c + b4c.
 // 16 lanes per env row (each lane owns hw/16 consecutive k), partial dot products reduced with 4 xor-shuffles,
 // so a 4096-env rollout step fills 256 workgroups instead of 16.
-__global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restrict__ h3a, const float* __restrict__ h3c, int hw,
+__global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restrict__ h3a, const float* __restrict__ h3c, int hw, int hwc,
                                                           const float* __restrict__ W4, const float* __restrict__ b4,
                                                           const float* __restrict__ W4c, const float* __restrict__ b4c,
                                                           const float* __restrict__ stdp, const float* __restrict__ eps,
@@ -59,28 +59,31 @@ __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restric
                                                           float* actions, float* mu_out, float* values, float* logp) {
   extern __shared__ float sm[];
   float* sW = sm;                 // [A][hw]
-  float* sWc = sm + A * hw;       // [hw]
+  float* sWc = sm + A * hw;       // [hwc]
   for (int i = threadIdx.x; i < A * hw; i += blockDim.x) sW[i] = W4[i];
-  for (int i = threadIdx.x; i < hw; i += blockDim.x) sWc[i] = W4c[i];
+  for (int i = threadIdx.x; i < hwc; i += blockDim.x) sWc[i] = W4c[i];
   __syncthreads();
   const int part = threadIdx.x & 15;
   const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int ec = e < n ? e : n - 1;            // keep every lane in the shuffles
-  const int per = hw / 16;
+  const int per = hw / 16, perc = hwc / 16;
   float mu[MAX_A];
   for (int j = 0; j < A; ++j) mu[j] = 0.f;
   float v = 0.f;
   const float* ha = h3a + (size_t)ec * hw + part * per;
-  const float* hc = h3c + (size_t)ec * hw + part * per;
+  const float* hc = h3c + (size_t)ec * hwc + part * perc;
   for (int k = 0; k < per; k += 4) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(ha + k);
-    const f32x4 y = *reinterpret_cast<const f32x4*>(hc + k);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int kk = part * per + k + q;
       for (int j = 0; j < A; ++j) mu[j] = fmaf(x[q], sW[j * hw + kk], mu[j]);
-      v = fmaf(y[q], sWc[kk], v);
     }
+  }
+  for (int k = 0; k < perc; k += 4) {
+    const f32x4 y = *reinterpret_cast<const f32x4*>(hc + k);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v = fmaf(y[q], sWc[part * perc + k + q], v);
   }
   for (int o = 8; o > 0; o >>= 1) {
     for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
@@ -435,11 +438,12 @@ __global__ void __launch_bounds__(256) hx_gather_kernel(GatherArgs g) {
 
 // Loss head (ppo.py:128-166 forward of the last layers, all loss terms, and their backward down to the
 // pre-activation gradient of the third hidden layer).  64 rows per workgroup.
-// Outputs: dZ3a[M][hw], dZ3c[M][hw] and one partial slab per workgroup:
-//   [A*hw dW4 | A db4 | hw dW4c | 1 db4c | A dstd | kl_sum, value_loss_sum, surrogate_sum, entropy_sum]
+// Outputs: dZ3a[M][hw], dZ3c[M][hwc] and one partial slab per workgroup:
+//   [A*hw dW4 | A db4 | hwc dW4c | 1 db4c | A dstd | kl_sum, value_loss_sum, surrogate_sum, entropy_sum]
+// hw / hwc are the last hidden widths of the actor / critic (they differ for the sibling tasks).
 #define HEAD_ROWS 32
 struct HeadArgs {
-  const float* h3a; const float* h3c; int hw;
+  const float* h3a; const float* h3c; int hw, hwc;
   const float* W4; const float* b4; const float* W4c; const float* b4c; const float* stdp; const float* sigma_old;
   const float* row_mb; int M, A;
   float clip, vcoef, ecoef; int use_clipped_value_loss;
@@ -447,37 +451,39 @@ struct HeadArgs {
 };
 __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   extern __shared__ float sm[];
-  const int hw = g.hw, A = g.A, hp = hw + 1;
-  float* sHa = sm;                       // [64][hw+1]
-  float* sHc = sHa + HEAD_ROWS * hp;     // [64][hw+1]
-  float* sW = sHc + HEAD_ROWS * hp;      // [A][hw]
-  float* sWc = sW + A * hw;              // [hw]
-  float* sD = sWc + hw;                  // [64][A+1]  dmu, dv
-  float* sL = sD + HEAD_ROWS * (A + 1);  // [64][4+A]  kl, vloss, sloss, entropy, dsigma[A]
+  const int hw = g.hw, hwc = g.hwc, A = g.A, hp = hw + 1, hpc = hwc + 1;
+  float* sHa = sm;                       // [rows][hw+1]
+  float* sHc = sHa + HEAD_ROWS * hp;     // [rows][hwc+1]
+  float* sW = sHc + HEAD_ROWS * hpc;     // [A][hw]
+  float* sWc = sW + A * hw;              // [hwc]
+  float* sD = sWc + hwc;                 // [rows][A+1]  dmu, dv
+  float* sL = sD + HEAD_ROWS * (A + 1);  // [rows][4+A]  kl, vloss, sloss, entropy, dsigma[A]
   const int r0 = blockIdx.x * HEAD_ROWS;
   const int tid = threadIdx.x;
   for (int i = tid; i < HEAD_ROWS * hw; i += 256) {
     const int r = i / hw, k = i % hw;
-    const bool ok = (r0 + r) < g.M;
-    sHa[r * hp + k] = ok ? g.h3a[(size_t)(r0 + r) * hw + k] : 0.f;
-    sHc[r * hp + k] = ok ? g.h3c[(size_t)(r0 + r) * hw + k] : 0.f;
+    sHa[r * hp + k] = (r0 + r) < g.M ? g.h3a[(size_t)(r0 + r) * hw + k] : 0.f;
+  }
+  for (int i = tid; i < HEAD_ROWS * hwc; i += 256) {
+    const int r = i / hwc, k = i % hwc;
+    sHc[r * hpc + k] = (r0 + r) < g.M ? g.h3c[(size_t)(r0 + r) * hwc + k] : 0.f;
   }
   for (int i = tid; i < A * hw; i += 256) sW[i] = g.W4[i];
-  for (int i = tid; i < hw; i += 256) sWc[i] = g.W4c[i];
+  for (int i = tid; i < hwc; i += 256) sWc[i] = g.W4c[i];
   __syncthreads();
   {
     // 8 lanes per row: each lane owns hw/8 consecutive k of both dot products, 3 xor-shuffles reduce them,
     // lane 0 of the row finishes the loss terms
     const int r = tid >> 3, part = tid & 7, m = r0 + r;
-    const int per = hw / 8;
+    const int per = hw / 8, perc = hwc / 8;
     float mu[MAX_A];
     for (int j = 0; j < A; ++j) mu[j] = 0.f;
     float v = 0.f;
     for (int k = part * per; k < (part + 1) * per; ++k) {
       const float x = sHa[r * hp + k];
       for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
-      v = fmaf(sHc[r * hp + k], sWc[k], v);
     }
+    for (int k = part * perc; k < (part + 1) * perc; ++k) v = fmaf(sHc[r * hpc + k], sWc[k], v);
     for (int o = 4; o > 0; o >>= 1) {
       for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
       v += __shfl_xor(v, o);
@@ -540,9 +546,14 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
     if (r0 + r >= g.M) continue;
     float s = 0.f;
     for (int j = 0; j < A; ++j) s = fmaf(sD[r * (A + 1) + j], sW[j * hw + k], s);
-    const float ha = sHa[r * hp + k], hc = sHc[r * hp + k];
+    const float ha = sHa[r * hp + k];
     g.dz3a[(size_t)(r0 + r) * hw + k] = s * (ha > 0.f ? 1.f : ha + 1.f);
-    g.dz3c[(size_t)(r0 + r) * hw + k] = sD[r * (A + 1) + A] * sWc[k] * (hc > 0.f ? 1.f : hc + 1.f);
+  }
+  for (int i = tid; i < HEAD_ROWS * hwc; i += 256) {
+    const int r = i / hwc, k = i % hwc;
+    if (r0 + r >= g.M) continue;
+    const float hc = sHc[r * hpc + k];
+    g.dz3c[(size_t)(r0 + r) * hwc + k] = sD[r * (A + 1) + A] * sWc[k] * (hc > 0.f ? 1.f : hc + 1.f);
   }
   // partial parameter gradients of the two heads, summed over this workgroup's rows
   float* slab = g.slab + (size_t)blockIdx.x * g.slab_w;
@@ -552,26 +563,26 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
     for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + j], sHa[r * hp + k], s);
     slab[i] = s;
   }
-  for (int k = tid; k < hw; k += 256) {
+  for (int k = tid; k < hwc; k += 256) {
     float s = 0.f;
-    for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + A], sHc[r * hp + k], s);
+    for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + A], sHc[r * hpc + k], s);
     slab[A * hw + A + k] = s;
   }
   if (tid < A) {
     float s = 0.f, d = 0.f;
     for (int r = 0; r < HEAD_ROWS; ++r) { s += sD[r * (A + 1) + tid]; d += sL[r * (4 + A) + 4 + tid]; }
     slab[A * hw + tid] = s;                      // db4
-    slab[A * hw + A + hw + 1 + tid] = d;         // dstd
+    slab[A * hw + A + hwc + 1 + tid] = d;        // dstd
   }
   if (tid == 32) {
     float s = 0.f;
     for (int r = 0; r < HEAD_ROWS; ++r) s += sD[r * (A + 1) + A];
-    slab[A * hw + A + hw] = s;                   // db4c
+    slab[A * hw + A + hwc] = s;                  // db4c
   }
   if (tid >= 64 && tid < 68) {
     float s = 0.f;
     for (int r = 0; r < HEAD_ROWS; ++r) s += sL[r * (4 + A) + (tid - 64)];
-    slab[A * hw + A + hw + 1 + A + (tid - 64)] = s;
+    slab[A * hw + A + hwc + 1 + A + (tid - 64)] = s;
   }
 }
 
@@ -620,21 +631,21 @@ __global__ void __launch_bounds__(256) hx_reduce_all_kernel(ReduceTable t) {
 }
 
 // scatter the head slab sums into the flat gradient buffer + statistics
-struct HeadScatter { size_t w4, b4, w4c, b4c, stdo, stats; int A, hw; };
+struct HeadScatter { size_t w4, b4, w4c, b4c, stdo, stats; int A, hw, hwc; };
 __global__ void hx_head_scatter_kernel(const float* __restrict__ slab, int S, int slab_w, float* grads, HeadScatter o, float rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= slab_w) return;
   float s = 0.f;
   for (int k = 0; k < S; ++k) s += slab[(size_t)k * slab_w + i];
-  const int A = o.A, hw = o.hw;
+  const int A = o.A, hw = o.hw, hwc = o.hwc;
   size_t dst;
   if (i < A * hw) dst = o.w4 + i;
   else if (i < A * hw + A) dst = o.b4 + (i - A * hw);
-  else if (i < A * hw + A + hw) dst = o.w4c + (i - A * hw - A);
-  else if (i < A * hw + A + hw + 1) dst = o.b4c;
-  else if (i < A * hw + A + hw + 1 + A) dst = o.stdo + (i - (A * hw + A + hw + 1));
+  else if (i < A * hw + A + hwc) dst = o.w4c + (i - A * hw - A);
+  else if (i < A * hw + A + hwc + 1) dst = o.b4c;
+  else if (i < A * hw + A + hwc + 1 + A) dst = o.stdo + (i - (A * hw + A + hwc + 1));
   else {
-    const int q = i - (A * hw + A + hw + 1 + A);   // 0 kl, 1 vloss, 2 sloss, 3 entropy
+    const int q = i - (A * hw + A + hwc + 1 + A);   // 0 kl, 1 vloss, 2 sloss, 3 entropy
     if (q == 3) return;
     dst = o.stats + q;
   }
@@ -962,12 +973,17 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
 extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
-  if (cfg->num_actions > MAX_A) { hx_set_error("hx_ppo_create: num_actions > 16"); return -2; }
+  if (cfg->num_actions > MAX_A || cfg->num_actions < 1) { hx_set_error("hx_ppo_create: num_actions must be in [1, 32]"); return -2; }
   for (int l = 0; l < 3; ++l)
     if (cfg->actor_hidden[l] % 4 != 0 || cfg->critic_hidden[l] % 4 != 0 || cfg->actor_hidden[l] <= 0 || cfg->critic_hidden[l] <= 0) {
       hx_set_error("hx_ppo_create: hidden layer widths must be positive multiples of 4 (16-byte vector accesses)"); return -2;
     }
-  if (cfg->actor_hidden[2] != cfg->critic_hidden[2] || cfg->actor_hidden[2] % 64) { hx_set_error("hx_ppo_create: last hidden widths must match and be a multiple of 64"); return -2; }
+  if (cfg->actor_hidden[2] % 64 || cfg->critic_hidden[2] % 64) { hx_set_error("hx_ppo_create: last hidden widths must be multiples of 64 (head kernels split a row over 16 lanes of 4-wide loads)"); return -2; }
+  {
+    const int A_ = cfg->num_actions, ha_ = cfg->actor_hidden[2], hc_ = cfg->critic_hidden[2];
+    const size_t head_lds = (size_t)(HEAD_ROWS * (ha_ + 1) + HEAD_ROWS * (hc_ + 1) + A_ * ha_ + hc_ + HEAD_ROWS * (A_ + 1) + HEAD_ROWS * (4 + A_)) * sizeof(float);
+    if (head_lds > 160 * 1024 || (size_t)(A_ * ha_ + hc_) * sizeof(float) > 64 * 1024) { hx_set_error("hx_ppo_create: last hidden widths too large for the loss head's LDS tile"); return -2; }
+  }
   static_assert(HEAD_ROWS * 8 == 256, "loss head: 8 lanes per row");
   hx_ppo* s = new hx_ppo();
   s->cfg = *cfg;
@@ -1058,7 +1074,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   s->slab_floats = slab_tot;
   rc |= palloc(s, &s->slab, slab_tot);
   rc |= palloc(s, &s->bias_slab, bslab_tot);
-  s->head_slab_w = A * cfg->actor_hidden[2] + A + cfg->actor_hidden[2] + 1 + A + 4;
+  s->head_slab_w = A * cfg->actor_hidden[2] + A + cfg->critic_hidden[2] + 1 + A + 4;
   s->head_blocks_max = (s->Mmax + HEAD_ROWS - 1) / HEAD_ROWS;
   rc |= palloc(s, &s->head_slab, (size_t)s->head_blocks_max * s->head_slab_w);
   rc |= palloc(s, &s->head_slab2, (size_t)((s->head_blocks_max + 31) / 32) * s->head_slab_w);
@@ -1074,6 +1090,7 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   HX_CHECK(hipStreamSynchronize(s->stream));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
   s->prof = false; s->ev_used = 0;
@@ -1211,7 +1228,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
   if (priv != sp) HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)count * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
   float* aa[3]; float* ac[3];
   for (int l = 0; l < 3; ++l) { aa[l] = s->act_a[l] + (size_t)env0 * s->cfg.actor_hidden[l]; ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l]; }
-  const int hw = s->cfg.actor_hidden[2];
+  const int hw = s->cfg.actor_hidden[2], hwc = s->cfg.critic_hidden[2];
   if (t == 0 && env0 == 0) HX_CHECK(hipMemcpyAsync(s->sigma_old, s->params + s->std_off, A * sizeof(float), hipMemcpyDeviceToDevice, st));
   float* acts = s->s_actions + ((size_t)t * N + env0) * A;
   if (dual) {
@@ -1243,8 +1260,8 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
   } else {
     mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
     mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);
-    hipLaunchKernelGGL(hx_act_head_kernel, dim3((count + 15) / 16), dim3(256), (A + 1) * hw * sizeof(float), st,
-                       aa[2], ac[2], hw, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
+    hipLaunchKernelGGL(hx_act_head_kernel, dim3((count + 15) / 16), dim3(256), (size_t)(A * hw + hwc) * sizeof(float), st,
+                       aa[2], ac[2], hw, hwc, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
                        s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi + (uint32_t)env0, s->act_counter, acts,
                        s->s_mu + ((size_t)t * N + env0) * A, s->s_values + (size_t)t * N + env0, s->s_logp + (size_t)t * N + env0);
     if (env0 + count == N) s->crit_done = t + 1;             // shard path computes values inline
@@ -1357,17 +1374,17 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a);
   mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c);
   // heads: losses + gradient into the third hidden layer
-  const int hw = c.actor_hidden[2];
+  const int hw = c.actor_hidden[2], hwc = c.critic_hidden[2];
   const int hblocks = (M + HEAD_ROWS - 1) / HEAD_ROWS;
   HeadArgs h{};
-  h.h3a = s->act_a[2]; h.h3c = s->act_c[2]; h.hw = hw;
+  h.h3a = s->act_a[2]; h.h3c = s->act_c[2]; h.hw = hw; h.hwc = hwc;
   h.W4 = s->params + s->L[3].w; h.b4 = s->params + s->L[3].b; h.W4c = s->params + s->L[7].w; h.b4c = s->params + s->L[7].b;
   h.stdp = s->params + s->std_off; h.sigma_old = s->sigma_old; h.row_mb = s->row_mb; h.M = M; h.A = A;
   h.clip = c.clip_param; h.vcoef = c.value_loss_coef; h.ecoef = c.entropy_coef; h.use_clipped_value_loss = c.use_clipped_value_loss;
   h.dz3a = s->dz_a[2]; h.dz3c = s->dz_c[2]; h.slab = s->head_slab; h.slab_w = s->head_slab_w;
-  const size_t shm = (size_t)(2 * HEAD_ROWS * (hw + 1) + A * hw + hw + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
+  const size_t shm = (size_t)(HEAD_ROWS * (hw + 1) + HEAD_ROWS * (hwc + 1) + A * hw + hwc + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
   hipLaunchKernelGGL(hx_loss_head_kernel, dim3(hblocks), dim3(256), shm, st, h);
-  HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw};
+  HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw, hwc};
   const int hchunk = 32, hchunks = (hblocks + hchunk - 1) / hchunk;
   hipLaunchKernelGGL(hx_slab_chunk_kernel, dim3((s->head_slab_w + 255) / 256, hchunks), dim3(256), 0, st, s->head_slab, hblocks, s->head_slab_w, hchunk, s->head_slab2);
   hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab2, hchunks, s->head_slab_w, s->grads, hs, (float)M);
