@@ -57,6 +57,8 @@ extern "C" {
 #define HX_RP_CMD_B 31         /* legged_robot.py:186 resample inside reset_idx        U x3 */
 #define HX_RP_OBS_NOISE 34     /* hector_env.py:243    N   x41 */
 #define HX_RP_SIZE 75
+#define HX_RP_LEVEL 75         /* legged_robot.py:415-416 randint(max_terrain_level) as U x1.  Read ONLY when a terrain
+                                  curriculum is set (hx_sim_set_terrain_curriculum): packs then have HX_RP_SIZE + 1 rows */
 
 /* indices into hx_sim_cfg.reward_scale (already multiplied by dt, legged_robot.py:527) */
 enum {
@@ -149,6 +151,14 @@ int hx_sim_create(const hx_sim_cfg* cfg, const float* shape_friction_h, const fl
  * heights_h == NULL returns to the ground plane z = 0 (gym.add_ground, legged_robot.py:541-551). */
 int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t rows, int32_t cols, float horizontal_scale,
                        float vertical_scale, float x0, float y0);
+/* Terrain curriculum, LeggedRobot._update_terrain_curriculum (legged_robot.py:399-419) with the tables of
+ * _get_env_origins (legged_robot.py:687-697).  origins_h [rows][cols][3] = terrain.env_origins, levels_h / types_h [N] =
+ * terrain_levels / terrain_types, env_length = terrain.env_length, max_episode_length_s as in the config.  Every reset
+ * after the constructor's then moves the robot one row up (walked > env_length / 2), one row down (walked less than
+ * half the commanded distance) or to a random row (past the last), and re-bases its origin.  origins_h == NULL: off. */
+int hx_sim_set_terrain_curriculum(hx_sim* s, const float* origins_h, int32_t rows, int32_t cols, const int32_t* levels_h,
+                                  const int32_t* types_h, float env_length, float max_episode_length_s);
+int hx_sim_get_terrain_levels(hx_sim* s, int32_t* levels_h /*[N]*/);
 void hx_sim_destroy(hx_sim* s);
 int hx_sim_reset_all(hx_sim* s, const float* pack /*nullable*/);
 int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const float* pack /*nullable*/);

@@ -17,7 +17,7 @@ NUM_OBS, NUM_PRIV = 615, 1050
 OBS_LD, PRIV_LD = 616, 1052
 NUM_REWARDS = 22
 RP_SIZE = 75
-RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34)
+RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34, level=75)
 REWARD_NAMES = ["action_smoothness", "base_acc", "base_height", "collision", "default_joint_pos", "dof_acc",
                 "dof_vel", "feet_air_time", "feet_clearance", "feet_contact_forces", "feet_contact_number",
                 "feet_distance", "foot_slip", "joint_pos", "knee_distance", "low_speed", "orientation", "torques",
@@ -93,6 +93,8 @@ def lib():
     L.hx_sim_set_commands.argtypes = [vp, vp]
     L.hx_sim_get_base_velocities.argtypes = [vp, vp, vp]
     L.hx_sim_set_terrain.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.hx_sim_set_terrain_curriculum.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, C.c_float]
+    L.hx_sim_get_terrain_levels.argtypes = [vp, vp]
     L.hx_sim_episode_stats.argtypes = [vp, vp, vp]
     L.hx_sim_stream.argtypes = [vp]
     L.hx_sim_stream.restype = vp

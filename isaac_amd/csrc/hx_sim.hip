@@ -47,6 +47,14 @@ struct SimPtrs {
   const float* terrain;
   int t_rows, t_cols;
   float t_inv_hs, t_hs, t_x0, t_y0;
+  // terrain curriculum (legged_robot.py:399-419): level per env, tile column per env, platform origin per tile;
+  // cur_levels == nullptr = off
+  int* cur_levels;            // [N]
+  const int* cur_types;       // [N]
+  const float* cur_origins;   // [cur_rows][cur_cols][3]
+  int cur_rows, cur_cols;
+  float cur_up_dist;          // terrain.env_length / 2
+  float cur_down_scale;       // max_episode_length_s * 0.5
 };
 
 // ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   float last_feet_z[2] = {LD(S_LAST_FEET_Z), LD(S_LAST_FEET_Z + 1)};
   float push_f[2] = {LD(S_PUSH_F), LD(S_PUSH_F + 1)};
   float push_t[3] = {LD(S_PUSH_T), LD(S_PUSH_T + 1), LD(S_PUSH_T + 2)};
-  const V3 origin = mk(LD(S_ORIGIN), LD(S_ORIGIN + 1), LD(S_ORIGIN + 2));
+  V3 origin = mk(LD(S_ORIGIN), LD(S_ORIGIN + 1), LD(S_ORIGIN + 2));
   V3 base_lin_vel = mk(LD(S_BLV), LD(S_BLV + 1), LD(S_BLV + 2));
   V3 base_ang_vel = mk(LD(S_BAV), LD(S_BAV + 1), LD(S_BAV + 2));
   float ep_ret = LD(S_EP_RET);
@@ -502,6 +510,21 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
 
   // ---- reset_idx (legged_robot.py:162-214 ; hector_env.py:256-261)
   if (reset) {
+    // _update_terrain_curriculum (legged_robot.py:399-419), skipped on the constructor's reset (init_done false):
+    // walked more than half a tile -> harder row; less than half of the commanded distance -> easier row; past the
+    // last row -> a random one.  Uses the commands of the finished episode (reset_idx resamples them afterwards).
+    if (p.cur_levels != nullptr && A.mode == 0) {
+      const float dx = S.pos.x - origin.x, dy = S.pos.y - origin.y;
+      const float dist = sqrtf(dx * dx + dy * dy);
+      const bool up = dist > p.cur_up_dist;
+      const bool down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * p.cur_down_scale) && !up;
+      int lvl = p.cur_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
+      if (lvl >= p.cur_rows) lvl = min((int)(rng.uni(HX_RP_LEVEL) * (float)p.cur_rows), p.cur_rows - 1);
+      else lvl = max(lvl, 0);
+      const float* o = p.cur_origins + ((size_t)lvl * p.cur_cols + p.cur_types[e]) * 3;
+      origin = mk(o[0], o[1], o[2]);
+      if (writer) { p.cur_levels[e] = lvl; ST(S_ORIGIN, origin.x); ST(S_ORIGIN + 1, origin.y); ST(S_ORIGIN + 2, origin.z); }
+    }
     for (int j = 0; j < 10; ++j) {
       qa[j] = cfg.default_dof_pos[j] + (0.3f * rng.uni(HX_RP_RESET_Q + j) - 0.15f);
       qda[j] = 0.f;
@@ -782,6 +805,33 @@ extern "C" int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t r
   HX_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
   s->p.terrain = d; s->p.t_rows = rows; s->p.t_cols = cols;
   s->p.t_hs = horizontal_scale; s->p.t_inv_hs = 1.0f / horizontal_scale; s->p.t_x0 = x0; s->p.t_y0 = y0;
+  return 0;
+}
+
+extern "C" int hx_sim_set_terrain_curriculum(hx_sim* s, const float* origins_h, int32_t rows, int32_t cols, const int32_t* levels_h,
+                                             const int32_t* types_h, float env_length, float max_episode_length_s) {
+  if (!s) { hx_set_error("hx_sim_set_terrain_curriculum: null sim"); return -2; }
+  if (!origins_h) { s->p.cur_levels = nullptr; return 0; }
+  if (rows <= 0 || cols <= 0 || !levels_h || !types_h) { hx_set_error("hx_sim_set_terrain_curriculum: bad table"); return -2; }
+  const int n = s->cfg.num_envs;
+  for (int e = 0; e < n; ++e)
+    if (levels_h[e] < 0 || levels_h[e] >= rows || types_h[e] < 0 || types_h[e] >= cols) {
+      hx_set_error("hx_sim_set_terrain_curriculum: level / type outside the tile table"); return -2;
+    }
+  int *lv = nullptr, *ty = nullptr; float* og = nullptr;
+  if (dalloc(s, &lv, (size_t)n) || dalloc(s, &ty, (size_t)n) || dalloc(s, &og, (size_t)rows * cols * 3)) return -3;
+  HX_CHECK(hipMemcpy(lv, levels_h, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  HX_CHECK(hipMemcpy(ty, types_h, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  HX_CHECK(hipMemcpy(og, origins_h, (size_t)rows * cols * 3 * sizeof(float), hipMemcpyHostToDevice));
+  s->p.cur_levels = lv; s->p.cur_types = ty; s->p.cur_origins = og; s->p.cur_rows = rows; s->p.cur_cols = cols;
+  s->p.cur_up_dist = 0.5f * env_length; s->p.cur_down_scale = 0.5f * max_episode_length_s;
+  return 0;
+}
+
+extern "C" int hx_sim_get_terrain_levels(hx_sim* s, int32_t* levels_h) {
+  if (!s || !s->p.cur_levels) { hx_set_error("hx_sim_get_terrain_levels: no terrain curriculum set"); return -2; }
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(levels_h, s->p.cur_levels, (size_t)s->cfg.num_envs * sizeof(int), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -85,10 +85,7 @@ class HectorFreeEnv(VecEnv):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
         rough = mesh_type in ("heightfield", "trimesh")
         if not rough:
-            cfg.terrain.curriculum = False
-        elif cfg.terrain.curriculum:
-            raise NotImplementedError("terrain.curriculum=True (legged_robot.py:399-419) is not built; the hector task "
-                                      "trains with curriculum=False (hector_config.py:47)")
+            cfg.terrain.curriculum = False                   # legged_robot.py:714-716
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = math.ceil(self.max_episode_length_s / self.dt)
         cfg.domain_rand.push_interval = math.ceil(cfg.domain_rand.push_interval_s / self.dt)
@@ -122,7 +119,9 @@ class HectorFreeEnv(VecEnv):
             self.env_origins = np.asarray(creation["origins"], np.float32)
             if rough:
                 terrain_grid = creation["terrain"]      # dict(heights int16 [R][C], horizontal_scale, vertical_scale, border_size)
-                self.terrain_levels, self.terrain_types = creation.get("terrain_levels"), creation.get("terrain_types")
+                self._terrain_levels0, self.terrain_types = creation.get("terrain_levels"), creation.get("terrain_types")
+                self.terrain_origins = creation.get("terrain_origins")
+                self.max_terrain_level = cfg.terrain.num_rows
         else:
             if rough:
                 from .terrain import HumanoidTerrain
@@ -224,6 +223,17 @@ class HectorFreeEnv(VecEnv):
                                             float(terrain_grid["horizontal_scale"]), float(terrain_grid["vertical_scale"]),
                                             -float(terrain_grid["border_size"]), -float(terrain_grid["border_size"])),
                        "hx_sim_set_terrain")
+        self._curriculum = bool(rough and cfg.terrain.curriculum)
+        if self._curriculum:              # _update_terrain_curriculum (legged_robot.py:399-419) runs inside the env-step kernel
+            if getattr(self, "terrain_origins", None) is None or self._terrain_levels0 is None:
+                raise ValueError("terrain curriculum needs terrain_origins / terrain_levels / terrain_types")
+            og = np.ascontiguousarray(self.terrain_origins, np.float32)
+            sl = slice(self.env_lo, self.env_hi)
+            lv = np.ascontiguousarray(np.asarray(self._terrain_levels0)[sl], np.int32)
+            ty = np.ascontiguousarray(np.asarray(self.terrain_types)[sl], np.int32)
+            capi.check(L.hx_sim_set_terrain_curriculum(h, og.ctypes.data, og.shape[0], og.shape[1], lv.ctypes.data, ty.ctypes.data,
+                                                       float(cfg.terrain.terrain_length), float(self.max_episode_length_s)),
+                       "hx_sim_set_terrain_curriculum")
         self.stream = L.hx_sim_stream(h)
         self.common_step_counter = 0
         self.extras = {}
@@ -241,11 +251,11 @@ class HectorFreeEnv(VecEnv):
             levels = torch.randint(0, max_init_level + 1, (n,)).numpy()
         except ImportError:                                   # pragma: no cover
             levels = np.random.randint(0, max_init_level + 1, n)
-        self.terrain_levels = levels.astype(np.int64)
+        self._terrain_levels0 = levels.astype(np.int64)
         self.terrain_types = np.floor(np.arange(n) / (n / cfg.terrain.num_cols)).astype(np.int64)
         self.max_terrain_level = cfg.terrain.num_rows
         self.terrain_origins = terrain.env_origins.astype(np.float32)
-        return self.terrain_origins[self.terrain_levels, self.terrain_types].copy()
+        return self.terrain_origins[self._terrain_levels0, self.terrain_types].copy()
 
     @staticmethod
     def _grid_origins(cfg, n):
@@ -381,10 +391,21 @@ class HectorFreeEnv(VecEnv):
         cnt = capi.C.c_int32(0)
         capi.check(self._L.hx_sim_episode_stats(self._h, capi.ptr(mean), capi.C.byref(cnt)), "episode_stats")
         info = {"rew_" + k: float(mean[capi.REWARD_NAMES.index(k)]) for k in self.reward_names}
-        if self.cfg.terrain.mesh_type == "trimesh" and getattr(self, "terrain_levels", None) is not None:
+        if self.cfg.terrain.mesh_type == "trimesh" and getattr(self, "_terrain_levels0", None) is not None:
             info["terrain_level"] = float(np.mean(self.terrain_levels))           # legged_robot.py:203-204
         self.last_episode_return, self.last_episode_length = float(mean[capi.NUM_REWARDS]), float(mean[capi.NUM_REWARDS + 1])
         return info, cnt.value
+
+    @property
+    def terrain_levels(self):
+        """legged_robot.py:693 / :414-418: the row of the tile map each robot is on (moves with the curriculum)."""
+        if getattr(self, "_terrain_levels0", None) is None:
+            return None
+        if not getattr(self, "_curriculum", False):
+            return np.asarray(self._terrain_levels0)[getattr(self, "env_lo", 0):getattr(self, "env_hi", None)]
+        lv = np.zeros(self.num_envs, np.int32)
+        capi.check(self._L.hx_sim_get_terrain_levels(self._h, lv.ctypes.data), "hx_sim_get_terrain_levels")
+        return lv.astype(np.int64)
 
     def sync(self):
         capi.check(self._L.hx_sync(self.stream), "sync")
@@ -423,7 +444,8 @@ class PipelinedHectorEnv(VecEnv):
                                        vertical_scale=cfg.terrain.vertical_scale, border_size=cfg.terrain.border_size)
             probe = HectorFreeEnv.__new__(HectorFreeEnv)
             probe_origins = probe._terrain_origins(cfg, n, self.terrain)
-            creation["terrain_levels"], creation["terrain_types"] = probe.terrain_levels, probe.terrain_types
+            creation["terrain_levels"], creation["terrain_types"] = probe._terrain_levels0, probe.terrain_types
+            creation["terrain_origins"] = probe.terrain_origins
         else:
             probe_origins = HectorFreeEnv._grid_origins(cfg, n)
         friction, mass, start = creation_randomisation(cfg, n, probe_origins)
@@ -472,6 +494,8 @@ class PipelinedHectorEnv(VecEnv):
         tot = sum(cnts)
         w = [c / tot if tot else 0.0 for c in cnts]
         info = {k: sum(wi * i[k] for wi, i in zip(w, infos)) for k in infos[0]}
+        if "terrain_level" in info:                    # a mean over ALL robots (legged_robot.py:203-204), not over the episodes
+            info["terrain_level"] = sum(s.num_envs * i["terrain_level"] for s, i in zip(self.shards, infos)) / self.num_envs
         self.last_episode_return = sum(wi * s.last_episode_return for wi, s in zip(w, self.shards))
         self.last_episode_length = sum(wi * s.last_episode_length for wi, s in zip(w, self.shards))
         return info, tot

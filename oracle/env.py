@@ -22,7 +22,7 @@ import numpy as np
 from . import physics as P
 
 F = np.float32
-RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34)
+RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34, level=75)
 RP_SIZE = 75
 
 # constants of HectorCfg (reference hector_config.py); the product reads them from its own config classes
@@ -87,11 +87,21 @@ def unif(lo, hi, u):
 
 class HectorEnvOracle:
     def __init__(self, n, shape_friction, base_mass, env_origins, init_pack, add_noise=True,
-                 start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False):
+                 start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False, curriculum=None):
         """terrain: oracle.terrain.HeightField or None (plane).  custom_origins: True for heightfield/trimesh
-        (legged_robot.py:688), which adds U[-1,1] to the reset xy (:381-384)."""
+        (legged_robot.py:688), which adds U[-1,1] to the reset xy (:381-384).
+        curriculum: None or dict(origins [rows][cols][3], levels [n], types [n], env_length) -- the terrain curriculum of
+        legged_robot.py:399-419; packs then carry one more row, RP["level"]."""
         self.n = n
         self.custom_origins = custom_origins
+        self.curriculum = curriculum
+        self.init_done = False
+        if curriculum is not None:
+            self.terrain_origins = np.asarray(curriculum["origins"], F)
+            self.terrain_levels = np.asarray(curriculum["levels"], np.int64).copy()
+            self.terrain_types = np.asarray(curriculum["types"], np.int64)
+            self.max_terrain_level = self.terrain_origins.shape[0]
+            self.env_length = float(curriculum["env_length"])
         m0 = P.load_model()["bodies"][0]["mass"]
         self.phys = P.HectorPhysics(n, base_mass_added=np.asarray(base_mass, np.float64) - m0,
                                     shape_friction=shape_friction, dtype=phys_dtype, terrain=terrain)
@@ -100,7 +110,7 @@ class HectorEnvOracle:
             # actor creation pose (legged_robot.py:653-655): origin + U[-1,1]^2, z of the origin; the first
             # privileged frames read body poses from this pose because reset does not refresh them
             self.state.root_pos[:] = np.asarray(start_xy, phys_dtype)
-        self.env_origins = np.asarray(env_origins, F)
+        self.env_origins = np.array(env_origins, F)          # own copy: the terrain curriculum re-bases rows
         self.env_frictions = np.asarray(shape_friction, F).reshape(n, 1)
         self.body_mass = np.asarray(base_mass, F).reshape(n, 1)
         self.add_noise = add_noise
@@ -134,6 +144,7 @@ class HectorEnvOracle:
         self.base_euler = euler_xyz_wrapped(self.root[:, 3:7])
         # constructor: reset all, then first observation (hector_env.py:50-51)
         self.reset_idx(np.arange(n), init_pack)
+        self.init_done = True
         self.compute_observations(init_pack)
 
     # ---- simulator <-> glue views
@@ -236,10 +247,26 @@ class HectorEnvOracle:
         self.root[:, 10:13] = self.rand_push_torque
         self._push_root(np.arange(self.n))
 
+    def _update_terrain_curriculum(self, ids, pack):
+        """legged_robot.py:399-419.  randint_like(levels, max) arrives as a uniform: level = floor(u * max)."""
+        if not self.init_done:
+            return
+        d = self.root[ids, :2] - self.env_origins[ids, :2]
+        distance = np.sqrt(np.sum(d * d, 1, dtype=F), dtype=F)
+        move_up = distance > F(self.env_length / 2)
+        cn = np.sqrt(np.sum(self.commands[ids, :2] ** 2, 1, dtype=F), dtype=F)
+        move_down = (distance < cn * F(self.max_episode_length * self.dt) * F(0.5)) & ~move_up
+        lv = self.terrain_levels[ids] + move_up.astype(np.int64) - move_down.astype(np.int64)
+        rnd = np.minimum(np.floor(pack[RP["level"]][ids] * F(self.max_terrain_level)).astype(np.int64), self.max_terrain_level - 1)
+        self.terrain_levels[ids] = np.where(lv >= self.max_terrain_level, rnd, np.clip(lv, 0, None))
+        self.env_origins[ids] = self.terrain_origins[self.terrain_levels[ids], self.terrain_types[ids]]
+
     # ---- reset (legged_robot.py:162-214, hector_env.py:256-261)
     def reset_idx(self, ids, pack):
         if len(ids) == 0:
             return
+        if self.curriculum is not None:
+            self._update_terrain_curriculum(ids, pack)
         o = RP["reset_q"]
         self.dof_pos[ids] = DEFAULT_Q + unif(-0.15, 0.15, pack[o:o + 10].T[ids])
         self.dof_vel[ids] = 0

@@ -26,8 +26,8 @@ sys.path.insert(0, REPO)
 from tests.refstub import loader  # noqa: E402
 
 # random-pack field offsets (floats per env); mirrored in include/hx_sim.h
-RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34)
-RP_SIZE = 75
+RP = dict(delay=0, act_noise=1, cmd_a=11, push=14, reset_q=19, reset_xy=29, cmd_b=31, obs_noise=34, level=75)
+RP_SIZE = 75          # + 1 row (RP["level"]) when the terrain curriculum is on
 
 
 def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_counter_init=0, add_noise=True,
@@ -53,7 +53,13 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
     sim_params.use_gpu_pipeline = False
 
     log = []
-    real_rand, real_randn_like = torch.rand, torch.randn_like
+    real_rand, real_randn_like, real_randint_like = torch.rand, torch.randn_like, torch.randint_like
+    curriculum = bool(terrain is not None and terrain.get("curriculum", False))
+
+    def randint_like(x, *a, **k):
+        r = real_randint_like(x, *a, **k)
+        log.append(("randint", r.clone(), int(a[0])))
+        return r
 
     def rand(*a, **k):
         r = real_rand(*a, **k)
@@ -65,7 +71,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         log.append(("randn", r.clone()))
         return r
 
-    torch.rand, torch.randn_like = rand, randn_like
+    torch.rand, torch.randn_like, torch.randint_like = rand, randn_like, randint_like
     try:
         env = env_mod.HectorFreeEnv(cfg, sim_params, gymapi.SIM_PHYSX, "cpu", True)
         gym = env.gym
@@ -89,7 +95,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         env._resample_commands, env._reset_dofs = resample, reset_dofs
 
         def build_pack(entries, is_init):
-            pack = np.zeros((RP_SIZE, N), np.float32)
+            pack = np.zeros((RP_SIZE + (1 if curriculum else 0), N), np.float32)
+            pending_level = None
             it = iter(entries)
             state = "start"
             resample_count = 0
@@ -110,8 +117,16 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
                         assert r[0] == "rand" and r[1].shape == (len(ids), 1), (r[0], r[1].shape, len(ids))
                         pack[field + k, ids] = r[1][:, 0].numpy()
                     resample_count += 1
+                elif e[0] == "randint":
+                    # _update_terrain_curriculum (legged_robot.py:415): one draw per resetting env, made BEFORE _reset_dofs;
+                    # stored as the uniform whose floor(u * max_level) is the drawn level
+                    pending_level = (e[1].numpy().astype(np.float64) + 0.5) / e[2]
                 elif e[0] == "mark_reset":
                     ids = e[1].numpy()
+                    if pending_level is not None:
+                        assert pending_level.shape == (len(ids),)
+                        pack[RP["level"], ids] = pending_level.astype(np.float32)
+                        pending_level = None
                     r = next(it)
                     assert r[0] == "rand" and r[1].shape == (len(ids), 10)
                     pack[RP["reset_q"]:RP["reset_q"] + 10, ids] = r[1].numpy().T
@@ -144,6 +159,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         out = {k: [] for k in ("actions", "obs41", "priv70", "rew", "reset", "timeout", "root", "q", "qd",
                                "contact", "bodies", "torques", "commands", "ep_len", "feet_air_time",
                                "feet_height", "episode_sums", "timeouts_visible")}
+        if curriculum:
+            out["levels"], out["origins"] = [], []
         full = {}
         init = dict(obs_full=env.obs_buf.numpy().copy(), priv_full=env.privileged_obs_buf.numpy().copy(),
                     root=gym.root_t.numpy().copy(), q=gym.state.q.copy(), commands=env.commands.numpy().copy(),
@@ -151,6 +168,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
                     start_pos=np.array(gym.start_pos),
                     env_origins=env.env_origins.numpy().copy(), env_frictions=env.env_frictions.numpy().copy(),
                     body_mass=env.body_mass.numpy().copy())
+        if curriculum:
+            init["terrain_levels"] = env.terrain_levels.numpy().copy()
         if ep_len_init is not None:
             env.episode_length_buf[:] = torch.as_tensor(ep_len_init, dtype=torch.long)
         env.common_step_counter = step_counter_init
@@ -181,6 +200,9 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
             out["feet_air_time"].append(env.feet_air_time.numpy().copy())
             out["feet_height"].append(env.feet_height.numpy().copy())
             out["episode_sums"].append(np.stack([env.episode_sums[k].numpy() for k in reward_names], 0))
+            if curriculum:
+                out["levels"].append(env.terrain_levels.numpy().copy())
+                out["origins"].append(env.env_origins.numpy().copy())
             if (t + 1) in full_stack_steps or t == n_steps - 1:
                 full[t + 1] = (obs.numpy().copy(), priv.numpy().copy())
         res = {k: np.stack(v) for k, v in out.items()}
@@ -205,6 +227,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
             res["terrain_levels"] = env.terrain_levels.numpy().copy()
             res["terrain_types"] = env.terrain_types.numpy().copy()
             res["terrain_origins"] = env.terrain_origins.numpy().copy()
+            res["terrain_env_length"] = np.array(float(env.terrain.env_length))
+            res["terrain_curriculum"] = np.array(int(curriculum))
             res["terrain_level_stat"] = np.array(float(env.extras["episode"]["terrain_level"])) if "episode" in env.extras and "terrain_level" in env.extras["episode"] else np.array(np.nan)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **res)
@@ -212,20 +236,34 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
               "torque checks", gym.torque_checks, "size %.0f KB" % (os.path.getsize(path) / 1024),
               "mean rew %.4f" % res["rew"].mean())
     finally:
-        torch.rand, torch.randn_like = real_rand, real_randn_like
+        torch.rand, torch.randn_like, torch.randint_like = real_rand, real_randn_like, real_randint_like
 
 
 if __name__ == "__main__":
     assert loader.available(), "needs /root/reference"
+    only = set(sys.argv[1:])          # e.g. `make_env_fixtures.py env_rollout_d`; nothing = all
+    want = lambda name: not only or name in only
     N = 8
     # A: ordinary rollout from the initial reset; falls (contact terminations) happen on their own
-    generate("env_rollout_a", N, 120, seed=5, action_std=1.0)
+    if want("env_rollout_a"):
+        generate("env_rollout_a", N, 120, seed=5, action_std=1.0)
     # B: exercises the calendar events: command resampling (ep_len % 800 == 0), time-outs (> 2400),
     #    the global push (counter % 400 == 0); observation noise off so stacks are exact
-    generate("env_rollout_b", N, 40, seed=7, action_std=0.3,
-             ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390, add_noise=False)
+    if want("env_rollout_b"):
+        generate("env_rollout_b", N, 40, seed=7, action_std=0.3,
+                 ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390, add_noise=False)
     # C: rough terrain (the reference's default mesh_type): tile map from the reference's HumanoidTerrain,
     #    env origins on the tiles, reset xy offsets, contact against slopes / blocks / stairs
-    generate("env_rollout_c", N, 100, seed=5, action_std=0.6,
-             ep_len_init=[0, 2350, 0, 0, 2380, 0, 0, 0],
-             terrain=dict(mesh_type="trimesh", num_rows=2, num_cols=4, border_size=3.0))
+    if want("env_rollout_c"):
+        generate("env_rollout_c", N, 100, seed=5, action_std=0.6,
+                 ep_len_init=[0, 2350, 0, 0, 2380, 0, 0, 0],
+                 terrain=dict(mesh_type="trimesh", num_rows=2, num_cols=4, border_size=3.0))
+    # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
+    #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others
+    #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 19 shows every
+    #    branch: 0->1 and 1->2 (up), 1->0 and 2->1 (down), 2->0 twice (past the last row -> random row)
+    if want("env_rollout_d"):
+        generate("env_rollout_d", N, 150, seed=19, action_std=0.8,
+                 ep_len_init=[2290, 2300, 2310, 2320, 0, 2340, 0, 2360],
+                 terrain=dict(mesh_type="trimesh", curriculum=True, num_rows=3, num_cols=2, border_size=2.0,
+                              terrain_length=1.6, terrain_width=1.6, max_init_terrain_level=2))

@@ -35,11 +35,16 @@ def make_env(fx):
         cfg.terrain.mesh_type = "trimesh"
         creation["terrain"] = dict(heights=fx["terrain_heights"], horizontal_scale=hs, vertical_scale=vs, border_size=border)
         creation["terrain_levels"], creation["terrain_types"] = fx["terrain_levels"], fx["terrain_types"]
+        if "terrain_curriculum" in fx and int(fx["terrain_curriculum"]):      # fixture D: legged_robot.py:399-419
+            cfg.terrain.curriculum = True
+            cfg.terrain.num_rows, cfg.terrain.num_cols = (int(x) for x in fx["terrain_origins"].shape[:2])
+            cfg.terrain.terrain_length = cfg.terrain.terrain_width = float(fx["terrain_env_length"])
+            creation["terrain_levels"], creation["terrain_origins"] = fx["init_terrain_levels"], fx["terrain_origins"]
     env = HectorFreeEnv(cfg, sim_device="cuda:0", creation=creation, init_pack=fx["packs"][0])
     return env, n, steps, sc0
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d"])
 def test_constructor_reset_and_first_observation(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -51,7 +56,7 @@ def test_constructor_reset_and_first_observation(hxlib, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d"])
 def test_teacher_forced_steps(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -74,6 +79,8 @@ def test_teacher_forced_steps(hxlib, name):
         assert np.array_equal(env.time_out_buf.numpy(), fx["timeout"][t]), f"time-out flags differ at step {t}"
         assert np.array_equal(extras["time_outs"].numpy(), fx["timeouts_visible"][t]), f"extras time_outs differ at step {t}"
         np.testing.assert_array_equal(env.episode_length_buf.numpy(), fx["ep_len"][t])
+        if "levels" in fx:       # terrain curriculum: the row every robot is on after this step's resets
+            np.testing.assert_array_equal(env.terrain_levels, fx["levels"][t], err_msg=f"terrain levels differ at step {t}")
     print(name, "teacher-forced worst errors", {k: float("%.3g" % v) for k, v in worst.items()})
     # fp32 ABA vs float64 CRBA inside one env step (10 substeps): round-off level except where a contact point
     # crosses its activation threshold at a slightly different substep (violent late steps of rollout_a)
@@ -261,3 +268,40 @@ def test_blow_up_guard(hxlib):
     for (o0, p0, r0, d0), (o1, p1, r1, d1) in zip(clean, bad):
         assert np.isfinite(o1).all() and np.isfinite(p1).all() and np.isfinite(r1).all()
         assert np.array_equal(o0[others], o1[others]) and np.array_equal(r0[others], r1[others]) and np.array_equal(d0[others], d1[others])
+
+
+def test_curriculum_with_device_rng(hxlib):
+    """terrain.curriculum=True through the ordinary constructor (curriculum tile layout, Philox draws): rows stay inside
+    the table, change only when the robot resets, and every reset pose sits within 1 m (the U[-1,1] xy offset) of the
+    platform origin of the robot's current (row, column) tile -- legged_robot.py:381-384, :399-419."""
+    from isaac_amd.utils.helpers import set_seed
+    n = 256
+    cfg = HectorCfg()
+    cfg.env.num_envs = n
+    cfg.seed = set_seed(3)
+    cfg.terrain.mesh_type = "trimesh"
+    cfg.terrain.curriculum = True
+    cfg.terrain.num_rows, cfg.terrain.num_cols, cfg.terrain.border_size = 4, 4, 5.0
+    cfg.terrain.terrain_length = cfg.terrain.terrain_width = 4.0
+    cfg.terrain.max_init_terrain_level = 1
+    env = HectorFreeEnv(cfg, sim_device="cuda:0")
+    lv0 = env.terrain_levels.copy()
+    assert lv0.min() >= 0 and lv0.max() <= 1                      # max_init_terrain_level
+    rng = np.random.default_rng(0)
+    prev, moved = lv0, 0
+    for t in range(120):
+        obs, priv, rew, reset, extras = env.step((1.5 * rng.standard_normal((n, 10))).astype(np.float32))
+        lv, r = env.terrain_levels, reset.numpy().astype(bool)
+        assert lv.min() >= 0 and lv.max() < 4
+        assert not np.any((lv != prev) & ~r)
+        moved += int(np.sum(lv != prev))
+        if r.any():
+            root, _, _ = env.get_state()
+            og = env.terrain_origins[lv, np.asarray(env.terrain_types)]
+            assert np.abs(root[r, :2] - og[r, :2]).max() <= 1.0 + 1e-5
+            np.testing.assert_allclose(root[r, 2], og[r, 2] + 0.55, rtol=0, atol=1e-5)
+        prev = lv
+    assert moved > 0
+    info, cnt = env.episode_stats()
+    assert info["terrain_level"] == pytest.approx(float(np.mean(env.terrain_levels)))
+    env.close()

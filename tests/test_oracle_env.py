@@ -19,12 +19,15 @@ def make_oracle_env(fx, **kw):
         from oracle.terrain import HeightField
         hs, vs, border = fx["terrain_params"]
         terrain = HeightField(fx["terrain_heights"], hs, vs, border)
+    if "terrain_curriculum" in fx and int(fx["terrain_curriculum"]):
+        kw.setdefault("curriculum", dict(origins=fx["terrain_origins"], levels=fx["init_terrain_levels"], types=fx["terrain_types"],
+                                         env_length=float(fx["terrain_env_length"])))
     return HectorEnvOracle(n, fx["init_shape_friction"], fx["init_base_mass"], fx["init_env_origins"], fx["packs"][0],
                            add_noise=bool(noise), start_xy=fx["init_start_pos"], terrain=terrain,
                            custom_origins=terrain is not None, **kw)
 
 
-@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100)])
+@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100), ("env_rollout_d", 150)])
 def test_oracle_env_reproduces_reference(name, steps):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
@@ -50,6 +53,9 @@ def test_oracle_env_reproduces_reference(name, steps):
         np.testing.assert_allclose(env.feet_air_time, fx["feet_air_time"][t], rtol=0, atol=1e-6)
         np.testing.assert_allclose(env.feet_height, fx["feet_height"][t], rtol=0, atol=1e-5)
         np.testing.assert_allclose(np.stack([env.episode_sums[k] for k in REWARD_ORDER]), fx["episode_sums"][t], rtol=0, atol=1e-5)
+        if "levels" in fx:                               # terrain curriculum: rows and re-based origins after every reset
+            np.testing.assert_array_equal(env.terrain_levels, fx["levels"][t], err_msg=f"levels step {t}")
+            np.testing.assert_array_equal(env.env_origins, fx["origins"][t], err_msg=f"origins step {t}")
         if (t + 1) in full:
             np.testing.assert_allclose(obs, fx["full_obs"][full[t + 1]], rtol=0, atol=1e-4)
             np.testing.assert_allclose(priv, fx["full_priv"][full[t + 1]], rtol=0, atol=1e-4)
@@ -70,6 +76,25 @@ def test_terrain_fixture_places_robots_on_the_reference_tiles():
     assert fx["reset"].sum() >= 4 and fx["timeout"].sum() >= 2
     assert np.abs(fx["packs"][1:, 29:31]).sum() > 0                  # reset xy offsets were drawn
     assert float(fx["terrain_level_stat"]) == pytest.approx(fx["terrain_levels"].mean())
+
+
+def test_curriculum_fixture_shows_every_branch():
+    """Fixture D (terrain.curriculum=True): the reference's _update_terrain_curriculum (legged_robot.py:399-419) moved
+    robots up, down and -- past the last row -- to a drawn row; the constructor's reset moved nobody."""
+    fx = np.load(os.path.join(GOLD, "env_rollout_d.npz"))
+    rows = fx["terrain_origins"].shape[0]
+    assert np.array_equal(fx["init_env_origins"], fx["terrain_origins"][fx["init_terrain_levels"], fx["terrain_types"]])
+    prev, moves = fx["init_terrain_levels"].copy(), []
+    for t in range(fx["levels"].shape[0]):
+        changed = np.nonzero(fx["levels"][t] != prev)[0]
+        assert set(changed) <= set(np.nonzero(fx["reset"][t])[0])           # rows change only at a reset
+        for e in np.nonzero(fx["reset"][t])[0]:
+            moves.append((int(prev[e]), int(fx["levels"][t, e]), float(fx["packs"][t + 1][75, e])))
+        prev = fx["levels"][t]
+    assert any(b == a + 1 for a, b, _ in moves) and any(b == a - 1 for a, b, _ in moves)
+    wraps = [(a, b, u) for a, b, u in moves if a == rows - 1 and b == 0]        # 2 -> 0 can only be the random row
+    assert wraps and all(int(u * rows) == b for a, b, u in wraps)
+    assert fx["packs"].shape[1] == 76
 
 
 def test_fixture_exercises_events():
