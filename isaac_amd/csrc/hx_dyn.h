@@ -192,20 +192,11 @@ HXD float terrain_query(const DynParams& P, float u, float w, V3& nw) {
 // a_true != nullptr: returns the implicit-consistent net force (body coords)  sum_c [f0_c - K_c Xc a].
 // Plane: normal = world z, penetration = -z.  Terrain: normal of the triangle under the point, penetration =
 // distance to that triangle's plane.
-// `rad` bounds |r| over the point set (HX_RAD_*): when the body origin is more than `rad` above the highest ground any of
-// the points could meet, no point can penetrate and the whole shape is skipped (exact: such points contribute zero).
-#define HX_RAD_BASE 0.169f
-#define HX_RAD_THIGH 0.186f
-#define HX_RAD_TOE 0.097f
-#ifndef HX_CONTACT_UNROLL
-#define HX_CONTACT_UNROLL 1
-#endif
-HXD V3 contact_points(const DynParams& P, const float* pts, int npts, float rad, SV v, const M3& Rb, V3 pb, SV& f0, SI& B, const SV* a_true) {
+HXD V3 contact_points(const DynParams& P, const float* pts, int npts, SV v, const M3& Rb, V3 pb, SV& f0, SI& B, const SV* a_true) {
   const float c_n = P.dn + P.kn * P.dt;
   V3 net = mk(0.f, 0.f, 0.f);
-  if (!__any(pb.z - rad < (P.patch != nullptr ? P.zmax : 0.f))) return net;
   const V3 zb = row(Rb, 2);          // world z in body coords
-#pragma unroll HX_CONTACT_UNROLL
+#pragma unroll 1
   for (int k = 0; k < npts; ++k) {
     const V3 r = mk(pts[3 * k], pts[3 * k + 1], pts[3 * k + 2]);
     const float z = pb.z + dot(zb, r);
@@ -361,7 +352,7 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
       const M3& Rb = (L == 2) ? R_thigh : R_toe;
       SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
       SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-      contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, (L == 2) ? HX_RAD_THIGH : HX_RAD_TOE, v[L + 1], Rb, (L == 2) ? p_thigh : p_toe, f0, B, nullptr);
+      contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], Rb, (L == 2) ? p_thigh : p_toe, f0, B, nullptr);
       IA.A = IA.A + B.A; IA.H = IA.H + B.H; IA.M = IA.M + B.M;
       SV g; g.w = mk(0, 0, 0); g.v = P.gz * row(Rb, 2);
       pA = pA - f0 + mulSI(B, g);
@@ -416,7 +407,7 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
   {
     SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
     SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-    contact_points(P, C.basept + 12 * leg, 4, HX_RAD_BASE, v[0], R0, S.pos, f0, B, nullptr);
+    contact_points(P, C.basept + 12 * leg, 4, v[0], R0, S.pos, f0, B, nullptr);
     accI.A = accI.A + B.A; accI.H = accI.H + B.H; accI.M = accI.M + B.M;
     accP = accP - f0 + mulSI(B, g0);
   }
@@ -471,14 +462,14 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
     SV dmy; SI dmyB;
     {
       SV at = a[0]; at.v = at.v + g0.v;
-      const V3 part = contact_points(P, C.basept + 12 * leg, 4, HX_RAD_BASE, v[0], R0, S.pos, dmy, dmyB, &at);
+      const V3 part = contact_points(P, C.basept + 12 * leg, 4, v[0], R0, S.pos, dmy, dmyB, &at);
       F.base = mul(R0, part + xchg(part));
     }
     {
       SV at = a[3]; at.v = at.v + P.gz * row(R_thigh, 2);     // true spatial acceleration
-      F.thigh = mul(R_thigh, contact_points(P, C.thigh_pts(), 8, HX_RAD_THIGH, v[3], R_thigh, p_thigh, dmy, dmyB, &at));
+      F.thigh = mul(R_thigh, contact_points(P, C.thigh_pts(), 8, v[3], R_thigh, p_thigh, dmy, dmyB, &at));
       at = a[5]; at.v = at.v + P.gz * row(R_toe, 2);
-      F.toe = mul(R_toe, contact_points(P, C.toe_pts(), 8, HX_RAD_TOE, v[5], R_toe, p_toe, dmy, dmyB, &at));
+      F.toe = mul(R_toe, contact_points(P, C.toe_pts(), 8, v[5], R_toe, p_toe, dmy, dmyB, &at));
     }
   }
   // ---- integrate (semi-implicit Euler); the base update is identical on both lanes

@@ -51,21 +51,3 @@ def test_actor_critic_state_dict_layout():
     assert ac.num_params() == 1_517_973
     sd = ac.state_dict()
     assert sd["actor.0.weight"].shape == (512, 615) and abs(sd["actor.0.weight"]).max() <= 1 / np.sqrt(615) + 1e-6
-
-
-def test_contact_bounding_radii_cover_the_model():
-    """hx_dyn.h skips a whole collision shape when the body origin is more than HX_RAD_* above the ground: the radii
-    must bound every corner point of the compiled model."""
-    import json
-    import re
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "isaac_amd", "csrc", "hx_dyn.h")).read()
-    rad = {k: float(v) for k, v in re.findall(r"#define HX_RAD_(\w+) ([0-9.]+)f", src)}
-    model = json.load(open(os.path.join(root, "isaac_amd", "assets", "hector_model.json")))
-    seen = set()
-    for c in model["contacts"]:
-        name = model["bodies"][c["body"]]["name"].split("_")[-1].upper()
-        r = float(np.linalg.norm(np.asarray(c["points"]), axis=1).max())
-        assert r * (1 + 1e-4) < rad[name], (name, r, rad[name])
-        seen.add(name)
-    assert seen == {"BASE", "THIGH", "TOE"}
