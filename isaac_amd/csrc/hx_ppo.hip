@@ -970,6 +970,8 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
   return 0;
 }
 
+static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo* s);
+extern "C" void hx_ppo_destroy(hx_ppo* s);
 extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
@@ -986,6 +988,13 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   }
   static_assert(HEAD_ROWS * 8 == 256, "loss head: 8 lanes per row");
   hx_ppo* s = new hx_ppo();
+  const int rc = ppo_create_impl(cfg, stream, ext_grad, s);
+  if (rc) { hx_ppo_destroy(s); return rc; }      // nothing of a half-built learner survives an error
+  *out = s;
+  return 0;
+}
+
+static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo* s) {
   s->cfg = *cfg;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
@@ -1095,7 +1104,6 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
   s->prof = false; s->ev_used = 0;
   for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
-  *out = s;
   return 0;
 }
 
@@ -1104,9 +1112,12 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
   (void)hipDeviceSynchronize();      // the stream may be borrowed from an env that no longer exists
   for (void* a : s->allocs) (void)hipFree(a);
   for (auto e : s->ev) (void)hipEventDestroy(e);
-  (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2);
-  (void)hipEventDestroy(s->ev_fork); (void)hipEventDestroy(s->ev_join); (void)hipEventDestroy(s->ev_priv); (void)hipEventDestroy(s->ev_crit);
-  if (s->own_stream) (void)hipStreamDestroy(s->stream);
+  // null checks: hx_ppo_create also ends here with a half-built object, and a failed destroy call would leave a
+  // sticky HIP error for the next launch check to trip over
+  if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
+  for (hipEvent_t e : {s->ev_fork, s->ev_join, s->ev_priv, s->ev_crit})
+    if (e) (void)hipEventDestroy(e);
+  if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 

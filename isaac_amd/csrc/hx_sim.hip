@@ -726,12 +726,23 @@ template <typename T> static int dalloc(hx_sim* s, T** ptr, size_t count) {
   return 0;
 }
 
+static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const float* base_mass_h, const float* origins_h,
+                           const float* start_pos_h, uint64_t seed, void* stream, hx_sim* s);
+extern "C" void hx_sim_destroy(hx_sim* s);
 extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, const float* base_mass_h, const float* origins_h,
                              const float* start_pos_h, uint64_t seed, void* stream, hx_sim** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_sim_create: no HIP device (this library has no CPU path)"); return -1; }
   if (!cfg || cfg->num_envs <= 0) { hx_set_error("hx_sim_create: bad cfg"); return -2; }
   hx_sim* s = new hx_sim();
+  const int rc = sim_create_impl(cfg, friction_h, base_mass_h, origins_h, start_pos_h, seed, stream, s);
+  if (rc) { hx_sim_destroy(s); return rc; }       // nothing of a half-built simulator survives an error
+  *out = s;
+  return 0;
+}
+
+static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const float* base_mass_h, const float* origins_h,
+                           const float* start_pos_h, uint64_t seed, void* stream, hx_sim* s) {
   s->cfg = *cfg;
   s->seed = seed;
   s->step_counter = 0;
@@ -787,7 +798,6 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(s, &s->cfg_d, 1)) return -3;
   HX_CHECK(hipMemcpy(s->cfg_d, &s->cfg, sizeof(hx_sim_cfg), hipMemcpyHostToDevice));
-  *out = s;
   return 0;
 }
 

@@ -87,3 +87,15 @@ def test_more_than_32_actions_is_refused(hxlib):
     alg = PPO(ac, num_learning_epochs=1, num_mini_batches=1)
     with pytest.raises(RuntimeError, match="num_actions"):
         alg.init_storage(8, 2, [40], [40], [33])
+
+
+def test_failed_create_leaves_the_library_usable(hxlib):
+    """A configuration error found after allocation has begun (row stride smaller than the padded input width) frees the
+    half-built learner; the next learner works."""
+    ac = ActorCritic(40, 40, 4, actor_hidden_dims=[64, 64, 64], critic_hidden_dims=[64, 64, 64], init_noise_std=1.0)
+    alg = PPO(ac, num_learning_epochs=1, num_mini_batches=1)
+    with pytest.raises(RuntimeError, match="obs_ld"):
+        alg.init_storage(8, 2, [40], [40], [4], obs_ld=12)
+    ac, alg, orc, inp = _pair("odd", 1, 2, 8, 1, 1, 1e-4)
+    a = alg.act(inp["obs"][0], inp["priv"][0], eps=inp["eps"][0]).numpy()
+    np.testing.assert_allclose(a, orc.act(inp["obs"][0], inp["priv"][0], inp["eps"][0]), rtol=0, atol=5e-5)
