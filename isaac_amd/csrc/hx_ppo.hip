@@ -236,8 +236,8 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
   }
 }
 
-template <bool BF>
-__global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __restrict__ obs, int obs_ld, int n,
+template <bool BF, int NW>   // NW waves per workgroup (4 or 8): each owns 1/NW of a layer's output columns
+__global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __restrict__ obs, int obs_ld, int n,
                                                              const float* __restrict__ W1, const float* __restrict__ b1, int K1, int N1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int N2,
                                                              const float* __restrict__ W3, const float* __restrict__ b3, int N3,
@@ -255,22 +255,22 @@ __global__ void __launch_bounds__(256) hx_actor_fused_kernel(const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * FA_ROWS;
   // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
-  for (int i = tid; i < FA_ROWS * (K1 / 4); i += 256) {
+  for (int i = tid; i < FA_ROWS * (K1 / 4); i += 64 * NW) {
     const int r = i / (K1 / 4), c4 = i % (K1 / 4);
     const int gr = min(row0 + r, n - 1);
     const f32x4v v = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
     *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = BF ? hx_bf16r4(v) : v;
   }
   __syncthreads();
-  fa_layer<8, BF, BF>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * 128, lane);      // 615(616) -> 512 : 8 tiles per wave
+  fa_layer<32 / NW, BF, BF>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane);      // 615(616) -> 512
   __syncthreads();
-  fa_layer<4, BF, BF>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * 64, lane);       // 512 -> 256
+  fa_layer<16 / NW, BF, BF>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * (256 / NW), lane);      // 512 -> 256
   __syncthreads();
-  fa_layer<2, BF, false>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * 32, lane);      // the head reads H3 unrounded, like the update's fp32 loss head       // 256 -> 128
+  fa_layer<8 / NW, BF, false>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
   __syncthreads();
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]
-  if (tid < FA_ROWS * A) {
-    const int r = tid / A, j = tid % A;
+  for (int i = tid; i < FA_ROWS * A; i += 64 * NW) {
+    const int r = i / A, j = i % A;
     float m = 0.f;
     for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4[j * N3 + k], m);
     sMu[r * MAX_A + j] = m + b4[j];
@@ -731,6 +731,7 @@ struct hx_ppo {
   int64_t adam_t;
   int mb_done, mb_total;
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
+  int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
   uint32_t seed_lo, seed_hi, act_counter, perm_counter;
   // profiling
@@ -1097,8 +1098,13 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   for (int j = 0; j < A; ++j) sd[j] = cfg->init_noise_std;
   HX_CHECK(hipMemcpyAsync(s->params + s->std_off, sd.data(), sd.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  // 8 waves (each streams 1/8 of a layer's weight rows) keep twice the bytes in flight per CU: 68 us per call against
+  // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
+  { const char* e = getenv("HX_ACTOR_WAVES"); s->actor_waves = (e && atoi(e) == 4) ? 4 : 8; }
   HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
@@ -1258,8 +1264,14 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
                    s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
       // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
-      if (s->bf16) hipLaunchKernelGGL(hx_actor_fused_kernel<true>, dim3((count + FA_ROWS - 1) / FA_ROWS), dim3(256), shm, st, HX_FA_ARGS);
-      else hipLaunchKernelGGL(hx_actor_fused_kernel<false>, dim3((count + FA_ROWS - 1) / FA_ROWS), dim3(256), shm, st, HX_FA_ARGS);
+      const dim3 fgrid((count + FA_ROWS - 1) / FA_ROWS);
+      if (s->actor_waves == 8) {
+        if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+        else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+      } else {
+        if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
+        else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
+      }
 #undef HX_FA_ARGS
     } else {
       mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
