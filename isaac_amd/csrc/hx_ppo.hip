@@ -449,6 +449,7 @@ struct HeadArgs {
   float clip, vcoef, ecoef; int use_clipped_value_loss;
   float* dz3a; float* dz3c; float* slab; int slab_w;
 };
+template <int MA>   // register-array bound on the action count (16 for hector's 10, 32 otherwise): loops over MA are unrolled
 __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   extern __shared__ float sm[];
   const int hw = g.hw, hwc = g.hwc, A = g.A, hp = hw + 1, hpc = hwc + 1;
@@ -460,13 +461,14 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   float* sL = sD + HEAD_ROWS * (A + 1);  // [rows][4+A]  kl, vloss, sloss, entropy, dsigma[A]
   const int r0 = blockIdx.x * HEAD_ROWS;
   const int tid = threadIdx.x;
-  for (int i = tid; i < HEAD_ROWS * hw; i += 256) {
-    const int r = i / hw, k = i % hw;
-    sHa[r * hp + k] = (r0 + r) < g.M ? g.h3a[(size_t)(r0 + r) * hw + k] : 0.f;
-  }
-  for (int i = tid; i < HEAD_ROWS * hwc; i += 256) {
-    const int r = i / hwc, k = i % hwc;
-    sHc[r * hpc + k] = (r0 + r) < g.M ? g.h3c[(size_t)(r0 + r) * hwc + k] : 0.f;
+  // a wave per row, lanes along k (widths are multiples of 64): coalesced and free of integer divisions
+  const int wave = tid >> 6, lane = tid & 63, hmax = hw > hwc ? hw : hwc;
+  for (int r = wave; r < HEAD_ROWS; r += 4) {
+    const bool ok = (r0 + r) < g.M;
+    for (int k = lane; k < hmax; k += 64) {      // one loop for both nets: two loads in flight per trip
+      if (k < hw) sHa[r * hp + k] = ok ? g.h3a[(size_t)(r0 + r) * hw + k] : 0.f;
+      if (k < hwc) sHc[r * hpc + k] = ok ? g.h3c[(size_t)(r0 + r) * hwc + k] : 0.f;
+    }
   }
   for (int i = tid; i < A * hw; i += 256) sW[i] = g.W4[i];
   for (int i = tid; i < hwc; i += 256) sWc[i] = g.W4c[i];
@@ -476,14 +478,22 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
     // lane 0 of the row finishes the loss terms
     const int r = tid >> 3, part = tid & 7, m = r0 + r;
     const int per = hw / 8, perc = hwc / 8;
-    float mu[MAX_A];
+    float mu[MA];
     for (int j = 0; j < A; ++j) mu[j] = 0.f;
     float v = 0.f;
-    for (int k = part * per; k < (part + 1) * per; ++k) {
-      const float x = sHa[r * hp + k];
-      for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
+    if (hw == hwc) {           // one pass over k for both nets (hector: 128 / 128)
+      for (int k = part * per; k < (part + 1) * per; ++k) {
+        const float x = sHa[r * hp + k];
+        for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
+        v = fmaf(sHc[r * hpc + k], sWc[k], v);
+      }
+    } else {
+      for (int k = part * per; k < (part + 1) * per; ++k) {
+        const float x = sHa[r * hp + k];
+        for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
+      }
+      for (int k = part * perc; k < (part + 1) * perc; ++k) v = fmaf(sHc[r * hpc + k], sWc[k], v);
     }
-    for (int k = part * perc; k < (part + 1) * perc; ++k) v = fmaf(sHc[r * hpc + k], sWc[k], v);
     for (int o = 4; o > 0; o >>= 1) {
       for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
       v += __shfl_xor(v, o);
@@ -496,7 +506,7 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
       const float* row = g.row_mb + (size_t)m * (2 * A + 4);
       v += g.b4c[0];
       float logp = 0.f, ent = 0.f, kl = 0.f;
-      float sg[MAX_A];
+      float sg[MA];
       for (int j = 0; j < A; ++j) {
         mu[j] += g.b4[j];
         sg[j] = mu[j] * 0.f + g.stdp[j];
@@ -541,19 +551,21 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   }
   __syncthreads();
   // dZ3 = (W4^T dmu) * elu'(h3)   and   dZ3c = dv w4c * elu'(h3c)
-  for (int i = tid; i < HEAD_ROWS * hw; i += 256) {
-    const int r = i / hw, k = i % hw;
+  for (int r = wave; r < HEAD_ROWS; r += 4) {
     if (r0 + r >= g.M) continue;
-    float s = 0.f;
-    for (int j = 0; j < A; ++j) s = fmaf(sD[r * (A + 1) + j], sW[j * hw + k], s);
-    const float ha = sHa[r * hp + k];
-    g.dz3a[(size_t)(r0 + r) * hw + k] = s * (ha > 0.f ? 1.f : ha + 1.f);
-  }
-  for (int i = tid; i < HEAD_ROWS * hwc; i += 256) {
-    const int r = i / hwc, k = i % hwc;
-    if (r0 + r >= g.M) continue;
-    const float hc = sHc[r * hpc + k];
-    g.dz3c[(size_t)(r0 + r) * hwc + k] = sD[r * (A + 1) + A] * sWc[k] * (hc > 0.f ? 1.f : hc + 1.f);
+    const float dv = sD[r * (A + 1) + A];
+    for (int k = lane; k < hmax; k += 64) {
+      if (k < hw) {
+        float s = 0.f;
+        for (int j = 0; j < A; ++j) s = fmaf(sD[r * (A + 1) + j], sW[j * hw + k], s);
+        const float ha = sHa[r * hp + k];
+        g.dz3a[(size_t)(r0 + r) * hw + k] = s * (ha > 0.f ? 1.f : ha + 1.f);
+      }
+      if (k < hwc) {
+        const float hc = sHc[r * hpc + k];
+        g.dz3c[(size_t)(r0 + r) * hwc + k] = dv * sWc[k] * (hc > 0.f ? 1.f : hc + 1.f);
+      }
+    }
   }
   // partial parameter gradients of the two heads, summed over this workgroup's rows
   float* slab = g.slab + (size_t)blockIdx.x * g.slab_w;
@@ -1105,7 +1117,14 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   // 8 waves (each streams 1/8 of a layer's weight rows) keep twice the bytes in flight per CU: 68 us per call against
   // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
   { const char* e = getenv("HX_ACTOR_WAVES"); s->actor_waves = (e && atoi(e) == 4) ? 4 : 8; }
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  {
+    const int ha_ = cfg->actor_hidden[2], hc_ = cfg->critic_hidden[2];
+    const size_t head_lds = (size_t)(HEAD_ROWS * (ha_ + 1) + HEAD_ROWS * (hc_ + 1) + A * ha_ + hc_ + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
+    if (head_lds > 64 * 1024) {      // only wide critics need the opt-in; hector's 43 KB launch keeps the default
+      HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+  }
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
   s->prof = false; s->ev_used = 0;
@@ -1406,7 +1425,8 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   h.clip = c.clip_param; h.vcoef = c.value_loss_coef; h.ecoef = c.entropy_coef; h.use_clipped_value_loss = c.use_clipped_value_loss;
   h.dz3a = s->dz_a[2]; h.dz3c = s->dz_c[2]; h.slab = s->head_slab; h.slab_w = s->head_slab_w;
   const size_t shm = (size_t)(HEAD_ROWS * (hw + 1) + HEAD_ROWS * (hwc + 1) + A * hw + hwc + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
-  hipLaunchKernelGGL(hx_loss_head_kernel, dim3(hblocks), dim3(256), shm, st, h);
+  if (A <= 16) hipLaunchKernelGGL(hx_loss_head_kernel<16>, dim3(hblocks), dim3(256), shm, st, h);
+  else hipLaunchKernelGGL(hx_loss_head_kernel<32>, dim3(hblocks), dim3(256), shm, st, h);
   HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw, hwc};
   const int hchunk = 32, hchunks = (hblocks + hchunk - 1) / hchunk;
   hipLaunchKernelGGL(hx_slab_chunk_kernel, dim3((s->head_slab_w + 255) / 256, hchunks), dim3(256), 0, st, s->head_slab, hblocks, s->head_slab_w, hchunk, s->head_slab2);
