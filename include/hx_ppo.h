@@ -112,6 +112,10 @@ int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, con
 
 /* timing hook: mean ms per launch of one learner GEMM (kind 0 fwd, 1 dgrad, 2 wgrad split-K; bk 16 or 32) */
 int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out);
+/* measurement hook: TFLOP/s of 256-thread workgroups whose waves issue n v_mfma_f32_32x32x2_f32 each with, by mode,
+ * 0 nothing else, 1 + the GEMM's LDS fragment reads, 2 + a barrier per BK=16 tile, 3 + the tile's global loads and LDS
+ * stores -- where between the matrix-pipe peak and the GEMM kernels the throughput goes (tools/mfma_peak.py) */
+int hx_mfma_probe(int mode, int blocks, int n, float* tflops_out);
 
 /* device memory helpers for hosts without a tensor library */
 int hx_malloc(size_t bytes, void** out);

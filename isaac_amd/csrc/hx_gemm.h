@@ -43,8 +43,13 @@ struct GemmArgs {
 // activation's own scale); the libm expm1f it replaces cost ~10 % of a short-K GEMM's epilogue.
 __device__ __forceinline__ float hx_elu(float x) { return x > 0.f ? x : (__expf(x) - 1.0f); }
 
+#ifdef HX_GEMM_WAVES
+#define HX_GEMM_OCC __attribute__((amdgpu_waves_per_eu(HX_GEMM_WAVES, HX_GEMM_WAVES)))
+#else
+#define HX_GEMM_OCC
+#endif
 template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI>
-__global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
+__global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
   constexpr int A_ELEMS = A_KM ? BM * (HX_BK + HX_KPAD) : HX_BK * BM;
@@ -88,37 +93,65 @@ __global__ void __launch_bounds__(256) hx_gemm_kernel(GemmArgs g) {
   f32x4 ra[A_LOADS], rb[B_LOADS];
   float dbacc = 0.f;
 
-  auto load_tile = [&](int kt) {
-    const int k0 = k_begin + kt * HX_BK;
+  // Global -> register staging of one K tile.  The MFMA loop must stay nearly free of VALU work and of divergent
+  // regions (tools/mfma_peak.py, profiles/r01_n_mfma_probe.txt: a probe with this loop's ingredients sustains 0.91 of the
+  // matrix-pipe peak, 0.80 once its loads are guarded; per-tile 64-bit address arithmetic costs about as much).  So:
+  //   * every lane owns fixed (row, k-offset) slots; their addresses are computed ONCE and advanced by a constant stride;
+  //   * rows / columns past the matrix edge alias a valid row (their products land in output elements that the epilogue
+  //     never stores), so no lane is ever masked off;
+  //   * only the last tile of a reduction can be partial in k: a uniform branch takes the zero-filling path there.
+  const float* pa[A_LOADS]; const float* pb[B_LOADS];
+  int ka[A_LOADS], kb_[B_LOADS];                    // k offset of the slot inside a tile
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (A_KM) {
-        const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
-        const int gm = m0 + row, gk = k0 + k4 * 4;
-        if (gm < g.M && gk < k_end) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gm * g.lda + gk);
-      } else {
-        const int k = idx / (BM / 4), m4 = idx % (BM / 4);
-        const int gk = k0 + k, gm = m0 + m4 * 4;
-        if (gk < k_end && gm < g.M) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)gk * g.lda + gm);
-      }
-      ra[i] = v;
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int idx = tid + i * 256;
+    if (A_KM) {
+      const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
+      ka[i] = k4 * 4;
+      pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + k_begin + k4 * 4;
+    } else {
+      const int k = idx / (BM / 4), m4 = idx % (BM / 4);
+      const int gm = m0 + m4 * 4;
+      ka[i] = k;
+      pa[i] = g.A + (size_t)(k_begin + k) * g.lda + (gm < g.M ? gm : 0);
     }
+  }
 #pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int idx = tid + i * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (B_KM) {
-        const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
-        const int gn = n0 + row, gk = k0 + k4 * 4;
-        if (gn < g.N && gk < k_end) v = *reinterpret_cast<const f32x4*>(g.B + (size_t)gn * g.ldb + gk);
-      } else {
-        const int k = idx / (BN / 4), n4 = idx % (BN / 4);
-        const int gk = k0 + k, gn = n0 + n4 * 4;
-        if (gk < k_end && gn < g.N) v = *reinterpret_cast<const f32x4*>(g.B + (size_t)gk * g.ldb + gn);
+  for (int i = 0; i < B_LOADS; ++i) {
+    const int idx = tid + i * 256;
+    if (B_KM) {
+      const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
+      kb_[i] = k4 * 4;
+      pb[i] = g.B + (size_t)min(n0 + row, g.N - 1) * g.ldb + k_begin + k4 * 4;
+    } else {
+      const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+      const int gn = n0 + n4 * 4;
+      kb_[i] = k;
+      pb[i] = g.B + (size_t)(k_begin + k) * g.ldb + (gn < g.N ? gn : 0);
+    }
+  }
+  const size_t stride_a = A_KM ? (size_t)HX_BK : (size_t)HX_BK * g.lda;
+  const size_t stride_b = B_KM ? (size_t)HX_BK : (size_t)HX_BK * g.ldb;
+  auto load_tile = [&](int kt) {        // tiles must be requested in order 0, 1, 2, ...: the slot pointers advance
+    const int k0 = k_begin + kt * HX_BK;
+    if (k0 + HX_BK <= k_end) {          // uniform: whole tile inside the reduction range
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) { ra[i] = *reinterpret_cast<const f32x4*>(pa[i]); pa[i] += stride_a; }
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i) { rb[i] = *reinterpret_cast<const f32x4*>(pb[i]); pb[i] += stride_b; }
+    } else {                            // the one partial tile at the end: k positions past k_end contribute zeros
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + ka[i] < k_end) v = *reinterpret_cast<const f32x4*>(pa[i]);
+        ra[i] = v;
       }
-      rb[i] = v;
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k0 + kb_[i] < k_end) v = *reinterpret_cast<const f32x4*>(pb[i]);
+        rb[i] = v;
+      }
     }
   };
   auto store_tile = [&](int buf) {

@@ -929,6 +929,112 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   return 0;
 }
 
+// Matrix-pipe ceiling probe (tools/mfma_peak.py): what rate does v_mfma_f32_32x32x2_f32 sustain when a wave does
+//   mode 0  nothing else (register operands, NACC independent accumulators)
+//   mode 1  + the GEMM's LDS fragment reads: 4 x ds_read_b128 per 16 MFMAs (2x2 tiles of 32x32, 8-deep k block)
+//   mode 2  + one workgroup barrier per 32 MFMAs (a BK = 16 tile)
+//   mode 3  + the tile's global loads (4 x dwordx4 per thread) and LDS stores per 32 MFMAs, double-buffered like hx_gemm.h
+//   mode 4  = 3 with the wgrad kernel's fragment reads (operands stored [k][rows]: 4 x ds_read_b32 per operand per k block)
+//   mode 5  = 3 with guarded global loads (exec-masked, as at the edges of a real matrix; the guard is always true here)
+// No result of the probe is meaningful; only the instruction streams are.
+template <int MODE>
+__global__ void __launch_bounds__(256) hx_mfma_probe_kernel(float* out, const float* __restrict__ src, int n) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * 128 * 20];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r32 = lane & 31;
+  for (int i = tid; i < 2 * 2 * 128 * 20; i += 256) lds[i] = 1.0f + 1e-6f * (float)(i & 1023);
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  f32x4 fa[2], fb[2];
+  fa[0] = fa[1] = fb[0] = fb[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
+  f32x4 st[4];
+  const float* gp = src + (size_t)blockIdx.x * 4096 + tid * 4;
+  if (MODE >= 3) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st[q] = *reinterpret_cast<const f32x4*>(gp + q * 1024);
+  }
+  const int wm = wave >> 1, wn = wave & 1;
+  for (int it = 0; it < n; it += 32) {                  // one BK = 16 tile: 2 k-blocks x 16 MFMAs
+    const int buf = (it >> 5) & 1;
+    const float* As = lds + buf * (2 * 128 * 20);
+    const float* Bs = As + 128 * 20;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (MODE == 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            fa[i][j] = As[(kb * 8 + 4 * h + j) * 128 + wm * 64 + i * 32 + r32];
+            fb[i][j] = Bs[(kb * 8 + 4 * h + j) * 128 + wn * 64 + i * 32 + r32];
+          }
+      } else if (MODE >= 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          fa[i] = *reinterpret_cast<const f32x4*>(As + (wm * 64 + i * 32 + r32) * 20 + kb * 8 + 4 * h);
+          fb[i] = *reinterpret_cast<const f32x4*>(Bs + (wn * 64 + i * 32 + r32) * 20 + kb * 8 + 4 * h);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    }
+    if (MODE >= 3) {
+      float* Ws = lds + (buf ^ 1) * (2 * 128 * 20);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(Ws + ((tid + q * 256) >> 2) * 20 + ((tid + q * 256) & 3) * 4) = st[q];
+      const float* gq = gp + (size_t)(((it >> 5) + 1) & 15) * 4 * 1024 * 0;     // same 16 KB again: an L2 hit, like the GEMM's re-used operand rows
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (MODE == 5) { st[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (tid * 4 + q < n) st[q] = *reinterpret_cast<const f32x4*>(gq + q * 1024); }
+        else st[q] = *reinterpret_cast<const f32x4*>(gq + q * 1024);
+      }
+    }
+    if (MODE >= 2) __syncthreads();
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s += acc[a][b][e];
+  out[blockIdx.x * 256 + tid] = s;
+}
+extern "C" int hx_mfma_probe(int mode, int blocks, int n, float* tflops_out) {
+  float *out = nullptr, *src = nullptr;
+  HX_CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+  HX_CHECK(hipMalloc(&src, (size_t)blocks * 4096 * 4));
+  HX_CHECK(hipMemset(src, 0x3c, (size_t)blocks * 4096 * 4));
+  hipEvent_t e0, e1; HX_CHECK(hipEventCreate(&e0)); HX_CHECK(hipEventCreate(&e1));
+  auto run = [&]() {
+    if (mode == 0) hipLaunchKernelGGL(hx_mfma_probe_kernel<0>, dim3(blocks), dim3(256), 0, 0, out, src, n);
+    else if (mode == 1) hipLaunchKernelGGL(hx_mfma_probe_kernel<1>, dim3(blocks), dim3(256), 0, 0, out, src, n);
+    else if (mode == 2) hipLaunchKernelGGL(hx_mfma_probe_kernel<2>, dim3(blocks), dim3(256), 0, 0, out, src, n);
+    else if (mode == 3) hipLaunchKernelGGL(hx_mfma_probe_kernel<3>, dim3(blocks), dim3(256), 0, 0, out, src, n);
+    else if (mode == 4) hipLaunchKernelGGL(hx_mfma_probe_kernel<4>, dim3(blocks), dim3(256), 0, 0, out, src, n);
+    else hipLaunchKernelGGL(hx_mfma_probe_kernel<5>, dim3(blocks), dim3(256), 0, 0, out, src, n);
+  };
+  run();
+  HX_CHECK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 5; ++i) run();
+  HX_CHECK(hipEventRecord(e1, 0));
+  HX_CHECK(hipEventSynchronize(e1));
+  HX_CHECK(hipGetLastError());
+  float ms = 0; HX_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  *tflops_out = (float)(5.0 * blocks * 4.0 * n * (2.0 * 32 * 32 * 2) / (ms * 1e-3) / 1e12);
+  (void)hipFree(out); (void)hipFree(src); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+}
+
 // timing hook (tools/gemm_bench.py): `iters` launches of one learner GEMM on scratch buffers filled with a
 // non-trivial bit pattern; returns the mean milliseconds per launch measured with HIP events on the stream.
 extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out) {
@@ -937,7 +1043,8 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
   float *X, *W, *Y, *slab, *bslab;
   const size_t nx = (size_t)rows * in_ld, ny = (size_t)rows * out, nw = (size_t)out * in_ld;
   HX_CHECK(hipMalloc(&X, nx * 4)); HX_CHECK(hipMalloc(&W, nw * 4)); HX_CHECK(hipMalloc(&Y, ny * 4));
-  const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
+  const int wbm = getenv("HX_WGRAD_BM") ? atoi(getenv("HX_WGRAD_BM")) : 128;      // experiment: 256-row wgrad tiles
+  const int tiles = ((out + wbm - 1) / wbm) * ((in_ld + 127) / 128);
   static int target_blocks = -1, round_up = 1;
   if (target_blocks < 0) {
     const char* e = getenv("HX_WGRAD_BLOCKS");
@@ -967,7 +1074,9 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
     else if (kind == 1) { g.A = Y; g.lda = out; g.B = W; g.ldb = in_ld; g.C = X; g.ldc = in_ld; g.M = rows; g.N = in_ld; g.K = out; g.H = X; g.ldh = in_ld;
       HX_PICK(true, false, EPI_ELU_GRAD); }
     else { g.A = Y; g.lda = out; g.B = X; g.ldb = in_ld; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = rows; g.splits = splits; g.kchunk = kchunk; g.dbias = bslab;
-      if (bk == 16) HX_V(128, 16, false, false, EPI_SLAB); else HX_V(128, 32, false, false, EPI_SLAB); }
+      if (getenv("HX_BENCH_LD0")) { g.lda = 0; g.ldb = 0; }      // experiment: every k row aliases row 0 -> operands come from the L1
+      if (wbm == 256) HX_V(256, 16, false, false, EPI_SLAB);
+      else if (bk == 16) HX_V(128, 16, false, false, EPI_SLAB); else HX_V(128, 32, false, false, EPI_SLAB); }
 #undef HX_PICK
 #undef HX_V
   };
