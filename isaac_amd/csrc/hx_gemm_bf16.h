@@ -54,8 +54,24 @@ __global__ void __launch_bounds__(256) hx_gemm_bf16_kernel(GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 ra[LOADS], rb[LOADS];
+  // Interior tiles (all of them at the production sizes) load through one base pointer per operand plus uniform offsets:
+  // no per-tile 64-bit address arithmetic and no divergent regions in the MFMA loop (hx_gemm.h, profiles/r01_n_mfma_probe.txt)
+  const bool fast_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+  const int row_t = tid / (HXB_BK / 4), k4_t = tid % (HXB_BK / 4);
+  const float* pa0 = g.A + (size_t)(fast_mn ? m0 + row_t : 0) * g.lda + k4_t * 4;
+  const float* pb0 = g.B + (size_t)(fast_mn ? n0 + row_t : 0) * g.ldb + k4_t * 4;
+  constexpr int ROWS_PER_PASS = 256 / (HXB_BK / 4);
+  const size_t sa = (size_t)ROWS_PER_PASS * g.lda, sb = (size_t)ROWS_PER_PASS * g.ldb;
   auto load_tile = [&](int kt) {
     const int k0 = kt * HXB_BK;
+    if (fast_mn && k0 + HXB_BK <= g.K) {
+#pragma unroll
+      for (int i = 0; i < LOADS; ++i) {
+        ra[i] = *reinterpret_cast<const f32x4*>(pa0 + k0 + i * sa);
+        rb[i] = *reinterpret_cast<const f32x4*>(pb0 + k0 + i * sb);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < LOADS; ++i) {
       const int idx = tid + i * 256;
@@ -206,8 +222,25 @@ __global__ void __launch_bounds__(256) hx_wgrad_bf16_kernel(GemmArgs g) {
   const bool want_db = (g.dbias != nullptr) && (tile_n == 0);
   f32x4 dbacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
+  // whole tiles inside the matrix and the reduction range (every tile but the last of a split at the production sizes):
+  // one base pointer per operand, uniform offsets, no divergent regions in the MFMA loop (hx_gemm.h)
+  const bool fast_mn = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+  const float* pa0 = g.A + (size_t)(k_begin + 4 * (tid >> 5)) * g.lda + (fast_mn ? m0 + 4 * (tid & 31) : 0);
+  const float* pb0 = g.B + (size_t)(k_begin + 4 * (tid >> 5)) * g.ldb + (fast_mn ? n0 + 4 * (tid & 31) : 0);
   auto load_tile = [&](int kt) {
     const int k0 = k_begin + kt * HXB_BK;
+    if (fast_mn && k0 + HXB_BK <= k_end) {
+      const float* pa = pa0 + (size_t)(kt * HXB_BK) * g.lda;
+      const float* pb = pb0 + (size_t)(kt * HXB_BK) * g.ldb;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)               // idx = tid + 256 i  ->  kb = (tid >> 5) + 8 i: rows 32 i further down
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ra[i][j] = *reinterpret_cast<const f32x4*>(pa + (size_t)(32 * i + j) * g.lda);
+          rb[i][j] = *reinterpret_cast<const f32x4*>(pb + (size_t)(32 * i + j) * g.ldb);
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + i * 256;
