@@ -160,7 +160,7 @@ def main():
     if comm.rank == 0:
         env_steps = T * args.envs * world * args.steps
         value = env_steps / elapsed
-        out = {"metric": "env-steps/sec (whole node), hector 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+        out = {"metric": f"env-steps/sec (whole node), hector {args.envs} envs/GPU", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"hector {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
