@@ -33,7 +33,8 @@ struct GemmArgs {
   const float* bias;        // EPI_BIAS_ELU / EPI_BIAS: [N]
   const float* H; int ldh;  // EPI_ELU_GRAD: activations of the layer whose pre-activation gradient is produced
   int splits, kchunk;       // EPI_SLAB: reduction split; C is [splits][M][ldc]
-  float* dbias;             // EPI_SLAB: [splits][M] column sums of A (bias gradient), nullable
+  float* dbias;             // EPI_SLAB: [splits * db_parts][M] partial column sums of A (bias gradient), nullable
+  int db_parts;             // EPI_SLAB: the column-sum work of a (tile_m, split) is shared by the first db_parts tile_n blocks
   int tiles_m, tiles_n;
 };
 
@@ -91,6 +92,11 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 ra[A_LOADS], rb[B_LOADS];
+  // Bias gradient = column sums of dZ = row sums over k of the A tile.  Every tile_n block of a (tile_m, split) sees the
+  // same A tiles; block tile_n takes K tiles tile_n, tile_n + P, ... (P = db_parts) and writes its own partial row, so no
+  // block carries the whole side job (one owner made the launch 4 % longer: all workgroups end with the slowest).
+  const bool db_owner = (EPI == EPI_SLAB) && !A_KM && (g.dbias != nullptr) && (tile_n < g.db_parts) && (tid < BM);
+  int db_next = tile_n;
   float dbacc = 0.f;
 
   // Global -> register staging of one K tile.  The MFMA loop must stay nearly free of VALU work and of divergent
@@ -210,13 +216,17 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q][a][j], f.b[q][b][j], acc[a][b], 0, 0, 0);
   };
-  auto bias_grad = [&](int buf) {
+  auto bias_grad = [&](int buf, int kt) {
     if (EPI == EPI_SLAB && !A_KM) {
-      // bias gradient = column sums of dZ = row sums over k of the A tile; done once per tile row
-      const float* As = lds + buf * (A_ELEMS + B_ELEMS);
-      if (g.dbias != nullptr && tile_n == 0 && tid < BM) {
+      if (kt == db_next) {                                   // uniform
+        db_next += g.db_parts;
+        if (db_owner) {
+          const float* As = lds + buf * (A_ELEMS + B_ELEMS);
+          float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;      // four chains instead of one 16-deep dependent chain
 #pragma unroll
-        for (int k = 0; k < HX_BK; ++k) dbacc += As[k * BM + tid];
+          for (int k = 0; k < HX_BK; k += 4) { p0 += As[k * BM + tid]; p1 += As[(k + 1) * BM + tid]; p2 += As[(k + 2) * BM + tid]; p3 += As[(k + 3) * BM + tid]; }
+          dbacc += (p0 + p1) + (p2 + p3);
+        }
       }
     }
   };
@@ -241,7 +251,7 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       read_frags(cur, 1, f1);
-      bias_grad(cur);
+      bias_grad(cur, kt);
       mfma_half(f0);
       if (kt + 1 < nk) store_tile(cur ^ 1);
       if (kt + 2 < nk) load_tile(kt + 2);
@@ -251,7 +261,7 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
     }
   }
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int kt) {
     const float* As = lds + buf * (A_ELEMS + B_ELEMS);
     const float* Bs = As + A_ELEMS;
 #pragma unroll
@@ -289,13 +299,7 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
       __builtin_amdgcn_s_setprio(0);
 #endif
     }
-    if (EPI == EPI_SLAB && !A_KM) {
-      // bias gradient = column sums of dZ = row sums over k of the A tile; done once per tile row
-      if (g.dbias != nullptr && tile_n == 0 && tid < BM) {
-#pragma unroll
-        for (int k = 0; k < HX_BK; ++k) dbacc += As[k * BM + tid];
-      }
-    }
+    bias_grad(buf, kt);
   };
 
   // Plain double-buffered loop (two barriers' worth of exposed LDS latency per K tile, but fewer live registers):
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = (kt + 1 < nk);
       if (more) load_tile(kt + 1);
-      compute(kt & 1);
+      compute(kt & 1, kt);
       if (more) store_tile((kt + 1) & 1);
       __syncthreads();
     }
@@ -371,6 +375,6 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
       }
   }
   if (EPI == EPI_SLAB && !A_KM) {
-    if (g.dbias != nullptr && tile_n == 0 && tid < BM && m0 + tid < g.M) g.dbias[(size_t)split * g.M + m0 + tid] = dbacc;
+    if (db_owner && m0 + tid < g.M) g.dbias[((size_t)split * g.db_parts + tile_n) * g.M + m0 + tid] = dbacc;
   }
 }

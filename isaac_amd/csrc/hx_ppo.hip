@@ -853,8 +853,10 @@ static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, cons
   if (s->bf16 && WT != nullptr) { g.B = WT; g.ldb = K; launch_gemm_bf16<EPI_ELU_GRAD>(s, g, st); return; }   // B = W^T[N][K], K-major
   launch_gemm<64, 128, 32, true, false, EPI_ELU_GRAD>(s, g, st);
 }
-// dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab / bias_slab
-static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab) {
+// dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab; *bias_parts = number of
+// partial rows written to bias_slab (splits x the tile_n blocks that share the column-sum work)
+static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab,
+                      int* bias_parts) {
   GemmArgs g{};
   g.A = dZ; g.lda = out; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = Mrows;
   const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
@@ -880,6 +882,8 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
     splits = (Mrows + kchunk - 1) / kchunk;
   }
   g.splits = splits; g.kchunk = kchunk; g.dbias = bias_slab;
+  g.db_parts = s->bf16 ? 1 : (in_ld + 127) / 128;
+  *bias_parts = splits * g.db_parts;
   if (s->bf16) {
     g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
     const int blocks = g.tiles_m * g.tiles_n * g.splits;
@@ -920,8 +924,14 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   else if (mode == 4) launch_gemm<64, 128, BKV, true, false, EPI_ELU_GRAD>(nullptr, g, st);                 \
   else if (mode == 2) {                                                                                    \
     /* single split, direct output (C holds [M][ldc]); column sums of A are written to `bias` */           \
-    g.splits = 1; g.kchunk = rup(K, 32); g.dbias = const_cast<float*>(bias);                               \
+    g.splits = 1; g.kchunk = rup(K, 32); g.db_parts = (N + 127) / 128;                                    \
+    float* dbtmp = nullptr;                                                                                \
+    HX_CHECK(hipMalloc(&dbtmp, (size_t)g.db_parts * M * sizeof(float)));                                   \
+    g.dbias = dbtmp;                                                                                       \
     launch_gemm<128, 128, BKV, false, false, EPI_SLAB>(nullptr, g, st);                                     \
+    hipLaunchKernelGGL(hx_slab_chunk_kernel, dim3((M + 255) / 256, 1), dim3(256), 0, st, dbtmp, g.db_parts, M, g.db_parts, const_cast<float*>(bias)); \
+    HX_CHECK(hipStreamSynchronize(st));                                                                    \
+    (void)hipFree(dbtmp);                                                                                  \
   } else { hx_set_error("hx_ppo_gemm_test: bad mode"); return -2; }
   if (variant == 0) { HX_DISPATCH(16) } else { HX_DISPATCH(32) }
 #undef HX_DISPATCH
@@ -953,7 +963,7 @@ __global__ void __launch_bounds__(256) hx_mfma_probe_kernel(float* out, const fl
   f32x4 fa[2], fb[2];
   fa[0] = fa[1] = fb[0] = fb[1] = (f32x4){1.f, 1.f, 1.f, 1.f};
   f32x4 st[4];
-  const float* gp = src + (size_t)blockIdx.x * 4096 + tid * 4;
+  const float* gp = src + (size_t)blockIdx.x * 4 * 4096 + tid * 4;
   if (MODE >= 3) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) st[q] = *reinterpret_cast<const f32x4*>(gp + q * 1024);
@@ -991,7 +1001,7 @@ __global__ void __launch_bounds__(256) hx_mfma_probe_kernel(float* out, const fl
       float* Ws = lds + (buf ^ 1) * (2 * 128 * 20);
 #pragma unroll
       for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(Ws + ((tid + q * 256) >> 2) * 20 + ((tid + q * 256) & 3) * 4) = st[q];
-      const float* gq = gp + (size_t)(((it >> 5) + 1) & 15) * 4 * 1024 * 0;     // same 16 KB again: an L2 hit, like the GEMM's re-used operand rows
+      const float* gq = gp + (size_t)(((it >> 5) + 1) & 3) * 4096;     // walks a 64 KB window per workgroup: L2 / Infinity-Cache hits, and the loads cannot be hoisted out of the loop
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (MODE == 5) { st[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (tid * 4 + q < n) st[q] = *reinterpret_cast<const f32x4*>(gq + q * 1024); }
@@ -1012,8 +1022,8 @@ __global__ void __launch_bounds__(256) hx_mfma_probe_kernel(float* out, const fl
 extern "C" int hx_mfma_probe(int mode, int blocks, int n, float* tflops_out) {
   float *out = nullptr, *src = nullptr;
   HX_CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
-  HX_CHECK(hipMalloc(&src, (size_t)blocks * 4096 * 4));
-  HX_CHECK(hipMemset(src, 0x3c, (size_t)blocks * 4096 * 4));
+  HX_CHECK(hipMalloc(&src, (size_t)blocks * 4 * 4096 * 4));
+  HX_CHECK(hipMemset(src, 0x3c, (size_t)blocks * 4 * 4096 * 4));
   hipEvent_t e0, e1; HX_CHECK(hipEventCreate(&e0)); HX_CHECK(hipEventCreate(&e1));
   auto run = [&]() {
     if (mode == 0) hipLaunchKernelGGL(hx_mfma_probe_kernel<0>, dim3(blocks), dim3(256), 0, 0, out, src, n);
@@ -1054,7 +1064,7 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
   int splits = round_up ? (target_blocks + tiles - 1) / tiles : target_blocks / tiles;
   if (splits < 1) splits = 1; int max_splits = rows / HX_WGRAD_MIN_CHUNK; if (max_splits < 1) max_splits = 1; if (splits > max_splits) splits = max_splits;
   int kchunk = rup((rows + splits - 1) / splits, 32); splits = (rows + kchunk - 1) / kchunk;
-  HX_CHECK(hipMalloc(&slab, (size_t)splits * nw * 4)); HX_CHECK(hipMalloc(&bslab, (size_t)splits * out * 4));
+  HX_CHECK(hipMalloc(&slab, (size_t)splits * nw * 4)); HX_CHECK(hipMalloc(&bslab, (size_t)splits * ((in_ld + 127) / 128) * out * 4));
   HX_CHECK(hipMemset(X, 0x3d, nx * 4)); HX_CHECK(hipMemset(W, 0x3c, nw * 4)); HX_CHECK(hipMemset(Y, 0x3b, ny * 4));
   hipStream_t st; HX_CHECK(hipStreamCreate(&st));
   hipEvent_t e0, e1; HX_CHECK(hipEventCreate(&e0)); HX_CHECK(hipEventCreate(&e1));
@@ -1073,8 +1083,9 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
       HX_PICK(true, true, EPI_BIAS_ELU); }
     else if (kind == 1) { g.A = Y; g.lda = out; g.B = W; g.ldb = in_ld; g.C = X; g.ldc = in_ld; g.M = rows; g.N = in_ld; g.K = out; g.H = X; g.ldh = in_ld;
       HX_PICK(true, false, EPI_ELU_GRAD); }
-    else { g.A = Y; g.lda = out; g.B = X; g.ldb = in_ld; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = rows; g.splits = splits; g.kchunk = kchunk; g.dbias = bslab;
+    else { g.A = Y; g.lda = out; g.B = X; g.ldb = in_ld; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = rows; g.splits = splits; g.kchunk = kchunk; g.dbias = bslab; g.db_parts = (in_ld + 127) / 128;
       if (getenv("HX_BENCH_LD0")) { g.lda = 0; g.ldb = 0; }      // experiment: every k row aliases row 0 -> operands come from the L1
+      if (getenv("HX_BENCH_NODB")) g.dbias = nullptr;             // experiment: without the bias-gradient column sums
       if (wbm == 256) HX_V(256, 16, false, false, EPI_SLAB);
       else if (bk == 16) HX_V(128, 16, false, false, EPI_SLAB); else HX_V(128, 32, false, false, EPI_SLAB); }
 #undef HX_PICK
@@ -1200,7 +1211,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     int max_splits = s->Mmax / 256; if (max_splits < 1) max_splits = 1;
     if (splits > max_splits + 1) splits = max_splits + 1;
     slab_tot += (size_t)splits * Ly.out * Ly.in_ld;
-    bslab_tot += (size_t)splits * Ly.out;
+    bslab_tot += (size_t)splits * ((Ly.in_ld + 127) / 128) * Ly.out;
   }
   s->slab_floats = slab_tot;
   rc |= palloc(s, &s->slab, slab_tot);
@@ -1553,12 +1564,13 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       const int ld_in = (l == 0) ? ldx : L[l].in_ld;
       float* slab = s->slab + s->slab_off[net * 4 + l];
       float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
-      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab);
+      int bparts = 0;
+      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts);
       const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
       int k = rt.nseg;
       rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
       k = ++rt.nseg;
-      rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (L[l].out + 1023) / 1024;
+      rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = bparts; rt.block0[k] = blocks; blocks += (L[l].out + 1023) / 1024;
       ++rt.nseg;
       if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out, s->wT[net * 4 + l]);
     }
