@@ -49,7 +49,8 @@ __device__ __forceinline__ float hx_elu(float x) { return x > 0.f ? x : (__expf(
 #else
 #define HX_GEMM_OCC
 #endif
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI>
+// KFULL: the host guarantees that every reduction range is a whole number of K tiles (no partial-tile path in the loop)
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
 __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
   const size_t stride_b = B_KM ? (size_t)HX_BK : (size_t)HX_BK * g.ldb;
   auto load_tile = [&](int kt) {        // tiles must be requested in order 0, 1, 2, ...: the slot pointers advance
     const int k0 = k_begin + kt * HX_BK;
-    if (k0 + HX_BK <= k_end) {          // uniform: whole tile inside the reduction range
+    if (KFULL || k0 + HX_BK <= k_end) { // uniform: whole tile inside the reduction range
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) { ra[i] = *reinterpret_cast<const f32x4*>(pa[i]); pa[i] += stride_a; }
 #pragma unroll

@@ -759,7 +759,7 @@ template <typename T> static int palloc(hx_ppo* s, T** ptr, size_t count) {
 }
 
 // ---- GEMM dispatch
-template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL = false> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
@@ -770,14 +770,14 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI> static void launc
   }
   if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
     (void)hipEventRecord(s->ev[s->ev_used], st);
-    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(blocks), dim3(256), 0, st, g);
     (void)hipEventRecord(s->ev[s->ev_used + 1], st);
     s->ev_kid[s->ev_used] = kid;
     s->ev_used += 2;
     s->prof_flops[kid] += 2.0 * g.M * g.N * g.K;
     s->prof_launches[kid] += 1;
   } else {
-    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI>), dim3(blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(blocks), dim3(256), 0, st, g);
   }
 }
 
@@ -843,7 +843,7 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   // profiles/r01_j_rollout_interference.txt).
   if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // every hidden-layer forward product in bf16 mode
   else if (background && M >= 16384) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
-  else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU>(s, g, st);
+  else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, g, st);     // whole K tiles only
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K,
@@ -851,7 +851,8 @@ static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, cons
   GemmArgs g{};
   g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = N; g.M = M; g.N = N; g.K = K; g.H = H; g.ldh = N;
   if (s->bf16 && WT != nullptr) { g.B = WT; g.ldb = K; launch_gemm_bf16<EPI_ELU_GRAD>(s, g, st); return; }   // B = W^T[N][K], K-major
-  launch_gemm<64, 128, 32, true, false, EPI_ELU_GRAD>(s, g, st);
+  if (K % 32 == 0) launch_gemm<64, 128, 32, true, false, EPI_ELU_GRAD, true>(s, g, st);
+  else launch_gemm<64, 128, 32, true, false, EPI_ELU_GRAD>(s, g, st);
 }
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab; *bias_parts = number of
 // partial rows written to bias_slab (splits x the tile_n blocks that share the column-sum work)
@@ -894,7 +895,9 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
     if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], st); s->ev_kid[s->ev_used] = 4; s->ev_used += 2; s->prof_flops[4] += 2.0 * g.M * g.N * g.K; s->prof_launches[4] += 1; }
     return splits;
   }
-  launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
+  // kchunk is a multiple of 32; with a row count that is a multiple of the K tile every split is whole tiles
+  if (Mrows % HX_BK_UPD == 0) launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true>(s, g, st);
+  else launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
   return splits;
 }
 
@@ -1087,7 +1090,8 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
       if (getenv("HX_BENCH_LD0")) { g.lda = 0; g.ldb = 0; }      // experiment: every k row aliases row 0 -> operands come from the L1
       if (getenv("HX_BENCH_NODB")) g.dbias = nullptr;             // experiment: without the bias-gradient column sums
       if (wbm == 256) HX_V(256, 16, false, false, EPI_SLAB);
-      else if (bk == 16) HX_V(128, 16, false, false, EPI_SLAB); else HX_V(128, 32, false, false, EPI_SLAB); }
+      else if (bk == 16) { if (rows % 16 == 0 && !getenv("HX_BENCH_NOKFULL")) launch_gemm<128, 128, 16, false, false, EPI_SLAB, true>(nullptr, g, st); else HX_V(128, 16, false, false, EPI_SLAB); }
+      else HX_V(128, 32, false, false, EPI_SLAB); }
 #undef HX_PICK
 #undef HX_V
   };
