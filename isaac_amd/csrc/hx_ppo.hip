@@ -451,7 +451,7 @@ struct HeadArgs {
 };
 template <int MA>   // register-array bound on the action count (16 for hector's 10, 32 otherwise): loops over MA are unrolled
 __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int hw = g.hw, hwc = g.hwc, A = g.A, hp = hw + 1, hpc = hwc + 1;
   float* sHa = sm;                       // [rows][hw+1]
   float* sHc = sHa + HEAD_ROWS * hp;     // [rows][hwc+1]
@@ -461,13 +461,22 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   float* sL = sD + HEAD_ROWS * (A + 1);  // [rows][4+A]  kl, vloss, sloss, entropy, dsigma[A]
   const int r0 = blockIdx.x * HEAD_ROWS;
   const int tid = threadIdx.x;
-  // a wave per row, lanes along k (widths are multiples of 64): coalesced and free of integer divisions
+  // half a wave per row, 16 bytes per lane (widths are multiples of 64 floats): coalesced, no integer divisions
   const int wave = tid >> 6, lane = tid & 63, hmax = hw > hwc ? hw : hwc;
-  for (int r = wave; r < HEAD_ROWS; r += 4) {
+  for (int r = 2 * wave + (lane >> 5); r < HEAD_ROWS; r += 8) {
     const bool ok = (r0 + r) < g.M;
-    for (int k = lane; k < hmax; k += 64) {      // one loop for both nets: two loads in flight per trip
-      if (k < hw) sHa[r * hp + k] = ok ? g.h3a[(size_t)(r0 + r) * hw + k] : 0.f;
-      if (k < hwc) sHc[r * hpc + k] = ok ? g.h3c[(size_t)(r0 + r) * hwc + k] : 0.f;
+    const size_t grow = (size_t)(ok ? r0 + r : 0);
+    for (int k = 4 * (lane & 31); k < hmax; k += 128) {      // one loop for both nets: two loads in flight per trip
+      if (k < hw) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3a + grow * hw + k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sHa[r * hp + k + q] = ok ? x[q] : 0.f;
+      }
+      if (k < hwc) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3c + grow * hwc + k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sHc[r * hpc + k + q] = ok ? x[q] : 0.f;
+      }
     }
   }
   for (int i = tid; i < A * hw; i += 256) sW[i] = g.W4[i];
@@ -479,7 +488,8 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
     const int r = tid >> 3, part = tid & 7, m = r0 + r;
     const int per = hw / 8, perc = hwc / 8;
     float mu[MA];
-    for (int j = 0; j < A; ++j) mu[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MA; ++j) mu[j] = 0.f;
     float v = 0.f;
     if (hw == hwc) {           // one pass over k for both nets (hector: 128 / 128)
       for (int k = part * per; k < (part + 1) * per; ++k) {
@@ -498,25 +508,36 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
       for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
       v += __shfl_xor(v, o);
     }
-    if (part == 0) {
+    // every lane of the row holds all the sums now; the loss terms of the row's actions are spread over its 8 lanes
+    // (lane p takes actions p, p + 8, ...) and reduced with three more shuffles
     float* L = sL + r * (4 + A);
     float* D = sD + r * (A + 1);
-    if (m < g.M) {
+    if (m < g.M) {                                   // uniform over the 8 lanes of a row
       const float invM = 1.0f / (float)g.M;
       const float* row = g.row_mb + (size_t)m * (2 * A + 4);
       v += g.b4c[0];
       float logp = 0.f, ent = 0.f, kl = 0.f;
-      float sg[MA];
-      for (int j = 0; j < A; ++j) {
-        mu[j] += g.b4[j];
-        sg[j] = mu[j] * 0.f + g.stdp[j];
-        const float d = row[j] - mu[j];
-        const float ls = logf(sg[j]);
-        logp += -(d * d) / (2.0f * sg[j] * sg[j]) - ls - LOG_SQRT_2PI;
-        ent += 0.5f + LOG_SQRT_2PI + ls;
-        const float so = g.sigma_old[j], dm = row[A + j] - mu[j];
-        kl += logf(sg[j] / so + 1.e-5f) + (so * so + dm * dm) / (2.0f * sg[j] * sg[j]) - 0.5f;
+      float dq[MA / 8], sq[MA / 8];
+#pragma unroll
+      for (int q = 0; q < MA / 8; ++q) {
+        const int j = part + 8 * q;
+        dq[q] = 0.f; sq[q] = 1.f;
+        if (j < A) {
+          float mj = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < MA; ++jj) mj = (jj == j) ? mu[jj] : mj;      // register array, lane-dependent index
+          mj += g.b4[j];
+          const float sgj = mj * 0.f + g.stdp[j];
+          const float d = row[j] - mj;
+          const float ls = logf(sgj);
+          logp += -(d * d) / (2.0f * sgj * sgj) - ls - LOG_SQRT_2PI;
+          ent += 0.5f + LOG_SQRT_2PI + ls;
+          const float so = g.sigma_old[j], dm = row[A + j] - mj;
+          kl += logf(sgj / so + 1.e-5f) + (so * so + dm * dm) / (2.0f * sgj * sgj) - 0.5f;
+          dq[q] = d; sq[q] = sgj;
+        }
       }
+      for (int o = 4; o > 0; o >>= 1) { logp += __shfl_xor(logp, o); ent += __shfl_xor(ent, o); kl += __shfl_xor(kl, o); }
       const float v_old = row[2 * A], ret = row[2 * A + 1], logp_old = row[2 * A + 2], adv = row[2 * A + 3];
       const float ratio = expf(logp - logp_old);
       const float lo = 1.0f - g.clip, hi = 1.0f + g.clip;
@@ -524,46 +545,61 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
       const float inr = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
       const float w = (s > sc) ? 1.f : ((s == sc) ? 0.5f + 0.5f * inr : inr);
       const float dlogp = -adv * w * ratio * invM;
-      float vl, dv;
-      if (g.use_clipped_value_loss) {
-        const float vc = v_old + fminf(fmaxf(v - v_old, -g.clip), g.clip);
-        const float la = (v - ret) * (v - ret), lb = (vc - ret) * (vc - ret);
-        vl = fmaxf(la, lb);
-        const float inv = (fabsf(v - v_old) <= g.clip) ? 1.f : 0.f;
-        const float ga = 2.0f * (v - ret), gb = 2.0f * (vc - ret) * inv;
-        dv = (la > lb) ? ga : ((la == lb) ? 0.5f * ga + 0.5f * gb : gb);
-      } else {
-        vl = (ret - v) * (ret - v);
-        dv = 2.0f * (v - ret);
+#pragma unroll
+      for (int q = 0; q < MA / 8; ++q) {
+        const int j = part + 8 * q;
+        if (j < A) {
+          const float d = dq[q], sgj = sq[q];
+          D[j] = dlogp * d / (sgj * sgj);
+          L[4 + j] = dlogp * (d * d / (sgj * sgj * sgj) - 1.0f / sgj) - g.ecoef * invM / sgj;
+        }
       }
-      D[A] = g.vcoef * dv * invM;
-      for (int j = 0; j < A; ++j) {
-        const float d = row[j] - mu[j];
-        D[j] = dlogp * d / (sg[j] * sg[j]);
-        L[4 + j] = dlogp * (d * d / (sg[j] * sg[j] * sg[j]) - 1.0f / sg[j]) - g.ecoef * invM / sg[j];
+      if (part == 0) {
+        float vl, dv;
+        if (g.use_clipped_value_loss) {
+          const float vc = v_old + fminf(fmaxf(v - v_old, -g.clip), g.clip);
+          const float la = (v - ret) * (v - ret), lb = (vc - ret) * (vc - ret);
+          vl = fmaxf(la, lb);
+          const float inv = (fabsf(v - v_old) <= g.clip) ? 1.f : 0.f;
+          const float ga = 2.0f * (v - ret), gb = 2.0f * (vc - ret) * inv;
+          dv = (la > lb) ? ga : ((la == lb) ? 0.5f * ga + 0.5f * gb : gb);
+        } else {
+          vl = (ret - v) * (ret - v);
+          dv = 2.0f * (v - ret);
+        }
+        D[A] = g.vcoef * dv * invM;
+        L[0] = kl; L[1] = vl; L[2] = fmaxf(s, sc); L[3] = ent;
       }
-      L[0] = kl; L[1] = vl; L[2] = fmaxf(s, sc); L[3] = ent;
-    } else {
+    } else if (part == 0) {
       for (int j = 0; j <= A; ++j) D[j] = 0.f;
       for (int j = 0; j < 4 + A; ++j) L[j] = 0.f;
-    }
     }
   }
   __syncthreads();
   // dZ3 = (W4^T dmu) * elu'(h3)   and   dZ3c = dv w4c * elu'(h3c)
-  for (int r = wave; r < HEAD_ROWS; r += 4) {
+  for (int r = 2 * wave + (lane >> 5); r < HEAD_ROWS; r += 8) {       // half a wave per row, four k per lane, 16-byte stores
     if (r0 + r >= g.M) continue;
     const float dv = sD[r * (A + 1) + A];
-    for (int k = lane; k < hmax; k += 64) {
+    for (int k = 4 * (lane & 31); k < hmax; k += 128) {
       if (k < hw) {
-        float s = 0.f;
-        for (int j = 0; j < A; ++j) s = fmaf(sD[r * (A + 1) + j], sW[j * hw + k], s);
-        const float ha = sHa[r * hp + k];
-        g.dz3a[(size_t)(r0 + r) * hw + k] = s * (ha > 0.f ? 1.f : ha + 1.f);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < A; ++j) {
+          const float dj = sD[r * (A + 1) + j];
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sW + j * hw + k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s[q] = fmaf(dj, w[q], s[q]);
+        }
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float ha = sHa[r * hp + k + q]; o[q] = s[q] * (ha > 0.f ? 1.f : ha + 1.f); }
+        *reinterpret_cast<f32x4*>(g.dz3a + (size_t)(r0 + r) * hw + k) = o;
       }
       if (k < hwc) {
-        const float hc = sHc[r * hpc + k];
-        g.dz3c[(size_t)(r0 + r) * hwc + k] = dv * sWc[k] * (hc > 0.f ? 1.f : hc + 1.f);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sWc + k);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float hc = sHc[r * hpc + k + q]; o[q] = dv * w[q] * (hc > 0.f ? 1.f : hc + 1.f); }
+        *reinterpret_cast<f32x4*>(g.dz3c + (size_t)(r0 + r) * hwc + k) = o;
       }
     }
   }
