@@ -28,6 +28,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MODEL_JSON = os.path.join(os.path.dirname(_HERE), "isaac_amd", "assets", "hector_model.json")
+# hector with arms (task hector_full, reference hector_w_arm_config.py:29): 19 bodies / 18 DoF, DoF order L leg, L arm,
+# R leg, R arm; no collision shapes compiled yet (tools/compile_urdf.py --full)
+MODEL_FULL_JSON = os.path.join(os.path.dirname(_HERE), "isaac_amd", "assets", "hector_full_model.json")
 
 # ---- simulation constants (mirrored in isaac_amd/csrc/hx_sim.hip; DESIGN.md lists them) ----
 GRAVITY = -9.81           # reference legged_robot_config.py:184
@@ -109,17 +112,17 @@ def crm(v):
 class State:
     """Per-env generalized state.  All arrays have leading dim N."""
 
-    def __init__(self, n, dtype=np.float64):
+    def __init__(self, n, dtype=np.float64, ndof=10):
         self.root_pos = np.zeros((n, 3), dtype)
         self.root_quat = np.zeros((n, 4), dtype)
         self.root_quat[:, 3] = 1
         self.root_linvel = np.zeros((n, 3), dtype)   # world frame, velocity of the base-link origin
         self.root_angvel = np.zeros((n, 3), dtype)   # world frame
-        self.q = np.zeros((n, 10), dtype)
-        self.qd = np.zeros((n, 10), dtype)
+        self.q = np.zeros((n, ndof), dtype)
+        self.qd = np.zeros((n, ndof), dtype)
 
     def copy(self):
-        s = State(self.q.shape[0], self.q.dtype)
+        s = State(self.q.shape[0], self.q.dtype, self.q.shape[1])
         for k, v in self.__dict__.items():
             setattr(s, k, v.copy())
         return s
@@ -163,7 +166,8 @@ class HectorPhysics:
         self.contacts = [(c["body"], np.array(c["points"], dtype)) for c in self.model["contacts"]]
         # outputs of the last substep
         self.contact_force = np.zeros((n, self.nb, 3), dtype)
-        self.tau = np.zeros((n, 10), dtype)
+        self.ndof = self.nb - 1
+        self.tau = np.zeros((n, self.ndof), dtype)
 
     # ------------------------------------------------------------------ kinematics
     def kinematics(self, s):
@@ -225,7 +229,7 @@ class HectorPhysics:
         # ---- actuation + soft joint limits (joint space, linearly implicit)
         tau, unclipped = self.pd_torque(s, target, kp, kd, tau_lim)
         self.tau = tau.copy()
-        beta = np.where(unclipped, dt * (kd + dt * kp), 0.0) * np.ones((n, 10), dtp)
+        beta = np.where(unclipped, dt * (kd + dt * kp), 0.0) * np.ones((n, self.ndof), dtp)
         c_lim = LIMIT_D + LIMIT_K * dt
         lo_pen = self.q_lo - s.q
         hi_pen = s.q - self.q_hi
@@ -291,7 +295,7 @@ class HectorPhysics:
             # contact: explicit force, and the implicit part acting on the velocity-product + gravity
             # share of the body's true spatial acceleration (a_true = J nu_dot + a_vp)
             f[i] -= f0[i] - np.einsum("nij,nj->ni", Bm[i], a_vp[i])
-        C = np.zeros((n, 16), dtp)
+        C = np.zeros((n, 6 + self.ndof), dtp)
         for i in range(nb - 1, 0, -1):
             C[:, 6 + i - 1] = f[i][:, self.axis[i]]
             f[self.parent[i]] += np.einsum("nji,nj->ni", Xup[i], f[i])
@@ -303,7 +307,7 @@ class HectorPhysics:
         for i in range(nb - 1, 0, -1):
             XT = np.swapaxes(Xup[i], -1, -2)
             Ic[self.parent[i]] += XT @ Ic[i] @ Xup[i]
-        H = np.zeros((n, 16, 16), dtp)
+        H = np.zeros((n, 6 + self.ndof, 6 + self.ndof), dtp)
         H[:, :6, :6] = Ic[0]
         for i in range(1, nb):
             F = Ic[i][:, :, self.axis[i]]
@@ -316,7 +320,7 @@ class HectorPhysics:
             F = np.einsum("nji,nj->ni", Xup[j], F)
             H[:, :6, 5 + i] = F
             H[:, 5 + i, :6] = F
-        idx = np.arange(10)
+        idx = np.arange(self.ndof)
         H[:, 6 + idx, 6 + idx] += beta
 
         rhs = -C

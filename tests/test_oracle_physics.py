@@ -88,3 +88,37 @@ def test_friction_cone_limits_tangential_force():
     f = ph.contact_force[0, [5, 10]]
     mu = 0.5 * (0.6 + 0.1)
     assert np.all(np.linalg.norm(f[:, :2], axis=1) <= mu * np.abs(f[:, 2]) * 1.3 + 1.0)
+
+
+def test_tree_generic_on_the_arm_model():
+    """The oracle's dynamics is written for any tree: on the 18-DoF hector-with-arms model (SURVEY 8f-4 groundwork,
+    tools/compile_urdf.py --full) free flight conserves energy and momentum, and the DoF order is the one the
+    reference task indexes (hector_w_arm_env.py:371-373: L leg 0-4, L arm 5-8, R leg 9-13, R arm 14-17)."""
+    from oracle.physics import MODEL_FULL_JSON, load_model
+    model = load_model(MODEL_FULL_JSON)
+    joints = [b["joint"] for b in model["bodies"][1:]]
+    assert [j[0] for j in joints] == list("LLLLLLLLLRRRRRRRRR")
+    assert ["shoulder" in j or "elbow" in j for j in joints] == ([False] * 5 + [True] * 4) * 2
+    n = 2
+    ph = HectorPhysics(n, model=model)
+    assert ph.ndof == 18 and abs(ph.mass.sum(0)[0] - model["total_mass"]) < 1e-9
+    ph.q_lo[:], ph.q_hi[:], ph.v_max[:] = -100, 100, 1e9
+    rng = np.random.default_rng(1)
+    s = State(n, ndof=18)
+    s.root_pos[:, 2] = 5.0
+    s.q[:] = rng.uniform(-.3, .3, (n, 18))
+    s.qd[:] = rng.uniform(-2, 2, (n, 18))
+    s.root_angvel[:] = rng.uniform(-1, 1, (n, 3))
+    s.root_linvel[:] = rng.uniform(-1, 1, (n, 3))
+    z = np.zeros((n, 18))
+    ke, pe = ph.energy(s)
+    P0, L0 = ph.momentum(s)
+    dt, steps = 1e-4, 200
+    for _ in range(steps):
+        ph.substep(s, z, z, z, z + 100.0, dt=dt)
+    ke1, pe1 = ph.energy(s)
+    P1, L1 = ph.momentum(s)
+    assert np.all(np.abs(ke1 + pe1 - ke - pe) < 5e-3)
+    mg = ph.mass.sum(0)[:, None] * np.array([0, 0, GRAVITY])
+    np.testing.assert_allclose(P1 - P0, mg * dt * steps, atol=1e-4)
+    np.testing.assert_allclose((L1 - L0)[:, 2], 0, atol=1e-4)

@@ -78,8 +78,12 @@ def stl_bbox(path):
     return pts.min(0), pts.max(0)
 
 
-def main():
-    root = ET.parse(URDF).getroot()
+def collapse(urdf_path, sort_children=False):
+    """URDF -> list of collapsed bodies (dicts) in depth-first order.  sort_children: visit the movable children of a
+    link in alphabetical order of their joint names -- the order Isaac Gym gives bodies and DoFs (the hector-with-arms
+    task indexes L leg 0-4, L arm 5-8, R leg 9-13, R arm 14-17: hector_w_arm_env.py:371-373, although the URDF lists
+    both legs first); robot.urdf is already in that order."""
+    root = ET.parse(urdf_path).getroot()
     links = {l.get("name"): l for l in root.findall("link")}
     joints = root.findall("joint")
     children = {}
@@ -141,10 +145,37 @@ def main():
                          "velocity": float(lim.get("velocity")), "effort": float(lim.get("effort"))})
         idx = len(bodies)
         bodies.append(body)
+        if sort_children:
+            movable = sorted(movable, key=lambda m: m[0].get("name"))
         for j, cp, cR in movable:
             build(j.find("child").get("link"), idx, j, cp, cR)
 
     build(root_link, -1, None, None, None)
+    return bodies
+
+
+def main_full():
+    """hector with arms (robot_w_arm.urdf, task hector_full): model data for the oracle only -- no kernel tables yet."""
+    urdf = os.path.join(REF, "resources/robots/hector_v2/xacro/robot_w_arm.urdf")
+    bodies = collapse(urdf, sort_children=True)
+    assert len(bodies) == 19, len(bodies)
+    names = [b["name"] for b in bodies]
+    assert [b.get("joint") for b in bodies[1:]] == [
+        "L_hip_joint", "L_hip_roll_joint", "L_thigh_joint", "L_calf_joint", "L_toe_joint",
+        "L_shoulder_yaw_joint", "L_shoulder_pitch_joint", "L_shoulder_roll_joint", "L_elbow_joint",
+        "R_hip_joint", "R_hip_roll_joint", "R_thigh_joint", "R_calf_joint", "R_toe_joint",
+        "R_shoulder_yaw_joint", "R_shoulder_pitch_joint", "R_shoulder_roll_joint", "R_elbow_joint"], names
+    model = {"source": "resources/robots/hector_v2/xacro/robot_w_arm.urdf (collapse_fixed_joints, children in alphabetical order)",
+             "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": []}
+    with open(os.path.join(ROOT, "isaac_amd/assets/hector_full_model.json"), "w") as f:
+        json.dump(model, f, indent=1)
+    for i, b in enumerate(bodies):
+        print(i, b["name"], "parent", b["parent"], "m=%.5f" % b["mass"], b.get("joint"), b.get("axis"))
+    print("total mass %.5f" % model["total_mass"])
+
+
+def main():
+    bodies = collapse(URDF)
     assert len(bodies) == 11, len(bodies)
     total = sum(b["mass"] for b in bodies)
 
@@ -249,4 +280,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main_full() if "--full" in sys.argv else main())
