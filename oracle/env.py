@@ -87,12 +87,21 @@ def unif(lo, hi, u):
 
 class HectorEnvOracle:
     def __init__(self, n, shape_friction, base_mass, env_origins, init_pack, add_noise=True,
-                 start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False, curriculum=None):
+                 start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False, curriculum=None,
+                 reward_scales=None):
         """terrain: oracle.terrain.HeightField or None (plane).  custom_origins: True for heightfield/trimesh
         (legged_robot.py:688), which adds U[-1,1] to the reset xy (:381-384).
         curriculum: None or dict(origins [rows][cols][3], levels [n], types [n], env_length) -- the terrain curriculum of
         legged_robot.py:399-419; packs then carry one more row, RP["level"]."""
         self.n = n
+        # reward_scales: overrides / additions to HectorCfg's scales (hector_config.py:161-189), e.g. the four terms HectorCfg
+        # zero-scales (joint_pos, low_speed, track_vel_hard, vel_mismatch_exp).  Active terms are evaluated in alphabetical
+        # order like the reference (dir(), helpers.py:47; zero scales are dropped, legged_robot.py:521-527).
+        sc = dict(REWARD_SCALE)
+        sc.update(reward_scales or {})
+        self.reward_scale = {k: v for k, v in sc.items() if v != 0}
+        self.reward_order = sorted(self.reward_scale)
+        self.ref_dof_pos = np.zeros((n, 10), F)
         self.custom_origins = custom_origins
         self.curriculum = curriculum
         self.init_done = False
@@ -130,7 +139,7 @@ class HectorEnvOracle:
         self.reset_buf = np.ones(n, bool)
         self.time_out_buf = np.zeros(n, bool)
         self.time_outs_visible = np.zeros(n, bool)      # extras["time_outs"], stale unless some env reset
-        self.episode_sums = {k: z(n) for k in REWARD_ORDER}
+        self.episode_sums = {k: z(n) for k in self.reward_order}
         self.rew_buf = z(n)
         self.torques = z(n, 10)
         self.obs_hist = z(15, n, 41)       # oldest .. newest
@@ -287,7 +296,7 @@ class HectorEnvOracle:
         self.episode_length_buf[ids] = 0
         self.reset_buf[ids] = True
         self.extras_episode = {}
-        for k in REWARD_ORDER:
+        for k in self.reward_order:
             self.extras_episode["rew_" + k] = np.mean(self.episode_sums[k][ids]) / F(24.0)
             self.episode_sums[k][ids] = 0
         self.time_outs_visible = self.time_out_buf.copy()
@@ -299,8 +308,8 @@ class HectorEnvOracle:
     # ---- rewards (hector_env.py:277-539), alphabetical evaluation order (helpers.py:47 dir())
     def compute_reward(self):
         self.rew_buf = np.zeros(self.n, F)
-        for name in REWARD_ORDER:
-            scale = F(REWARD_SCALE[name] * self.dt)
+        for name in self.reward_order:
+            scale = F(self.reward_scale[name] * self.dt)
             rew = (getattr(self, "_reward_" + name)().astype(F) * scale).astype(F)
             self.rew_buf = (self.rew_buf + rew).astype(F)
             self.episode_sums[name] = (self.episode_sums[name] + rew).astype(F)
@@ -388,6 +397,38 @@ class HectorEnvOracle:
         sp = np.sqrt(np.sum(self.rigid_state[:, FEET, 7:9] ** 2, 2))
         return np.sum(np.sqrt(sp) * contact, 1)
 
+    def _reward_joint_pos(self):
+        """hector_env.py:264-275; ref_dof_pos is what the LAST compute_observations left (compute_ref_state :90-111)."""
+        d = (self.dof_pos - self.ref_dof_pos).astype(F)
+        nn = np.sqrt(np.sum(d * d, 1, dtype=F), dtype=F)
+        return np.exp(-F(2) * nn) - F(0.2) * np.clip(nn, 0, 0.5)
+
+    def _reward_low_speed(self):
+        """hector_env.py:468-499"""
+        vx, cx = self.base_lin_vel[:, 0], self.commands[:, 0]
+        a_s, a_c = np.abs(vx), np.abs(cx)
+        low, high = a_s < F(0.5) * a_c, a_s > F(1.2) * a_c
+        r = np.zeros(self.n, F)
+        r[low] = -1.0
+        r[high] = 0.0
+        r[~(low | high)] = 1.2
+        r[np.sign(vx) != np.sign(cx)] = -2.0
+        return r * (a_c > 0.1)
+
+    def _reward_track_vel_hard(self):
+        """hector_env.py:407-424"""
+        d = self.commands[:, :2] - self.base_lin_vel[:, :2]
+        le = np.sqrt(np.sum(d * d, 1, dtype=F), dtype=F)
+        ae = np.abs(self.commands[:, 2] - self.base_ang_vel[:, 2])
+        return (np.exp(-le * F(10)) + np.exp(-ae * F(10))) / F(2) - F(0.2) * (le + ae)
+
+    def _reward_vel_mismatch_exp(self):
+        """hector_env.py:395-405"""
+        lin = np.exp(-np.square(self.base_lin_vel[:, 2]) * F(10))
+        w = self.base_ang_vel[:, :2]
+        ang = np.exp(-np.sqrt(np.sum(w * w, 1, dtype=F), dtype=F) * F(5))
+        return (lin + ang) / F(2)
+
     def _reward_knee_distance(self):
         return self._dist_reward(KNEES, 0.25)
 
@@ -410,6 +451,15 @@ class HectorEnvOracle:
     # ---- observations (hector_env.py:172-254)
     def compute_observations(self, pack):
         ph = self._phase()
+        # compute_ref_state (hector_env.py:90-111): the gait reference pose that _reward_joint_pos reads one step later
+        sp = np.sin(F(2 * np.pi) * ph).astype(F)
+        sl, sr = np.minimum(sp, 0), np.maximum(sp, 0)
+        ref = np.zeros((self.n, 10), F)
+        s1 = F(0.17)                                        # rewards.target_joint_pos_scale (hector_config.py:151)
+        ref[:, 2], ref[:, 3], ref[:, 4] = sl * s1, sl * (2 * s1), sl * s1
+        ref[:, 7], ref[:, 8], ref[:, 9] = sr * s1, sr * (2 * s1), sr * s1
+        ref[np.abs(sp) < 0.1] = 0
+        self.ref_dof_pos = ref
         sin_pos = np.sin(F(2 * np.pi) * ph).astype(F)[:, None]
         cos_pos = np.cos(F(2 * np.pi) * ph).astype(F)[:, None]
         sm = self._stance_mask()

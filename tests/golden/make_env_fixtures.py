@@ -31,7 +31,7 @@ RP_SIZE = 75          # + 1 row (RP["level"]) when the terrain curriculum is on
 
 
 def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_counter_init=0, add_noise=True,
-             full_stack_steps=(0, 1, 14, 15, 16), terrain=None):
+             full_stack_steps=(0, 1, 14, 15, 16), terrain=None, reward_scales=None):
     """terrain=None: ground plane.  terrain=dict(mesh_type=, num_rows=, num_cols=, border_size=): the reference's
     own HumanoidTerrain (humanoid/utils/terrain.py) lays out the map, the env takes its origins from it
     (legged_robot.py:687-697) and every reset adds U[-1,1] to xy (:381-384)."""
@@ -44,6 +44,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
     if terrain is not None:
         for k, v in terrain.items():
             setattr(cfg.terrain, k, v)
+    for k, v in (reward_scales or {}).items():      # e.g. the four reward terms HectorCfg zero-scales
+        setattr(cfg.rewards.scales, k, v)
     cfg.env.num_envs = n_envs
     cfg.noise.add_noise = add_noise
     cfg.seed = seed
@@ -213,6 +215,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         res["full_obs"] = np.stack([full[k][0] for k in sorted(full)])
         res["full_priv"] = np.stack([full[k][1] for k in sorted(full)])
         res["reward_names"] = np.array(reward_names)
+        res["reward_override_names"] = np.array(sorted(reward_scales or {}), dtype="U32")
+        res["reward_override_values"] = np.array([(reward_scales or {})[k] for k in sorted(reward_scales or {})], np.float64)
         res["reward_scales"] = np.array([env.reward_scales[k] for k in reward_names], np.float64)
         res["meta"] = np.array([n_envs, n_steps, seed, step_counter_init, int(add_noise)])
         res["ep_len_init"] = np.zeros(N, np.int64) if ep_len_init is None else np.asarray(ep_len_init, np.int64)
@@ -258,6 +262,13 @@ if __name__ == "__main__":
         generate("env_rollout_c", N, 100, seed=5, action_std=0.6,
                  ep_len_init=[0, 2350, 0, 0, 2380, 0, 0, 0],
                  terrain=dict(mesh_type="trimesh", num_rows=2, num_cols=4, border_size=3.0))
+    # E: the four reward terms that HectorCfg zero-scales (joint_pos, low_speed, track_vel_hard, vel_mismatch_exp), switched
+    #    on with the scales the sibling config hector_w_arm_config.py uses (:178-182) and humanoid_config's joint_pos 1.6:
+    #    the product's kernel implements them, this pins them
+    if want("env_rollout_e"):
+        generate("env_rollout_e", N, 90, seed=23, action_std=0.5,
+                 ep_len_init=[0, 37, 2385, 5, 797, 63, 31, 2395],
+                 reward_scales=dict(joint_pos=1.6, low_speed=0.2, track_vel_hard=0.5, vel_mismatch_exp=0.5))
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others
     #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 19 shows every

@@ -28,6 +28,9 @@ def make_env(fx):
     cfg.noise.add_noise = bool(noise)
     cfg.seed = seed
     cfg.terrain.mesh_type = "plane"
+    if "reward_override_names" in fx:     # fixture E: the four terms HectorCfg zero-scales, switched on
+        for k, v in zip(fx["reward_override_names"], fx["reward_override_values"]):
+            setattr(cfg.rewards.scales, str(k), float(v))
     creation = dict(friction=fx["init_shape_friction"], mass=fx["init_base_mass"], origins=fx["init_env_origins"],
                     start=fx["init_start_pos"])
     if "terrain_heights" in fx:           # fixture C: the tile map the reference's HumanoidTerrain laid out
@@ -56,7 +59,7 @@ def test_constructor_reset_and_first_observation(hxlib, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_e"])
 def test_teacher_forced_steps(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)

@@ -19,6 +19,8 @@ def make_oracle_env(fx, **kw):
         from oracle.terrain import HeightField
         hs, vs, border = fx["terrain_params"]
         terrain = HeightField(fx["terrain_heights"], hs, vs, border)
+    if "reward_override_names" in fx and len(fx["reward_override_names"]):
+        kw.setdefault("reward_scales", {str(k): float(v) for k, v in zip(fx["reward_override_names"], fx["reward_override_values"])})
     if "terrain_curriculum" in fx and int(fx["terrain_curriculum"]):
         kw.setdefault("curriculum", dict(origins=fx["terrain_origins"], levels=fx["init_terrain_levels"], types=fx["terrain_types"],
                                          env_length=float(fx["terrain_env_length"])))
@@ -27,15 +29,18 @@ def make_oracle_env(fx, **kw):
                            custom_origins=terrain is not None, **kw)
 
 
-@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100), ("env_rollout_d", 150)])
+@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100), ("env_rollout_d", 150),
+                                        ("env_rollout_e", 90)])
 def test_oracle_env_reproduces_reference(name, steps):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
     env = make_oracle_env(fx)
     np.testing.assert_allclose(env.obs_buf, fx["init_obs_full"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(env.priv_buf, fx["init_priv_full"], rtol=0, atol=1e-6)
-    assert list(fx["reward_names"]) == REWARD_ORDER          # alphabetical dir() order (helpers.py:47)
-    np.testing.assert_allclose(fx["reward_scales"], [REWARD_SCALE[k] * 0.01 for k in REWARD_ORDER], rtol=1e-12)
+    assert list(fx["reward_names"]) == env.reward_order      # alphabetical dir() order (helpers.py:47)
+    if name != "env_rollout_e":
+        assert env.reward_order == REWARD_ORDER
+    np.testing.assert_allclose(fx["reward_scales"], [env.reward_scale[k] * 0.01 for k in env.reward_order], rtol=1e-12)
     env.episode_length_buf[:] = fx["ep_len_init"]
     env.common_step_counter = sc0
     full = {int(s): i for i, s in enumerate(fx["full_steps"])}
@@ -52,7 +57,7 @@ def test_oracle_env_reproduces_reference(name, steps):
         np.testing.assert_array_equal(env.episode_length_buf, fx["ep_len"][t])
         np.testing.assert_allclose(env.feet_air_time, fx["feet_air_time"][t], rtol=0, atol=1e-6)
         np.testing.assert_allclose(env.feet_height, fx["feet_height"][t], rtol=0, atol=1e-5)
-        np.testing.assert_allclose(np.stack([env.episode_sums[k] for k in REWARD_ORDER]), fx["episode_sums"][t], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(np.stack([env.episode_sums[k] for k in env.reward_order]), fx["episode_sums"][t], rtol=0, atol=1e-5)
         if "levels" in fx:                               # terrain curriculum: rows and re-based origins after every reset
             np.testing.assert_array_equal(env.terrain_levels, fx["levels"][t], err_msg=f"levels step {t}")
             np.testing.assert_array_equal(env.env_origins, fx["origins"][t], err_msg=f"origins step {t}")
