@@ -99,3 +99,39 @@ def test_failed_create_leaves_the_library_usable(hxlib):
     ac, alg, orc, inp = _pair("odd", 1, 2, 8, 1, 1, 1e-4)
     a = alg.act(inp["obs"][0], inp["priv"][0], eps=inp["eps"][0]).numpy()
     np.testing.assert_allclose(a, orc.act(inp["obs"][0], inp["priv"][0], inp["eps"][0]), rtol=0, atol=5e-5)
+
+
+def test_option_branches_match_the_oracle(hxlib):
+    """Branches the hector defaults never take: unclipped value loss (ppo.py:157-158), fixed learning-rate schedule
+    (ppo.py:136 skipped), a gradient-norm limit small enough that clip_grad_norm_ always scales (ppo.py:173), other
+    loss coefficients and discount factors."""
+    no, npv, na, ah, ch = SHAPES["odd"]
+    seed, T, N, epochs, nmb, lr = 17, 5, 40, 2, 2, 3e-4
+    kw = dict(num_learning_epochs=epochs, num_mini_batches=nmb, clip_param=0.1, gamma=0.97, lam=0.8, value_loss_coef=0.5,
+              entropy_coef=0.01, learning_rate=lr, max_grad_norm=0.05, use_clipped_value_loss=False, schedule="fixed", desired_kl=0.01)
+    mk = lambda: ActorCriticOracle.default_init(np.random.default_rng(seed), no, npv, na, ah, ch, 1.0)
+    ac = ActorCritic(no, npv, na, actor_hidden_dims=list(ah), critic_hidden_dims=list(ch), init_noise_std=1.0)
+    ac.load_state_dict(mk().state_dict())
+    alg = PPO(ac, **kw)
+    alg.init_storage(N, T, [no], [npv], [na])
+    orc = PPOOracle(mk(), N, T, **kw)
+    inp = rollout_inputs(seed, T, N, no, npv, na)
+    for t in range(T):
+        alg.act(inp["obs"][t], inp["priv"][t], eps=inp["eps"][t])
+        orc.act(inp["obs"][t], inp["priv"][t], inp["eps"][t])
+        alg.process_env_step(inp["rewards"][t], inp["dones"][t].astype(np.uint8), {"time_outs": inp["time_outs"][t].astype(np.uint8)})
+        orc.process_env_step(inp["rewards"][t], inp["dones"][t], inp["time_outs"][t])
+    alg.compute_returns(inp["priv"][T])
+    orc.compute_returns(inp["priv"][T])
+    np.testing.assert_allclose(alg.buffer(5, (T, N)).numpy(), orc.returns, rtol=1e-4, atol=1e-4)
+    perm = np.random.default_rng(4).permutation(T * N).astype(np.int32)
+    mvl, msl = alg.update(perm=perm)
+    ovl, osl = orc.update(perm)
+    assert abs(mvl - ovl) <= 1e-4 * max(1.0, abs(ovl)) and abs(msl - osl) <= 1e-4
+    assert alg.learning_rate == pytest.approx(lr) and orc.lr == lr            # fixed schedule
+    assert min(orc.gnorm_hist) > 0.05                                          # every step was clipped
+    sd = ac.state_dict()
+    for k, v in orc.ac.state_dict().items():
+        d = np.abs(sd[k] - v)
+        assert d.max() <= 2 * epochs * nmb * lr, (k, d.max())
+        assert np.mean(d > 3e-6) < 2e-3, (k, float(np.mean(d > 3e-6)))
