@@ -88,7 +88,7 @@ def unif(lo, hi, u):
 class HectorEnvOracle:
     def __init__(self, n, shape_friction, base_mass, env_origins, init_pack, add_noise=True,
                  start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False, curriculum=None,
-                 reward_scales=None):
+                 reward_scales=None, opts=None):
         """terrain: oracle.terrain.HeightField or None (plane).  custom_origins: True for heightfield/trimesh
         (legged_robot.py:688), which adds U[-1,1] to the reset xy (:381-384).
         curriculum: None or dict(origins [rows][cols][3], levels [n], types [n], env_length) -- the terrain curriculum of
@@ -102,6 +102,18 @@ class HectorEnvOracle:
         self.reward_scale = {k: v for k, v in sc.items() if v != 0}
         self.reward_order = sorted(self.reward_scale)
         self.ref_dof_pos = np.zeros((n, 10), F)
+        # opts: config switches / ranges that differ from HectorCfg (all keys optional):
+        #   heading_command (commands.heading_command), only_positive_rewards, push_robots, cmd_ranges = dict(lin_vel_x=,
+        #   lin_vel_y=, ang_vel_yaw=, heading=), max_push_vel_xy, max_push_ang_vel
+        o = dict(heading_command=True, only_positive_rewards=True, push_robots=True,
+                 cmd_ranges=dict(lin_vel_x=(-0.6, 0.6), lin_vel_y=(-0.3, 0.3), ang_vel_yaw=(-0.3, 0.3), heading=(-3.14, 3.14)),
+                 max_push_vel_xy=0.3, max_push_ang_vel=0.4)
+        for k, v in (opts or {}).items():
+            if k == "cmd_ranges":
+                o["cmd_ranges"].update(v)
+            else:
+                o[k] = v
+        self.opts = o
         self.custom_origins = custom_origins
         self.curriculum = curriculum
         self.init_done = False
@@ -221,8 +233,9 @@ class HectorEnvOracle:
         self._resample_commands(ids, pack, "cmd_a")
         fwd = quat_apply(q, np.tile(np.array([[1, 0, 0]], F), (n, 1)))
         heading = np.arctan2(fwd[:, 1], fwd[:, 0]).astype(F)
-        self.commands[:, 2] = np.clip(F(0.5) * wrap_to_pi(self.commands[:, 3] - heading), -1, 1)
-        if self.common_step_counter % 400 == 0:
+        if self.opts["heading_command"]:                    # legged_robot.py:310-313
+            self.commands[:, 2] = np.clip(F(0.5) * wrap_to_pi(self.commands[:, 3] - heading), -1, 1)
+        if self.opts["push_robots"] and self.common_step_counter % 400 == 0:
             self._push_robots(pack)
         # termination (legged_robot.py:155-160)
         fn = np.sqrt(np.sum(self.contact_forces[:, TERM] ** 2, -1))
@@ -242,17 +255,22 @@ class HectorEnvOracle:
         if len(ids) == 0:
             return
         o = RP[field]
-        self.commands[ids, 0] = unif(-0.6, 0.6, pack[o][ids])
-        self.commands[ids, 1] = unif(-0.3, 0.3, pack[o + 1][ids])
-        self.commands[ids, 3] = unif(-3.14, 3.14, pack[o + 2][ids])
+        cr = self.opts["cmd_ranges"]
+        self.commands[ids, 0] = unif(cr["lin_vel_x"][0], cr["lin_vel_x"][1], pack[o][ids])
+        self.commands[ids, 1] = unif(cr["lin_vel_y"][0], cr["lin_vel_y"][1], pack[o + 1][ids])
+        if self.opts["heading_command"]:                    # legged_robot.py:329-332
+            self.commands[ids, 3] = unif(cr["heading"][0], cr["heading"][1], pack[o + 2][ids])
+        else:
+            self.commands[ids, 2] = unif(cr["ang_vel_yaw"][0], cr["ang_vel_yaw"][1], pack[o + 2][ids])
         nrm = np.sqrt(np.sum(self.commands[ids, :2] ** 2, 1))
         self.commands[ids, :2] *= (nrm > 0.2)[:, None]
 
     def _push_robots(self, pack):
         o = RP["push"]
-        self.rand_push_force[:, :2] = unif(-0.3, 0.3, pack[o:o + 2].T)
+        mx, ma = self.opts["max_push_vel_xy"], self.opts["max_push_ang_vel"]
+        self.rand_push_force[:, :2] = unif(-mx, mx, pack[o:o + 2].T)
         self.root[:, 7:9] = self.rand_push_force[:, :2]
-        self.rand_push_torque = unif(-0.4, 0.4, pack[o + 2:o + 5].T)
+        self.rand_push_torque = unif(-ma, ma, pack[o + 2:o + 5].T)
         self.root[:, 10:13] = self.rand_push_torque
         self._push_root(np.arange(self.n))
 
@@ -313,7 +331,8 @@ class HectorEnvOracle:
             rew = (getattr(self, "_reward_" + name)().astype(F) * scale).astype(F)
             self.rew_buf = (self.rew_buf + rew).astype(F)
             self.episode_sums[name] = (self.episode_sums[name] + rew).astype(F)
-        self.rew_buf = np.maximum(self.rew_buf, F(0))
+        if self.opts["only_positive_rewards"]:              # legged_robot.py:226-227
+            self.rew_buf = np.maximum(self.rew_buf, F(0))
 
     def _contact(self):
         return self.contact_forces[:, FEET, 2] > 5.0

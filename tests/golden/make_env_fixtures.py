@@ -14,6 +14,7 @@ time-out flags; post-step physics state (float64) and the tensors the glue read;
 
 Run in this container only:  python tests/golden/make_env_fixtures.py
 """
+import json
 import os
 import sys
 
@@ -31,7 +32,7 @@ RP_SIZE = 75          # + 1 row (RP["level"]) when the terrain curriculum is on
 
 
 def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_counter_init=0, add_noise=True,
-             full_stack_steps=(0, 1, 14, 15, 16), terrain=None, reward_scales=None):
+             full_stack_steps=(0, 1, 14, 15, 16), terrain=None, reward_scales=None, cfg_overrides=None):
     """terrain=None: ground plane.  terrain=dict(mesh_type=, num_rows=, num_cols=, border_size=): the reference's
     own HumanoidTerrain (humanoid/utils/terrain.py) lays out the map, the env takes its origins from it
     (legged_robot.py:687-697) and every reset adds U[-1,1] to xy (:381-384)."""
@@ -46,6 +47,12 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
             setattr(cfg.terrain, k, v)
     for k, v in (reward_scales or {}).items():      # e.g. the four reward terms HectorCfg zero-scales
         setattr(cfg.rewards.scales, k, v)
+    for path, v in (cfg_overrides or {}).items():   # dotted attribute paths, e.g. "commands.heading_command"
+        obj = cfg
+        parts = path.split(".")
+        for a in parts[:-1]:
+            obj = getattr(obj, a)
+        setattr(obj, parts[-1], v)
     cfg.env.num_envs = n_envs
     cfg.noise.add_noise = add_noise
     cfg.seed = seed
@@ -215,6 +222,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         res["full_obs"] = np.stack([full[k][0] for k in sorted(full)])
         res["full_priv"] = np.stack([full[k][1] for k in sorted(full)])
         res["reward_names"] = np.array(reward_names)
+        res["cfg_override_names"] = np.array(sorted(cfg_overrides or {}), dtype="U64")
+        res["cfg_override_values"] = np.array([json.dumps((cfg_overrides or {})[k]) for k in sorted(cfg_overrides or {})], dtype="U64")
         res["reward_override_names"] = np.array(sorted(reward_scales or {}), dtype="U32")
         res["reward_override_values"] = np.array([(reward_scales or {})[k] for k in sorted(reward_scales or {})], np.float64)
         res["reward_scales"] = np.array([env.reward_scales[k] for k in reward_names], np.float64)
@@ -269,6 +278,14 @@ if __name__ == "__main__":
         generate("env_rollout_e", N, 90, seed=23, action_std=0.5,
                  ep_len_init=[0, 37, 2385, 5, 797, 63, 31, 2395],
                  reward_scales=dict(joint_pos=1.6, low_speed=0.2, track_vel_hard=0.5, vel_mismatch_exp=0.5))
+    # F: config branches HectorCfg never takes: yaw-rate commands instead of heading commands (legged_robot.py:329-332,
+    #    :310-313 skipped), rewards not clipped at zero (:226-227), no pushes (:318), the sibling config's command ranges
+    if want("env_rollout_f"):
+        generate("env_rollout_f", N, 60, seed=31, action_std=0.4,
+                 ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390,
+                 cfg_overrides={"commands.heading_command": False, "rewards.only_positive_rewards": False,
+                                "domain_rand.push_robots": False, "commands.ranges.lin_vel_x": [-0.6, 0.8],
+                                "commands.ranges.ang_vel_yaw": [-0.5, 0.5]})
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others
     #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 19 shows every

@@ -28,6 +28,13 @@ def make_env(fx):
     cfg.noise.add_noise = bool(noise)
     cfg.seed = seed
     cfg.terrain.mesh_type = "plane"
+    if "cfg_override_names" in fx:        # fixture F: config branches HectorCfg never takes
+        import json
+        for path, v in zip(fx["cfg_override_names"], fx["cfg_override_values"]):
+            obj, parts = cfg, str(path).split(".")
+            for a in parts[:-1]:
+                obj = getattr(obj, a)
+            setattr(obj, parts[-1], json.loads(str(v)))
     if "reward_override_names" in fx:     # fixture E: the four terms HectorCfg zero-scales, switched on
         for k, v in zip(fx["reward_override_names"], fx["reward_override_values"]):
             setattr(cfg.rewards.scales, str(k), float(v))
@@ -59,7 +66,7 @@ def test_constructor_reset_and_first_observation(hxlib, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_e"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_e", "env_rollout_f"])
 def test_teacher_forced_steps(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)

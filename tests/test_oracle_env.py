@@ -19,6 +19,18 @@ def make_oracle_env(fx, **kw):
         from oracle.terrain import HeightField
         hs, vs, border = fx["terrain_params"]
         terrain = HeightField(fx["terrain_heights"], hs, vs, border)
+    if "cfg_override_names" in fx and len(fx["cfg_override_names"]):
+        import json
+        ov = {str(k): json.loads(str(v)) for k, v in zip(fx["cfg_override_names"], fx["cfg_override_values"])}
+        opts = {"cmd_ranges": {}}
+        for k, v in ov.items():
+            if k.startswith("commands.ranges."):
+                opts["cmd_ranges"][k.split(".")[-1]] = tuple(v)
+            elif k in ("commands.heading_command", "rewards.only_positive_rewards", "domain_rand.push_robots"):
+                opts[k.split(".")[-1]] = bool(v)
+            else:
+                raise AssertionError(f"fixture override {k} has no oracle counterpart")
+        kw.setdefault("opts", opts)
     if "reward_override_names" in fx and len(fx["reward_override_names"]):
         kw.setdefault("reward_scales", {str(k): float(v) for k, v in zip(fx["reward_override_names"], fx["reward_override_values"])})
     if "terrain_curriculum" in fx and int(fx["terrain_curriculum"]):
@@ -30,7 +42,7 @@ def make_oracle_env(fx, **kw):
 
 
 @pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100), ("env_rollout_d", 150),
-                                        ("env_rollout_e", 90)])
+                                        ("env_rollout_e", 90), ("env_rollout_f", 60)])
 def test_oracle_env_reproduces_reference(name, steps):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
@@ -40,6 +52,8 @@ def test_oracle_env_reproduces_reference(name, steps):
     assert list(fx["reward_names"]) == env.reward_order      # alphabetical dir() order (helpers.py:47)
     if name != "env_rollout_e":
         assert env.reward_order == REWARD_ORDER
+    if name == "env_rollout_f":
+        assert fx["rew"].min() < 0 and not env.opts["heading_command"]       # unclipped rewards, yaw-rate commands
     np.testing.assert_allclose(fx["reward_scales"], [env.reward_scale[k] * 0.01 for k in env.reward_order], rtol=1e-12)
     env.episode_length_buf[:] = fx["ep_len_init"]
     env.common_step_counter = sc0
