@@ -84,6 +84,8 @@ class HectorFreeEnv(VecEnv):
         if mesh_type not in ("plane", "heightfield", "trimesh"):
             raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
         rough = mesh_type in ("heightfield", "trimesh")
+        if getattr(cfg.env, "use_ref_actions", False):
+            raise NotImplementedError("env.use_ref_actions=True (hector_env.py:159-160) is not built; no reference config sets it")
         if not rough:
             cfg.terrain.curriculum = False                   # legged_robot.py:714-716
         self.max_episode_length_s = cfg.env.episode_length_s

@@ -104,10 +104,10 @@ class HectorEnvOracle:
         self.ref_dof_pos = np.zeros((n, 10), F)
         # opts: config switches / ranges that differ from HectorCfg (all keys optional):
         #   heading_command (commands.heading_command), only_positive_rewards, push_robots, cmd_ranges = dict(lin_vel_x=,
-        #   lin_vel_y=, ang_vel_yaw=, heading=), max_push_vel_xy, max_push_ang_vel
+        #   lin_vel_y=, ang_vel_yaw=, heading=), max_push_vel_xy, max_push_ang_vel, action_delay, action_noise
         o = dict(heading_command=True, only_positive_rewards=True, push_robots=True,
                  cmd_ranges=dict(lin_vel_x=(-0.6, 0.6), lin_vel_y=(-0.3, 0.3), ang_vel_yaw=(-0.3, 0.3), heading=(-3.14, 3.14)),
-                 max_push_vel_xy=0.3, max_push_ang_vel=0.4)
+                 max_push_vel_xy=0.3, max_push_ang_vel=0.4, action_delay=0.0, action_noise=0.02)
         for k, v in (opts or {}).items():
             if k == "cmd_ranges":
                 o["cmd_ranges"].update(v)
@@ -203,9 +203,9 @@ class HectorEnvOracle:
     # ---- step (hector_env.py:158-169 -> legged_robot.py:84-108)
     def step(self, actions, pack):
         a = np.clip(np.asarray(actions, F), -100, 100)
-        delay = pack[RP["delay"]][:, None] * F(0.0)
+        delay = pack[RP["delay"]][:, None] * F(self.opts["action_delay"])
         a = (F(1) - delay) * a + delay * self.actions
-        a = a + F(0.02) * pack[RP["act_noise"]:RP["act_noise"] + 10].T * a
+        a = a + F(self.opts["action_noise"]) * pack[RP["act_noise"]:RP["act_noise"] + 10].T * a
         self.actions = np.clip(a, -100, 100).astype(F)
         target = (self.actions * F(0.25) + DEFAULT_Q).astype(F)
         for _ in range(10):

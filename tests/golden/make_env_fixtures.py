@@ -279,13 +279,15 @@ if __name__ == "__main__":
                  ep_len_init=[0, 37, 2385, 5, 797, 63, 31, 2395],
                  reward_scales=dict(joint_pos=1.6, low_speed=0.2, track_vel_hard=0.5, vel_mismatch_exp=0.5))
     # F: config branches HectorCfg never takes: yaw-rate commands instead of heading commands (legged_robot.py:329-332,
-    #    :310-313 skipped), rewards not clipped at zero (:226-227), no pushes (:318), the sibling config's command ranges
+    #    :310-313 skipped), rewards not clipped at zero (:226-227), no pushes (:318), the sibling config's command ranges,
+    #    a non-zero action delay and another action-noise level (hector_env.py:166-168)
     if want("env_rollout_f"):
         generate("env_rollout_f", N, 60, seed=31, action_std=0.4,
                  ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390,
                  cfg_overrides={"commands.heading_command": False, "rewards.only_positive_rewards": False,
                                 "domain_rand.push_robots": False, "commands.ranges.lin_vel_x": [-0.6, 0.8],
-                                "commands.ranges.ang_vel_yaw": [-0.5, 0.5]})
+                                "commands.ranges.ang_vel_yaw": [-0.5, 0.5],
+                                "domain_rand.action_delay": 0.5, "domain_rand.action_noise": 0.05})
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others
     #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 19 shows every

@@ -28,6 +28,8 @@ def make_oracle_env(fx, **kw):
                 opts["cmd_ranges"][k.split(".")[-1]] = tuple(v)
             elif k in ("commands.heading_command", "rewards.only_positive_rewards", "domain_rand.push_robots"):
                 opts[k.split(".")[-1]] = bool(v)
+            elif k in ("domain_rand.action_delay", "domain_rand.action_noise"):
+                opts[k.split(".")[-1]] = float(v)
             else:
                 raise AssertionError(f"fixture override {k} has no oracle counterpart")
         kw.setdefault("opts", opts)
