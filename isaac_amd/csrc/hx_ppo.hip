@@ -1092,8 +1092,7 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
   float *X, *W, *Y, *slab, *bslab;
   const size_t nx = (size_t)rows * in_ld, ny = (size_t)rows * out, nw = (size_t)out * in_ld;
   HX_CHECK(hipMalloc(&X, nx * 4)); HX_CHECK(hipMalloc(&W, nw * 4)); HX_CHECK(hipMalloc(&Y, ny * 4));
-  const int wbm = getenv("HX_WGRAD_BM") ? atoi(getenv("HX_WGRAD_BM")) : 128;      // experiment: 256-row wgrad tiles
-  const int tiles = ((out + wbm - 1) / wbm) * ((in_ld + 127) / 128);
+  const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
   static int target_blocks = -1, round_up = 1;
   if (target_blocks < 0) {
     const char* e = getenv("HX_WGRAD_BLOCKS");
@@ -1125,8 +1124,7 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
     else { g.A = Y; g.lda = out; g.B = X; g.ldb = in_ld; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = rows; g.splits = splits; g.kchunk = kchunk; g.dbias = bslab; g.db_parts = (in_ld + 127) / 128;
       if (getenv("HX_BENCH_LD0")) { g.lda = 0; g.ldb = 0; }      // experiment: every k row aliases row 0 -> operands come from the L1
       if (getenv("HX_BENCH_NODB")) g.dbias = nullptr;             // experiment: without the bias-gradient column sums
-      if (wbm == 256) HX_V(256, 16, false, false, EPI_SLAB);
-      else if (bk == 16) { if (rows % 16 == 0 && !getenv("HX_BENCH_NOKFULL")) launch_gemm<128, 128, 16, false, false, EPI_SLAB, true>(nullptr, g, st); else HX_V(128, 16, false, false, EPI_SLAB); }
+      if (bk == 16) { if (rows % 16 == 0 && !getenv("HX_BENCH_NOKFULL")) launch_gemm<128, 128, 16, false, false, EPI_SLAB, true>(nullptr, g, st); else HX_V(128, 16, false, false, EPI_SLAB); }
       else HX_V(128, 32, false, false, EPI_SLAB); }
 #undef HX_PICK
 #undef HX_V
