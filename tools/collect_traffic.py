@@ -16,11 +16,12 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_traffic_{tag}")
-KEYS = {"<128, 128, 32, true, true, 0>": "hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)",
-        "<64, 128, 16, true, true, 0>": "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
-        "<128, 128, 32, true, false, 1>": "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)",
-        "<64, 128, 32, true, false, 1>": "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
-        "<128, 128, 16, false, false, 2>": "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"}
+# template-argument prefixes (a trailing KFULL flag follows in the symbol name)
+KEYS = {"<128, 128, 32, true, true, 0,": "hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)",
+        "<64, 128, 16, true, true, 0,": "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
+        "<128, 128, 32, true, false, 1,": "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)",
+        "<64, 128, 32, true, false, 1,": "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
+        "<128, 128, 16, false, false, 2,": "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
