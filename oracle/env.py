@@ -49,6 +49,72 @@ NOISE_VEC[35:38] = 0.1 * 1.0
 NOISE_VEC[38:41] = 0.03 * 1.0      # reference writes [38:42] on a 41-vector (hector_env.py:154)
 
 
+def rp_layout(ndof, nobs):
+    """Random-pack field offsets (include/hx_sim.h HX_RP_* for the hector task): delay 1, action noise ndof, command
+    resample 3, push 5, reset dofs ndof, reset xy 2, command resample at reset 3, observation noise nobs, terrain level 1."""
+    o, out = 0, {}
+    for name, w in (("delay", 1), ("act_noise", ndof), ("cmd_a", 3), ("push", 5), ("reset_q", ndof), ("reset_xy", 2),
+                    ("cmd_b", 3), ("obs_noise", nobs), ("level", 1)):
+        out[name] = o
+        o += w
+    return out
+
+
+class Task:
+    """What distinguishes one task of the hector family from another in the env glue (everything else is shared code)."""
+
+    def __init__(self, name, model_json, default_q, kp, kd, torque_limit, feet, knees, term, penal, noise_vec, reward_scale,
+                 opts, max_contact_force, min_dist, djp_pairs, djp_arm_pairs=()):
+        self.name, self.model_json = name, model_json
+        self.default_q, self.kp, self.kd, self.torque_limit = (np.asarray(x, F) for x in (default_q, kp, kd, torque_limit))
+        self.ndof = len(self.default_q)
+        self.nobs, self.npriv = 11 + 3 * self.ndof, 40 + 3 * self.ndof      # 41 / 70 for 10 DoF, 65 / 94 for 18
+        self.feet, self.knees, self.term, self.penal = feet, knees, term, penal
+        self.noise_vec = np.asarray(noise_vec, F)
+        self.reward_scale, self.opts = dict(reward_scale), dict(opts)
+        self.max_contact_force, self.min_dist = max_contact_force, min_dist
+        self.djp_pairs, self.djp_arm_pairs = djp_pairs, djp_arm_pairs       # joint slices of _reward_default_joint_pos
+        self.rp = rp_layout(self.ndof, self.nobs)
+        self.rp_size = self.rp["level"]
+
+
+_OPTS = dict(heading_command=True, only_positive_rewards=True, push_robots=True,
+             cmd_ranges=dict(lin_vel_x=(-0.6, 0.6), lin_vel_y=(-0.3, 0.3), ang_vel_yaw=(-0.3, 0.3), heading=(-3.14, 3.14)),
+             max_push_vel_xy=0.3, max_push_ang_vel=0.4, action_delay=0.0, action_noise=0.02)
+HECTOR = Task("hector", P.MODEL_JSON, DEFAULT_Q, KP, KD, TORQUE_LIMIT, FEET, KNEES, TERM, TERM, NOISE_VEC, REWARD_SCALE, _OPTS,
+              max_contact_force=180.0, min_dist=0.1, djp_pairs=((0, 2), (5, 7)))
+
+
+def _hector_full():
+    """hector with arms (reference hector_w_arm_config.py / hector_w_arm_env.py; DoF order L leg, L arm, R leg, R arm)."""
+    leg_q, arm_q = [0, 0, .785, -1.578, .785], [0, 0, 0, -.785]
+    leg_kp, arm_kp, leg_kd, arm_kd = [80, 80, 80, 80, 60], [30] * 4, [5, 5, 5, 5, 3], [3] * 4       # :97-100
+    # URDF efforts as compiled (the right elbow carries 24 Nm where the other arm joints carry 17: robot_w_arm.urdf)
+    eff = np.array([b["effort"] for b in P.load_model(P.MODEL_FULL_JSON)["bodies"][1:]], F)
+    side = lambda leg, arm: leg + arm
+    nv = np.zeros(65, F)                                   # hector_w_arm_env.py:157-161, overlapping slices included
+    nv[5:23] = 0.05 * 1.0
+    nv[23:41] = 0.5 * 0.05
+    nv[41:59] = 0.0
+    nv[58:61] = 0.1 * 1.0
+    nv[61:65] = 0.03 * 1.0
+    scale = dict(action_smoothness=-0.002, base_acc=0.22, base_height=0.8, collision=-1.0, default_joint_pos=1.2, dof_acc=-1e-6,
+                 dof_vel=-1e-3, feet_air_time=1.5, feet_clearance=1.2, feet_contact_forces=-0.02, feet_contact_number=1.5,
+                 feet_distance=0.2, foot_slip=-0.05, knee_distance=0.2, low_speed=0.2, orientation=1.0, torques=-1e-5,
+                 track_vel_hard=0.5, tracking_ang_vel=1.1, tracking_lin_vel=1.2, vel_mismatch_exp=0.5)    # :165-193
+    opts = dict(_OPTS)
+    opts["cmd_ranges"] = dict(_OPTS["cmd_ranges"], lin_vel_x=(-0.6, 0.8))                               # :146
+    opts["max_push_vel_xy"] = 0.5                                                                       # :133
+    return Task("hector_full", P.MODEL_FULL_JSON, side(leg_q, arm_q) * 2, side(leg_kp, arm_kp) * 2, side(leg_kd, arm_kd) * 2,
+                eff * F(0.85), feet=[5, 14], knees=[4, 13],
+                term=[0, 3, 12, 7, 16, 6, 15, 8, 17],      # 'base','thigh','shoulder','twist','roll' in that order (:35)
+                penal=[0, 3, 12], noise_vec=nv, reward_scale=scale, opts=opts, max_contact_force=200.0, min_dist=0.2,
+                djp_pairs=((0, 2), (9, 11)), djp_arm_pairs=((5, 7), (14, 16)))
+
+
+HECTOR_FULL = _hector_full()
+
+
 def quat_rotate_inverse(q, v):
     qw = q[:, 3:4]
     qv = q[:, :3]
@@ -88,26 +154,26 @@ def unif(lo, hi, u):
 class HectorEnvOracle:
     def __init__(self, n, shape_friction, base_mass, env_origins, init_pack, add_noise=True,
                  start_xy=None, phys_dtype=np.float64, terrain=None, custom_origins=False, curriculum=None,
-                 reward_scales=None, opts=None):
+                 reward_scales=None, opts=None, task=HECTOR):
         """terrain: oracle.terrain.HeightField or None (plane).  custom_origins: True for heightfield/trimesh
         (legged_robot.py:688), which adds U[-1,1] to the reset xy (:381-384).
         curriculum: None or dict(origins [rows][cols][3], levels [n], types [n], env_length) -- the terrain curriculum of
         legged_robot.py:399-419; packs then carry one more row, RP["level"]."""
         self.n = n
+        self.task = T = task
         # reward_scales: overrides / additions to HectorCfg's scales (hector_config.py:161-189), e.g. the four terms HectorCfg
         # zero-scales (joint_pos, low_speed, track_vel_hard, vel_mismatch_exp).  Active terms are evaluated in alphabetical
         # order like the reference (dir(), helpers.py:47; zero scales are dropped, legged_robot.py:521-527).
-        sc = dict(REWARD_SCALE)
+        sc = dict(T.reward_scale)
         sc.update(reward_scales or {})
         self.reward_scale = {k: v for k, v in sc.items() if v != 0}
         self.reward_order = sorted(self.reward_scale)
-        self.ref_dof_pos = np.zeros((n, 10), F)
+        self.ref_dof_pos = np.zeros((n, T.ndof), F)
         # opts: config switches / ranges that differ from HectorCfg (all keys optional):
         #   heading_command (commands.heading_command), only_positive_rewards, push_robots, cmd_ranges = dict(lin_vel_x=,
         #   lin_vel_y=, ang_vel_yaw=, heading=), max_push_vel_xy, max_push_ang_vel, action_delay, action_noise
-        o = dict(heading_command=True, only_positive_rewards=True, push_robots=True,
-                 cmd_ranges=dict(lin_vel_x=(-0.6, 0.6), lin_vel_y=(-0.3, 0.3), ang_vel_yaw=(-0.3, 0.3), heading=(-3.14, 3.14)),
-                 max_push_vel_xy=0.3, max_push_ang_vel=0.4, action_delay=0.0, action_noise=0.02)
+        o = dict(T.opts)
+        o["cmd_ranges"] = dict(T.opts["cmd_ranges"])
         for k, v in (opts or {}).items():
             if k == "cmd_ranges":
                 o["cmd_ranges"].update(v)
@@ -123,10 +189,11 @@ class HectorEnvOracle:
             self.terrain_types = np.asarray(curriculum["types"], np.int64)
             self.max_terrain_level = self.terrain_origins.shape[0]
             self.env_length = float(curriculum["env_length"])
-        m0 = P.load_model()["bodies"][0]["mass"]
+        model = P.load_model(T.model_json)
+        m0 = model["bodies"][0]["mass"]
         self.phys = P.HectorPhysics(n, base_mass_added=np.asarray(base_mass, np.float64) - m0,
-                                    shape_friction=shape_friction, dtype=phys_dtype, terrain=terrain)
-        self.state = P.State(n, phys_dtype)
+                                    shape_friction=shape_friction, dtype=phys_dtype, terrain=terrain, model=model)
+        self.state = P.State(n, phys_dtype, T.ndof)
         if start_xy is not None:
             # actor creation pose (legged_robot.py:653-655): origin + U[-1,1]^2, z of the origin; the first
             # privileged frames read body poses from this pose because reset does not refresh them
@@ -138,8 +205,8 @@ class HectorEnvOracle:
         self.dt = 0.01
         self.max_episode_length = 2400.0
         z = lambda *s: np.zeros(s, F)
-        self.actions, self.last_actions, self.last_last_actions = z(n, 10), z(n, 10), z(n, 10)
-        self.last_dof_vel, self.last_root_vel = z(n, 10), z(n, 6)
+        self.actions, self.last_actions, self.last_last_actions = z(n, T.ndof), z(n, T.ndof), z(n, T.ndof)
+        self.last_dof_vel, self.last_root_vel = z(n, T.ndof), z(n, 6)
         self.commands = z(n, 4)
         self.feet_air_time = z(n, 2)
         self.last_contacts = np.zeros((n, 2), bool)
@@ -153,9 +220,9 @@ class HectorEnvOracle:
         self.time_outs_visible = np.zeros(n, bool)      # extras["time_outs"], stale unless some env reset
         self.episode_sums = {k: z(n) for k in self.reward_order}
         self.rew_buf = z(n)
-        self.torques = z(n, 10)
-        self.obs_hist = z(15, n, 41)       # oldest .. newest
-        self.priv_hist = z(15, n, 70)
+        self.torques = z(n, T.ndof)
+        self.obs_hist = z(15, n, T.nobs)       # oldest .. newest
+        self.priv_hist = z(15, n, T.npriv)
         self.extras_episode = {}
         # tensors the glue reads from the simulator
         self._refresh(full=True)
@@ -203,14 +270,15 @@ class HectorEnvOracle:
     # ---- step (hector_env.py:158-169 -> legged_robot.py:84-108)
     def step(self, actions, pack):
         a = np.clip(np.asarray(actions, F), -100, 100)
+        RP, T = self.task.rp, self.task
         delay = pack[RP["delay"]][:, None] * F(self.opts["action_delay"])
         a = (F(1) - delay) * a + delay * self.actions
-        a = a + F(self.opts["action_noise"]) * pack[RP["act_noise"]:RP["act_noise"] + 10].T * a
+        a = a + F(self.opts["action_noise"]) * pack[RP["act_noise"]:RP["act_noise"] + T.ndof].T * a
         self.actions = np.clip(a, -100, 100).astype(F)
-        target = (self.actions * F(0.25) + DEFAULT_Q).astype(F)
+        target = (self.actions * F(0.25) + self.task.default_q).astype(F)
         for _ in range(10):
-            self.phys.substep(self.state, target.astype(np.float64), KP.astype(np.float64),
-                              KD.astype(np.float64), TORQUE_LIMIT.astype(np.float64))
+            self.phys.substep(self.state, target.astype(np.float64), T.kp.astype(np.float64),
+                              T.kd.astype(np.float64), T.torque_limit.astype(np.float64))
         # torque the reference reports = _compute_torques at the start of the last substep
         self.torques = self.phys.tau.astype(F)
         self._refresh(full=True)
@@ -238,7 +306,7 @@ class HectorEnvOracle:
         if self.opts["push_robots"] and self.common_step_counter % 400 == 0:
             self._push_robots(pack)
         # termination (legged_robot.py:155-160)
-        fn = np.sqrt(np.sum(self.contact_forces[:, TERM] ** 2, -1))
+        fn = np.sqrt(np.sum(self.contact_forces[:, self.task.term] ** 2, -1))
         self.reset_buf = np.any(fn > 1.0, 1)
         self.time_out_buf = self.episode_length_buf > self.max_episode_length
         self.reset_buf |= self.time_out_buf
@@ -254,7 +322,7 @@ class HectorEnvOracle:
     def _resample_commands(self, ids, pack, field):
         if len(ids) == 0:
             return
-        o = RP[field]
+        o = self.task.rp[field]
         cr = self.opts["cmd_ranges"]
         self.commands[ids, 0] = unif(cr["lin_vel_x"][0], cr["lin_vel_x"][1], pack[o][ids])
         self.commands[ids, 1] = unif(cr["lin_vel_y"][0], cr["lin_vel_y"][1], pack[o + 1][ids])
@@ -266,7 +334,7 @@ class HectorEnvOracle:
         self.commands[ids, :2] *= (nrm > 0.2)[:, None]
 
     def _push_robots(self, pack):
-        o = RP["push"]
+        o = self.task.rp["push"]
         mx, ma = self.opts["max_push_vel_xy"], self.opts["max_push_ang_vel"]
         self.rand_push_force[:, :2] = unif(-mx, mx, pack[o:o + 2].T)
         self.root[:, 7:9] = self.rand_push_force[:, :2]
@@ -284,7 +352,7 @@ class HectorEnvOracle:
         cn = np.sqrt(np.sum(self.commands[ids, :2] ** 2, 1, dtype=F), dtype=F)
         move_down = (distance < cn * F(self.max_episode_length * self.dt) * F(0.5)) & ~move_up
         lv = self.terrain_levels[ids] + move_up.astype(np.int64) - move_down.astype(np.int64)
-        rnd = np.minimum(np.floor(pack[RP["level"]][ids] * F(self.max_terrain_level)).astype(np.int64), self.max_terrain_level - 1)
+        rnd = np.minimum(np.floor(pack[self.task.rp["level"]][ids] * F(self.max_terrain_level)).astype(np.int64), self.max_terrain_level - 1)
         self.terrain_levels[ids] = np.where(lv >= self.max_terrain_level, rnd, np.clip(lv, 0, None))
         self.env_origins[ids] = self.terrain_origins[self.terrain_levels[ids], self.terrain_types[ids]]
 
@@ -294,15 +362,15 @@ class HectorEnvOracle:
             return
         if self.curriculum is not None:
             self._update_terrain_curriculum(ids, pack)
-        o = RP["reset_q"]
-        self.dof_pos[ids] = DEFAULT_Q + unif(-0.15, 0.15, pack[o:o + 10].T[ids])
+        o = self.task.rp["reset_q"]
+        self.dof_pos[ids] = self.task.default_q + unif(-0.15, 0.15, pack[o:o + self.task.ndof].T[ids])
         self.dof_vel[ids] = 0
         self._push_dofs(ids)
         base_init = np.array([0, 0, 0.55, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], F)
         self.root[ids] = base_init
         self.root[ids, :3] += self.env_origins[ids]
         if self.custom_origins:
-            o = RP["reset_xy"]
+            o = self.task.rp["reset_xy"]
             self.root[ids, :2] += unif(-1.0, 1.0, pack[o:o + 2].T[ids])
         self._push_root(ids)
         self._resample_commands(ids, pack, "cmd_b")
@@ -335,7 +403,7 @@ class HectorEnvOracle:
             self.rew_buf = np.maximum(self.rew_buf, F(0))
 
     def _contact(self):
-        return self.contact_forces[:, FEET, 2] > 5.0
+        return self.contact_forces[:, self.task.feet, 2] > 5.0
 
     def _reward_action_smoothness(self):
         t1 = np.sum((self.last_actions - self.actions) ** 2, 1)
@@ -349,19 +417,24 @@ class HectorEnvOracle:
 
     def _reward_base_height(self):
         sm = self._stance_mask()
-        mh = np.sum(self.rigid_state[:, FEET, 2] * sm, 1) / np.sum(sm, 1)
+        mh = np.sum(self.rigid_state[:, self.task.feet, 2] * sm, 1) / np.sum(sm, 1)
         bh = self.root[:, 2] - (mh - F(0.05))
         return np.exp(-np.abs(bh - F(0.55)) * F(100))
 
     def _reward_collision(self):
-        fn = np.sqrt(np.sum(self.contact_forces[:, TERM] ** 2, -1))
+        fn = np.sqrt(np.sum(self.contact_forces[:, self.task.penal] ** 2, -1))
         return np.sum(F(1.0) * (fn > 0.1), 1)
 
     def _reward_default_joint_pos(self):
-        jd = self.dof_pos - DEFAULT_Q
-        yr = np.sqrt(np.sum(jd[:, 0:2] ** 2, 1)) + np.sqrt(np.sum(jd[:, 5:7] ** 2, 1))
+        jd = self.dof_pos - self.task.default_q
+        nrm = lambda ab: np.sqrt(np.sum(jd[:, ab[0]:ab[1]] ** 2, 1))
+        yr = nrm(self.task.djp_pairs[0]) + nrm(self.task.djp_pairs[1])             # hip yaw / roll of both legs
         yr = np.clip(yr - F(0.1), 0, 50)
-        return np.exp(-yr * F(100)) - F(0.01) * np.sqrt(np.sum(jd * jd, 1))
+        r = np.exp(-yr * F(100)) - F(0.01) * np.sqrt(np.sum(jd * jd, 1))
+        if self.task.djp_arm_pairs:                                                # hector_w_arm_env.py:371-378
+            ar = nrm(self.task.djp_arm_pairs[0]) + nrm(self.task.djp_arm_pairs[1])
+            r = r + np.exp(-np.clip(ar - F(0.1), 0, 25) * F(2))
+        return r
 
     def _reward_dof_acc(self):
         return np.sum(((self.last_dof_vel - self.dof_vel) / F(self.dt)) ** 2, 1)
@@ -382,7 +455,7 @@ class HectorEnvOracle:
 
     def _reward_feet_clearance(self):
         contact = self._contact()
-        feet_z = self.rigid_state[:, FEET, 2] - F(0.05)
+        feet_z = self.rigid_state[:, self.task.feet, 2] - F(0.05)
         dz = feet_z - self.last_feet_z
         self.feet_height = (self.feet_height + dz).astype(F)
         self.last_feet_z = feet_z
@@ -393,8 +466,8 @@ class HectorEnvOracle:
         return r
 
     def _reward_feet_contact_forces(self):
-        fn = np.sqrt(np.sum(self.contact_forces[:, FEET] ** 2, -1))
-        return np.sum(np.clip(fn - F(180), 0, 400), 1)
+        fn = np.sqrt(np.sum(self.contact_forces[:, self.task.feet] ** 2, -1))
+        return np.sum(np.clip(fn - F(self.task.max_contact_force), 0, 400), 1)
 
     def _reward_feet_contact_number(self):
         contact = self._contact()
@@ -404,16 +477,16 @@ class HectorEnvOracle:
     def _dist_reward(self, idx, max_df):
         pos = self.rigid_state[:, idx, :2]
         d = np.sqrt(np.sum((pos[:, 0] - pos[:, 1]) ** 2, 1))
-        dmin = np.clip(d - F(0.1), -0.5, 0.0)
+        dmin = np.clip(d - F(self.task.min_dist), -0.5, 0.0)
         dmax = np.clip(d - F(max_df), 0, 0.5)
         return (np.exp(-np.abs(dmin) * F(100)) + np.exp(-np.abs(dmax) * F(100))) / F(2)
 
     def _reward_feet_distance(self):
-        return self._dist_reward(FEET, 0.5)
+        return self._dist_reward(self.task.feet, 0.5)
 
     def _reward_foot_slip(self):
         contact = self._contact()
-        sp = np.sqrt(np.sum(self.rigid_state[:, FEET, 7:9] ** 2, 2))
+        sp = np.sqrt(np.sum(self.rigid_state[:, self.task.feet, 7:9] ** 2, 2))
         return np.sum(np.sqrt(sp) * contact, 1)
 
     def _reward_joint_pos(self):
@@ -449,7 +522,7 @@ class HectorEnvOracle:
         return (lin + ang) / F(2)
 
     def _reward_knee_distance(self):
-        return self._dist_reward(KNEES, 0.25)
+        return self._dist_reward(self.task.knees, 0.25)
 
     def _reward_orientation(self):
         a = np.exp(-np.sum(np.abs(self.base_euler[:, :2]), 1) * F(10))
@@ -473,7 +546,7 @@ class HectorEnvOracle:
         # compute_ref_state (hector_env.py:90-111): the gait reference pose that _reward_joint_pos reads one step later
         sp = np.sin(F(2 * np.pi) * ph).astype(F)
         sl, sr = np.minimum(sp, 0), np.maximum(sp, 0)
-        ref = np.zeros((self.n, 10), F)
+        ref = np.zeros((self.n, self.task.ndof), F)
         s1 = F(0.17)                                        # rewards.target_joint_pos_scale (hector_config.py:151)
         ref[:, 2], ref[:, 3], ref[:, 4] = sl * s1, sl * (2 * s1), sl * s1
         ref[:, 7], ref[:, 8], ref[:, 9] = sr * s1, sr * (2 * s1), sr * s1
@@ -484,18 +557,18 @@ class HectorEnvOracle:
         sm = self._stance_mask()
         cm = self._contact().astype(F)
         cmd = np.concatenate([sin_pos, cos_pos, self.commands[:, :3] * np.array([2, 2, 1], F)], 1)
-        qd = (self.dof_pos - DEFAULT_Q).astype(F)
+        qd = (self.dof_pos - self.task.default_q).astype(F)
         dq = self.dof_vel * F(0.05)
         priv = np.concatenate([cmd, qd, dq, self.actions, self.base_lin_vel * F(2), self.base_ang_vel,
-                               self.base_euler, self.rigid_state[:, FEET, :3].reshape(self.n, 6),
-                               self.rigid_state[:, FEET, 7:10].reshape(self.n, 6), self.root[:, :3],
+                               self.base_euler, self.rigid_state[:, self.task.feet, :3].reshape(self.n, 6),
+                               self.rigid_state[:, self.task.feet, 7:10].reshape(self.n, 6), self.root[:, :3],
                                self.rand_push_force[:, :2], self.rand_push_torque, self.env_frictions,
                                self.body_mass / F(30.0), sm, cm], 1).astype(F)
         obs = np.concatenate([cmd, qd, dq, self.actions, self.base_ang_vel, self.base_euler], 1).astype(F)
         if self.add_noise:
-            o = RP["obs_noise"]
-            obs = (obs + pack[o:o + 41].T * NOISE_VEC * F(0.6)).astype(F)
+            o = self.task.rp["obs_noise"]
+            obs = (obs + pack[o:o + self.task.nobs].T * self.task.noise_vec * F(0.6)).astype(F)
         self.obs_hist = np.concatenate([self.obs_hist[1:], obs[None]], 0)
         self.priv_hist = np.concatenate([self.priv_hist[1:], priv[None]], 0)
-        self.obs_buf = self.obs_hist.transpose(1, 0, 2).reshape(self.n, 615)
-        self.priv_buf = self.priv_hist.transpose(1, 0, 2).reshape(self.n, 1050)
+        self.obs_buf = self.obs_hist.transpose(1, 0, 2).reshape(self.n, 15 * self.task.nobs)
+        self.priv_buf = self.priv_hist.transpose(1, 0, 2).reshape(self.n, 15 * self.task.npriv)

@@ -32,15 +32,19 @@ RP_SIZE = 75          # + 1 row (RP["level"]) when the terrain curriculum is on
 
 
 def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_counter_init=0, add_noise=True,
-             full_stack_steps=(0, 1, 14, 15, 16), terrain=None, reward_scales=None, cfg_overrides=None):
+             full_stack_steps=(0, 1, 14, 15, 16), terrain=None, reward_scales=None, cfg_overrides=None, task="hector"):
     """terrain=None: ground plane.  terrain=dict(mesh_type=, num_rows=, num_cols=, border_size=): the reference's
     own HumanoidTerrain (humanoid/utils/terrain.py) lays out the map, the env takes its origins from it
     (legged_robot.py:687-697) and every reset adds U[-1,1] to xy (:381-384)."""
-    env_mod, cfg_mod, helpers = loader.load_env()
+    env_mod, cfg_mod, helpers = loader.load_env(task)
     from isaacgym import gymapi, torch_utils
     import isaacgym.torch_utils  # noqa: F401
+    from oracle.env import HECTOR, HECTOR_FULL
+    T = HECTOR_FULL if task == "hector_full" else HECTOR
+    RP, RP_SIZE, ND, NOBS, NPRIV = T.rp, T.rp_size, T.ndof, T.nobs, T.npriv
+    env_cls = env_mod.HectorFullFreeEnv if task == "hector_full" else env_mod.HectorFreeEnv
 
-    cfg = cfg_mod.HectorCfg()
+    cfg = cfg_mod.HectorFullCfg() if task == "hector_full" else cfg_mod.HectorCfg()
     cfg.terrain.mesh_type = "plane"
     if terrain is not None:
         for k, v in terrain.items():
@@ -82,7 +86,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
 
     torch.rand, torch.randn_like, torch.randint_like = rand, randn_like, randint_like
     try:
-        env = env_mod.HectorFreeEnv(cfg, sim_params, gymapi.SIM_PHYSX, "cpu", True)
+        env = env_cls(cfg, sim_params, gymapi.SIM_PHYSX, "cpu", True)
         gym = env.gym
         gym.env = env
         N = n_envs
@@ -114,8 +118,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
                 assert e[0] == "rand" and e[1].shape == (N, 1)
                 pack[RP["delay"]] = e[1][:, 0].numpy()
                 e = next(it)
-                assert e[0] == "randn" and e[1].shape == (N, 10)
-                pack[RP["act_noise"]:RP["act_noise"] + 10] = e[1].numpy().T
+                assert e[0] == "randn" and e[1].shape == (N, ND)
+                pack[RP["act_noise"]:RP["act_noise"] + ND] = e[1].numpy().T
                 e = next(it, None)
             while e is not None:
                 if e[0] == "mark_resample":
@@ -137,8 +141,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
                         pack[RP["level"], ids] = pending_level.astype(np.float32)
                         pending_level = None
                     r = next(it)
-                    assert r[0] == "rand" and r[1].shape == (len(ids), 10)
-                    pack[RP["reset_q"]:RP["reset_q"] + 10, ids] = r[1].numpy().T
+                    assert r[0] == "rand" and r[1].shape == (len(ids), ND)
+                    pack[RP["reset_q"]:RP["reset_q"] + ND, ids] = r[1].numpy().T
                     if terrain is not None:          # custom origins: xy offset of the reset pose
                         r = next(it)
                         assert r[0] == "rand" and r[1].shape == (len(ids), 2)
@@ -149,8 +153,8 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
                     r = next(it)
                     assert r[0] == "rand" and r[1].shape == (N, 3)
                     pack[RP["push"] + 2:RP["push"] + 5] = r[1].numpy().T
-                elif e[0] == "randn" and e[1].shape == (N, 41):
-                    pack[RP["obs_noise"]:RP["obs_noise"] + 41] = e[1].numpy().T
+                elif e[0] == "randn" and e[1].shape == (N, NOBS):
+                    pack[RP["obs_noise"]:RP["obs_noise"] + NOBS] = e[1].numpy().T
                 else:
                     raise AssertionError(("unexpected draw", e[0], getattr(e[1], "shape", None)))
                 e = next(it, None)
@@ -185,13 +189,13 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         arng = np.random.default_rng(seed + 1000)
         reward_names = list(env.reward_names)
         for t in range(n_steps):
-            a = (arng.standard_normal((N, 10)) * action_std).astype(np.float32)
+            a = (arng.standard_normal((N, ND)) * action_std).astype(np.float32)
             obs, priv, rew, reset, extras = env.step(torch.from_numpy(a.copy()))
             packs.append(build_pack(list(log), False))
             log.clear()
             out["actions"].append(a)
-            out["obs41"].append(obs[:, -41:].numpy().copy())
-            out["priv70"].append(priv[:, -70:].numpy().copy())
+            out["obs41"].append(obs[:, -NOBS:].numpy().copy())         # newest frame (41 / 70 wide for hector, 65 / 94 for hector_full)
+            out["priv70"].append(priv[:, -NPRIV:].numpy().copy())
             out["rew"].append(rew.numpy().copy())
             out["reset"].append(reset.numpy().astype(np.uint8))
             out["timeout"].append(env.time_out_buf.numpy().astype(np.uint8))
@@ -202,7 +206,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
             out["q"].append(s.q.copy())
             out["qd"].append(s.qd.copy())
             out["contact"].append(env.contact_forces.numpy().copy())
-            out["bodies"].append(env.rigid_state.numpy()[:, [4, 5, 9, 10]].copy())
+            out["bodies"].append(env.rigid_state.numpy()[:, [T.knees[0], T.feet[0], T.knees[1], T.feet[1]]].copy())
             out["torques"].append(env.torques.numpy().copy())
             out["commands"].append(env.commands.numpy().copy())
             out["ep_len"].append(env.episode_length_buf.numpy().copy())
@@ -221,6 +225,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         res["full_steps"] = np.array(sorted(full))
         res["full_obs"] = np.stack([full[k][0] for k in sorted(full)])
         res["full_priv"] = np.stack([full[k][1] for k in sorted(full)])
+        res["task"] = np.array(task)
         res["reward_names"] = np.array(reward_names)
         res["cfg_override_names"] = np.array(sorted(cfg_overrides or {}), dtype="U64")
         res["cfg_override_values"] = np.array([json.dumps((cfg_overrides or {})[k]) for k in sorted(cfg_overrides or {})], dtype="U64")
@@ -288,6 +293,11 @@ if __name__ == "__main__":
                                 "domain_rand.push_robots": False, "commands.ranges.lin_vel_x": [-0.6, 0.8],
                                 "commands.ranges.ang_vel_yaw": [-0.5, 0.5],
                                 "domain_rand.action_delay": 0.5, "domain_rand.action_noise": 0.05})
+    # G: the sibling task hector_full (18 DoF: legs + arms, reference hector_w_arm_env.py / hector_w_arm_config.py) through
+    #    the same stub -- pins the oracle's restatement of that task's glue (SURVEY 8f-4 groundwork; no kernel yet)
+    if want("env_rollout_g"):
+        generate("env_rollout_g", N, 80, seed=37, action_std=0.5, task="hector_full",
+                 ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390)
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others
     #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 19 shows every

@@ -121,17 +121,21 @@ class Gym:
         self.terrain_hf = HeightField(v[:, 2].reshape(rows, cols), hs, 1.0, -params.transform.p.x)
 
     def load_asset(self, sim, root, file, options):
+        # the compiled model of the asset the task names: robot.urdf (hector) or robot_w_arm.urdf (hector_full)
+        if "w_arm" in str(file):
+            self.model = _phys.load_model(_phys.MODEL_FULL_JSON)
+        self.nd, self.nbod = len(self.model["bodies"]) - 1, len(self.model["bodies"])
         return "asset"
 
     def get_asset_dof_count(self, asset):
-        return 10
+        return self.nd
 
     def get_asset_rigid_body_count(self, asset):
-        return 11
+        return self.nbod
 
     def get_asset_dof_properties(self, asset):
         B = self.model["bodies"][1:]
-        props = np.zeros(10, dtype=[("lower", "f4"), ("upper", "f4"), ("velocity", "f4"), ("effort", "f4")])
+        props = np.zeros(self.nd, dtype=[("lower", "f4"), ("upper", "f4"), ("velocity", "f4"), ("effort", "f4")])
         for i, b in enumerate(B):
             props[i] = (b["lower"], b["upper"], b["velocity"], b["effort"])
         return props
@@ -178,13 +182,13 @@ class Gym:
         n = self.n
         m0 = self.model["bodies"][0]["mass"]
         self.phys = _phys.HectorPhysics(n, base_mass_added=np.array(self.base_mass) - m0,
-                                        shape_friction=np.array(self.shape_friction), terrain=self.terrain_hf)
-        self.state = _phys.State(n)
+                                        shape_friction=np.array(self.shape_friction), terrain=self.terrain_hf, model=self.model)
+        self.state = _phys.State(n, ndof=self.nd)
         self.state.root_pos[:] = np.array(self.start_pos)
         self.root_t = torch.zeros(n, 13)
-        self.dof_t = torch.zeros(n * 10, 2)
-        self.contact_t = torch.zeros(n * 11, 3)
-        self.body_t = torch.zeros(n * 11, 13)
+        self.dof_t = torch.zeros(n * self.nd, 2)
+        self.contact_t = torch.zeros(n * self.nbod, 3)
+        self.body_t = torch.zeros(n * self.nbod, 13)
         self._publish()
 
     # ---- tensor API
@@ -206,11 +210,11 @@ class Gym:
         self.root_t[:, 3:7] = torch.from_numpy(s.root_quat).float()
         self.root_t[:, 7:10] = torch.from_numpy(s.root_linvel).float()
         self.root_t[:, 10:13] = torch.from_numpy(s.root_angvel).float()
-        d = self.dof_t.view(self.n, 10, 2)
+        d = self.dof_t.view(self.n, self.nd, 2)
         d[..., 0] = torch.from_numpy(s.q).float()
         d[..., 1] = torch.from_numpy(s.qd).float()
-        self.body_t.view(self.n, 11, 13)[:] = torch.from_numpy(self.phys.body_states(s)).float()
-        self.contact_t.view(self.n, 11, 3)[:] = torch.from_numpy(self.phys.contact_force).float()
+        self.body_t.view(self.n, self.nbod, 13)[:] = torch.from_numpy(self.phys.body_states(s)).float()
+        self.contact_t.view(self.n, self.nbod, 3)[:] = torch.from_numpy(self.phys.contact_force).float()
 
     def refresh_dof_state_tensor(self, sim):
         pass   # tensors are republished at the end of every simulate / set call
@@ -218,7 +222,7 @@ class Gym:
     refresh_actor_root_state_tensor = refresh_net_contact_force_tensor = refresh_rigid_body_state_tensor = refresh_dof_state_tensor
 
     def set_dof_actuation_force_tensor(self, sim, t):
-        self.tau_in = t.detach().clone().view(self.n, 10)
+        self.tau_in = t.detach().clone().view(self.n, self.nd)
 
     def simulate(self, sim):
         env = self.env
@@ -242,7 +246,7 @@ class Gym:
 
     def set_dof_state_tensor_indexed(self, sim, t, ids, n):
         ids = ids.long().numpy()
-        d = self.dof_t.view(self.n, 10, 2)
+        d = self.dof_t.view(self.n, self.nd, 2)
         self.state.q[ids] = d[ids, :, 0].double().numpy()
         self.state.qd[ids] = d[ids, :, 1].double().numpy()
         self._publish_bodies()

@@ -32,8 +32,9 @@ def load_ppo():
     return ac, rs, ppo
 
 
-def load_env():
-    """reference HectorFreeEnv / HectorCfg / HectorCfgPPO over the stub isaacgym (tests/refstub/isaacgym)."""
+def load_env(task="hector"):
+    """reference HectorFreeEnv / HectorCfg (task "hector") or HectorFullFreeEnv / HectorFullCfg (task "hector_full") over
+    the stub isaacgym (tests/refstub/isaacgym)."""
     sys.dont_write_bytecode = True
     if _REPO not in sys.path:
         sys.path.insert(0, _REPO)
@@ -50,8 +51,9 @@ def load_env():
         _pkg("humanoid.envs.custom", os.path.join(REF, "humanoid/envs/custom"))
         lr = importlib.import_module("humanoid.envs.base.legged_robot")
         e.LeggedRobot = lr.LeggedRobot
-    env_mod = importlib.import_module("humanoid.envs.custom.hector_env")
-    cfg_mod = importlib.import_module("humanoid.envs.custom.hector_config")
+    stem = "hector_w_arm" if task == "hector_full" else "hector"
+    env_mod = importlib.import_module(f"humanoid.envs.custom.{stem}_env")
+    cfg_mod = importlib.import_module(f"humanoid.envs.custom.{stem}_config")
     helpers = importlib.import_module("humanoid.utils.helpers")
     return env_mod, cfg_mod, helpers
 

@@ -19,6 +19,9 @@ def make_oracle_env(fx, **kw):
         from oracle.terrain import HeightField
         hs, vs, border = fx["terrain_params"]
         terrain = HeightField(fx["terrain_heights"], hs, vs, border)
+    if "task" in fx and str(fx["task"]) == "hector_full":
+        from oracle.env import HECTOR_FULL
+        kw.setdefault("task", HECTOR_FULL)
     if "cfg_override_names" in fx and len(fx["cfg_override_names"]):
         import json
         ov = {str(k): json.loads(str(v)) for k, v in zip(fx["cfg_override_names"], fx["cfg_override_values"])}
@@ -44,7 +47,7 @@ def make_oracle_env(fx, **kw):
 
 
 @pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 100), ("env_rollout_d", 150),
-                                        ("env_rollout_e", 90), ("env_rollout_f", 60)])
+                                        ("env_rollout_e", 90), ("env_rollout_f", 60), ("env_rollout_g", 80)])
 def test_oracle_env_reproduces_reference(name, steps):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
@@ -52,7 +55,7 @@ def test_oracle_env_reproduces_reference(name, steps):
     np.testing.assert_allclose(env.obs_buf, fx["init_obs_full"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(env.priv_buf, fx["init_priv_full"], rtol=0, atol=1e-6)
     assert list(fx["reward_names"]) == env.reward_order      # alphabetical dir() order (helpers.py:47)
-    if name != "env_rollout_e":
+    if name not in ("env_rollout_e", "env_rollout_g"):
         assert env.reward_order == REWARD_ORDER
     if name == "env_rollout_f":
         assert fx["rew"].min() < 0 and not env.opts["heading_command"]       # unclipped rewards, yaw-rate commands
@@ -62,8 +65,8 @@ def test_oracle_env_reproduces_reference(name, steps):
     full = {int(s): i for i, s in enumerate(fx["full_steps"])}
     for t in range(min(steps, total)):
         obs, priv, rew, reset = env.step(fx["actions"][t], fx["packs"][t + 1])
-        np.testing.assert_allclose(obs[:, -41:], fx["obs41"][t], rtol=0, atol=1e-4, err_msg=f"obs step {t}")
-        np.testing.assert_allclose(priv[:, -70:], fx["priv70"][t], rtol=0, atol=1e-4, err_msg=f"priv step {t}")
+        np.testing.assert_allclose(obs[:, -env.task.nobs:], fx["obs41"][t], rtol=0, atol=1e-4, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(priv[:, -env.task.npriv:], fx["priv70"][t], rtol=0, atol=1e-4, err_msg=f"priv step {t}")
         np.testing.assert_allclose(rew, fx["rew"][t], rtol=0, atol=1e-6)
         assert np.array_equal(reset, fx["reset"][t].astype(bool))
         assert np.array_equal(env.time_out_buf, fx["timeout"][t].astype(bool))

@@ -154,6 +154,26 @@ def collapse(urdf_path, sort_children=False):
     return bodies
 
 
+def box_corners(center, size):
+    c, h = np.array(center), np.array(size) / 2
+    return [(c + h * np.array([sx, sy, sz])).tolist() for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+
+
+def leg_and_base_contacts(name_to_idx):
+    """The collision primitives of the biped proper (same for robot.urdf and robot_w_arm.urdf): see the module docstring."""
+    contacts = [{"body": name_to_idx["base"], "points": box_corners((0, 0, 0), (0.125, 0.19, 0.248)),
+                 "source": "const.xacro:17-19 trunk box (body.stl absent)"}]
+    for side, sgn in (("L", 1.0), ("R", -1.0)):
+        contacts.append({"body": name_to_idx[f"{side}_thigh"],
+                         "points": box_corners((0, sgn * 0.0175, -0.09), (0.06, 0.035, 0.18)),
+                         "source": "const.xacro:128-133 thigh box (thigh_combined_*2.stl absent)"})
+        lo, hi = stl_bbox(os.path.join(MESH_DIR, f"foot_{side}2.stl"))
+        ctr, size = (lo + hi) / 2, hi - lo
+        contacts.append({"body": name_to_idx[f"{side}_toe"], "points": box_corners(ctr, size),
+                         "source": f"foot_{side}2.stl axis-aligned bounding box", "bbox": [lo.tolist(), hi.tolist()]})
+    return contacts
+
+
 def main_full():
     """hector with arms (robot_w_arm.urdf, task hector_full): model data for the oracle only -- no kernel tables yet."""
     urdf = os.path.join(REF, "resources/robots/hector_v2/xacro/robot_w_arm.urdf")
@@ -165,8 +185,29 @@ def main_full():
         "L_shoulder_yaw_joint", "L_shoulder_pitch_joint", "L_shoulder_roll_joint", "L_elbow_joint",
         "R_hip_joint", "R_hip_roll_joint", "R_thigh_joint", "R_calf_joint", "R_toe_joint",
         "R_shoulder_yaw_joint", "R_shoulder_pitch_joint", "R_shoulder_roll_joint", "R_elbow_joint"], names
+    name_to_idx = {b["name"]: i for i, b in enumerate(bodies)}
+    contacts = leg_and_base_contacts(name_to_idx)
+    # arm links: bounding box of the collision mesh the URDF names, where the file exists (UpperArmRoll_*.stl does not:
+    # the roll links get no shape; they matter only for terminate_after_contacts_on, hector_w_arm_config.py:35)
+    root = ET.parse(urdf).getroot()
+    for link in root.findall("link"):
+        nm = link.get("name")
+        if nm not in name_to_idx or nm.split("_")[-1] not in ("twist", "shoulder", "roll", "elbow"):
+            continue
+        col = link.find("collision")
+        mesh = col.find("geometry").find("mesh") if col is not None and col.find("geometry") is not None else None
+        if mesh is None:
+            continue
+        path = os.path.normpath(os.path.join(os.path.dirname(urdf), mesh.get("filename")))
+        if not os.path.exists(path):
+            continue
+        o, R = parse_origin(col.find("origin"))
+        assert np.allclose(R, np.eye(3))
+        lo, hi = stl_bbox(path)
+        contacts.append({"body": name_to_idx[nm], "points": box_corners(o + (lo + hi) / 2, hi - lo),
+                         "source": os.path.basename(path) + " axis-aligned bounding box", "bbox": [lo.tolist(), hi.tolist()]})
     model = {"source": "resources/robots/hector_v2/xacro/robot_w_arm.urdf (collapse_fixed_joints, children in alphabetical order)",
-             "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": []}
+             "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": contacts}
     with open(os.path.join(ROOT, "isaac_amd/assets/hector_full_model.json"), "w") as f:
         json.dump(model, f, indent=1)
     for i, b in enumerate(bodies):
@@ -180,24 +221,8 @@ def main():
     total = sum(b["mass"] for b in bodies)
 
     # collision primitives: list of (body index, [points in body frame])
-    def box_corners(center, size):
-        c, h = np.array(center), np.array(size) / 2
-        return [(c + h * np.array([sx, sy, sz])).tolist()
-                for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
-
     name_to_idx = {b["name"]: i for i, b in enumerate(bodies)}
-    contacts = []
-    contacts.append({"body": name_to_idx["base"], "points": box_corners((0, 0, 0), (0.125, 0.19, 0.248)),
-                     "source": "const.xacro:17-19 trunk box (body.stl absent)"})
-    for side, sgn in (("L", 1.0), ("R", -1.0)):
-        contacts.append({"body": name_to_idx[f"{side}_thigh"],
-                         "points": box_corners((0, sgn * 0.0175, -0.09), (0.06, 0.035, 0.18)),
-                         "source": "const.xacro:128-133 thigh box (thigh_combined_*2.stl absent)"})
-        lo, hi = stl_bbox(os.path.join(MESH_DIR, f"foot_{side}2.stl"))
-        ctr, size = (lo + hi) / 2, hi - lo
-        contacts.append({"body": name_to_idx[f"{side}_toe"], "points": box_corners(ctr, size),
-                         "source": f"foot_{side}2.stl axis-aligned bounding box",
-                         "bbox": [lo.tolist(), hi.tolist()]})
+    contacts = leg_and_base_contacts(name_to_idx)
 
     model = {"source": "resources/robots/hector_v2/xacro/robot.urdf (collapse_fixed_joints)",
              "total_mass": total, "bodies": bodies, "contacts": contacts}
