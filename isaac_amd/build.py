@@ -25,6 +25,18 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Serialised across processes with a file lock: under `torch.distributed.run` every rank calls this (bench.py), and
+    ranks that found the library stale at the same time must not compile into the same files concurrently."""
+    import fcntl
+    with open(OUT + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
