@@ -410,3 +410,87 @@ class HectorCfgPPO(LeggedRobotCfgPPO):
         load_run = -1
         checkpoint = -1
         resume_path = None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# hector_full (reference humanoid/envs/custom/hector_w_arm_config.py): the same biped with its two 4-joint arms freed,
+# 18 DoF.  Written as what differs from HectorCfg; every value is pinned by tests/golden/configs.json.  The learner
+# runs this task's network shapes (tests/test_gpu_ppo_shapes.py) and the oracle reproduces its env glue
+# (tests/golden/env_rollout_g.npz); its env-step kernel is not built yet, so the task is not registered.
+class HectorFullCfg(HectorCfg):
+    class env(HectorCfg.env):
+        num_single_obs = 65
+        num_observations = int(HectorCfg.env.frame_stack * num_single_obs)
+        single_num_privileged_obs = 94
+        num_privileged_obs = int(HectorCfg.env.c_frame_stack * single_num_privileged_obs)
+        num_actions = 18
+
+    class asset(HectorCfg.asset):
+        file = '{LEGGED_GYM_ROOT_DIR}/resources/robots/hector_v2/xacro/robot_w_arm.urdf'
+        terminate_after_contacts_on = ['base', 'thigh', 'shoulder', 'twist', 'roll']
+
+    class terrain(HectorCfg.terrain):
+        mesh_type = 'plane'
+        terrain_proportions = [0.2, 0.2, 0.4, 0.1, 0.1, 0, 0]
+
+    class init_state(HectorCfg.init_state):
+        default_joint_angles = dict(HectorCfg.init_state.default_joint_angles, **{
+            'L_shoulder_yaw_joint': 0., 'L_shoulder_pitch_joint': 0., 'L_shoulder_roll_joint': 0., 'L_elbow_joint': -0.785,
+            'R_shoulder_yaw_joint': 0., 'R_shoulder_pitch_joint': 0., 'R_shoulder_roll_joint': 0., 'R_elbow_joint': -0.785})
+
+    class control(HectorCfg.control):
+        stiffness = {'hip_joint': 80.0, 'hip_roll': 80.0, 'thigh': 80.0, 'calf': 80.0, 'toe': 60.0,
+                     'shoulder_yaw': 30.0, 'shoulder_pitch': 30.0, 'shoulder_roll': 30.0, 'elbow': 30.0}
+        damping = {'hip_joint': 5.0, 'hip_roll': 5.0, 'thigh': 5.0, 'calf': 5.0, 'toe': 3.0,
+                   'shoulder_yaw': 3.0, 'shoulder_pitch': 3.0, 'shoulder_roll': 3.0, 'elbow': 3.0}
+
+    class sim(HectorCfg.sim):
+        class physx(HectorCfg.sim.physx):
+            num_velocity_iterations = 1
+
+    class domain_rand(HectorCfg.domain_rand):
+        friction_range = [0.1, 2.0]
+        added_mass_range = [-1., 4.]
+        max_push_vel_xy = 0.5
+
+    class commands(HectorCfg.commands):
+        class ranges(HectorCfg.commands.ranges):
+            lin_vel_x = [-0.6, 0.8]
+
+    class rewards(HectorCfg.rewards):
+        min_dist = 0.2
+        max_contact_force = 200
+
+        class scales(HectorCfg.rewards.scales):
+            feet_clearance = 1.2
+            feet_contact_number = 1.5
+            feet_air_time = 1.5
+            feet_contact_forces = -0.02
+            tracking_lin_vel = 1.2
+            tracking_ang_vel = 1.1
+            vel_mismatch_exp = 0.5
+            low_speed = 0.2
+            track_vel_hard = 0.5
+            default_joint_pos = 1.2
+            orientation = 1.
+            base_height = 0.8
+            base_acc = 0.22
+            action_smoothness = -0.002
+            dof_vel = -1e-3
+            collision = -1.
+
+
+class HectorFullCfgPPO(HectorCfgPPO):
+    class policy(HectorCfgPPO.policy):
+        actor_hidden_dims = [768, 512, 128]
+        critic_hidden_dims = [768, 768, 768]
+
+    class algorithm(HectorCfgPPO.algorithm):
+        entropy_coef = 0.01
+        num_learning_epochs = 5
+        learning_rate = 1.e-3
+        gamma = 0.99
+        lam = 0.95
+
+    class runner(HectorCfgPPO.runner):
+        experiment_name = 'hector_arm'

@@ -39,3 +39,18 @@ def test_reward_order_is_alphabetical():
     scales = class_to_dict(HectorCfg().rewards.scales)
     active = [k for k, v in scales.items() if v != 0]
     assert active == sorted(active) and len(active) == 18
+
+
+def test_hector_full_cfgs_match_reference():
+    """The sibling task's configs (hector_w_arm_config.py), written here as overrides of HectorCfg / HectorCfgPPO."""
+    from isaac_amd.envs.configs import HectorFullCfg, HectorFullCfgPPO
+    ref = json.load(open(GOLD))
+    assert _diff(json.loads(json.dumps(class_to_dict(HectorFullCfg()))), ref["HectorFullCfg"]) == []
+    assert _diff(json.loads(json.dumps(class_to_dict(HectorFullCfgPPO()))), ref["HectorFullCfgPPO"]) == []
+    # and the oracle's task table carries the same numbers
+    from oracle.env import HECTOR_FULL
+    sc = {k: v for k, v in class_to_dict(HectorFullCfg().rewards.scales).items() if v != 0}
+    assert HECTOR_FULL.reward_scale == sc
+    assert HECTOR_FULL.opts["cmd_ranges"]["lin_vel_x"] == tuple(HectorFullCfg.commands.ranges.lin_vel_x)
+    assert HECTOR_FULL.opts["max_push_vel_xy"] == HectorFullCfg.domain_rand.max_push_vel_xy
+    assert HECTOR_FULL.max_contact_force == HectorFullCfg.rewards.max_contact_force and HECTOR_FULL.min_dist == HectorFullCfg.rewards.min_dist
