@@ -102,7 +102,8 @@ int hx_ppo_get_lr(hx_ppo* p, float* lr_h);
 int hx_ppo_set_lr(hx_ppo* p, float lr);
 int hx_ppo_inference(hx_ppo* p, const float* obs, int rows, float* actions_out);
 /* HIP-event timing of the GEMM kernels on the learner's stream (events recorded on that stream around every
- * launch): which=1 starts/clears, which=0 stops and returns, per kernel symbol
+ * launch): which=1 starts/clears for all five kernel symbols, which = 0x100 | mask only for the symbols whose bit is
+ * set in mask (the event pairs cost ~1 us of GPU time per bracketed launch), which=0 stops and returns, per kernel symbol
  * {fwd 128x128, fwd 64x128, dgrad 128x128, dgrad 64x128, wgrad split-K}: {milliseconds, launches, flops} */
 int hx_ppo_prof(hx_ppo* p, int which, double* out_h /*[15]*/, void* reserved);
 /* unit-test hook: one GEMM of the given mode (0/3 fwd bias+ELU 128/64-row tile, 1/4 dgrad * elu', 2 wgrad single

@@ -355,15 +355,21 @@ class PPO:
     def load_optimizer_state(self, m, v, step):
         capi.check(self._L.hx_ppo_set_opt_state_h(self._h, capi.ptr(capi.farr(m)), capi.ptr(capi.farr(v)), int(step)), "set_opt_state")
 
-    def prof_begin(self):
-        capi.check(self._L.hx_ppo_prof(self._h, 1, None, None), "prof")
+    PROF_KERNELS = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
+                    "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)", "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
+                    "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"]
+
+    def prof_begin(self, only=None):
+        """Bracket GEMM launches with HIP events on the learner's stream.  only: a kernel name of PROF_KERNELS to bracket
+        just that symbol (each event pair costs about a microsecond of GPU time, 1.5 % of an iteration when every GEMM
+        launch carries one)."""
+        which = 1 if only is None else (0x100 | (1 << self.PROF_KERNELS.index(only)))
+        capi.check(self._L.hx_ppo_prof(self._h, which, None, None), "prof")
 
     def prof_end(self):
         out = np.zeros(15, np.float64)
         capi.check(self._L.hx_ppo_prof(self._h, 0, capi.ptr(out), None), "prof")
-        names = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
-                 "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)", "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
-                 "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"]
+        names = self.PROF_KERNELS
         ks = [dict(name=names[k], ms=float(out[3 * k]), launches=int(out[3 * k + 1]), flops=float(out[3 * k + 2]))
               for k in range(5) if out[3 * k + 1] > 0]
         for k in ks:

@@ -778,6 +778,7 @@ struct hx_ppo {
   double* sumsq; SchedState* sched;
   int64_t adam_t;
   int mb_done, mb_total;
+  int prof_mask;                 // kernel ids (launch_gemm kid 0..4) whose launches hx_ppo_prof brackets with HIP events
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
@@ -801,10 +802,11 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL = fals
   const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
   // kernel id for the profiler: 0 fwd128, 1 fwd64, 2 dgrad128, 3 dgrad64, 4 wgrad
   constexpr int kid = (EPI == EPI_SLAB) ? 4 : ((EPI == EPI_ELU_GRAD) ? (BM == 128 ? 2 : 3) : (BM == 128 ? 0 : 1));
-  if (s && s->prof) {
+  const bool timed = s && s->prof && ((s->prof_mask >> kid) & 1);
+  if (timed) {
     while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
   }
-  if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
+  if (timed && s->ev_used + 2 <= s->ev.size()) {
     (void)hipEventRecord(s->ev[s->ev_used], st);
     hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(blocks), dim3(256), 0, st, g);
     (void)hipEventRecord(s->ev[s->ev_used + 1], st);
@@ -823,10 +825,11 @@ template <int EPI> static void launch_gemm_bf16(hx_ppo* s, GemmArgs& g, hipStrea
   g.tiles_n = (g.N + 127) / 128;
   const int blocks = g.tiles_m * g.tiles_n;
   constexpr int kid = (EPI == EPI_ELU_GRAD) ? 2 : 0;
-  if (s && s->prof) {
+  const bool timed = s && s->prof && ((s->prof_mask >> kid) & 1);
+  if (timed) {
     while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
   }
-  if (s && s->prof && s->ev_used + 2 <= s->ev.size()) {
+  if (timed && s->ev_used + 2 <= s->ev.size()) {
     (void)hipEventRecord(s->ev[s->ev_used], st);
     hipLaunchKernelGGL((hx_gemm_bf16_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
     (void)hipEventRecord(s->ev[s->ev_used + 1], st);
@@ -924,8 +927,9 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   if (s->bf16) {
     g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
     const int blocks = g.tiles_m * g.tiles_n * g.splits;
-    if (s->prof) { while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); } }
-    const bool timed = s->prof && s->ev_used + 2 <= s->ev.size();
+    const bool want = s->prof && ((s->prof_mask >> 4) & 1);
+    if (want) { while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); } }
+    const bool timed = want && s->ev_used + 2 <= s->ev.size();
     if (timed) (void)hipEventRecord(s->ev[s->ev_used], st);
     hipLaunchKernelGGL(hx_wgrad_bf16_kernel, dim3(blocks), dim3(256), 0, st, g);
     if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], st); s->ev_kid[s->ev_used] = 4; s->ev_used += 2; s->prof_flops[4] += 2.0 * g.M * g.N * g.K; s->prof_launches[4] += 1; }
@@ -1697,7 +1701,8 @@ extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* ou
 }
 
 extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
-  if (which == 1) {
+  if (which == 1 || which >= 0x100) {
+    s->prof_mask = (which == 1) ? 31 : (which & 31);      // which = 0x100 | mask: bracket only the kernel ids in mask
     s->ev_used = 0; s->prof = true;
     for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
     return 0;
