@@ -116,19 +116,45 @@ struct DynParams {
 };
 
 #define HX_LEG_NJ 5
-// joint axes along a leg (same for both legs): hip yaw z, hip roll x, thigh / calf / toe pitch y
-template <int L> struct LegAxis { static constexpr int value = (L == 0) ? 2 : (L == 1) ? 0 : 1; };
-#define HX_LDS_CONST_FLOATS (2 * HX_LEGC_STRIDE + 24)
+#define HX_ARM_NJ 4
+// Kinematic chains hanging off the base on one body side.  Joint frames are axis aligned (no rpy in the URDF joint origins).
+//   leg: hip yaw z, hip roll x, thigh / calf / toe pitch y; collision shapes on the thigh (slot 0) and the toe (slot 1)
+//   arm (hector_full only): shoulder yaw z, pitch y, roll x, elbow pitch y; shapes on twist (2), shoulder (3), elbow (4)
+struct LegChain {
+  static constexpr int NJ = HX_LEG_NJ, B0 = 0, NS = 2;
+  static constexpr int axis(int L) { return (L == 0) ? 2 : (L == 1) ? 0 : 1; }
+  static constexpr int slot(int L) { return (L == 2) ? 0 : (L == 4) ? 1 : -1; }     // collision-shape slot of local body L
+  static constexpr int slot0 = 0;
+};
+struct ArmChain {
+  static constexpr int NJ = HX_ARM_NJ, B0 = HX_LEG_NJ, NS = 3;
+  static constexpr int axis(int L) { return (L == 0) ? 2 : (L == 1) ? 1 : (L == 2) ? 0 : 1; }
+  static constexpr int slot(int L) { return (L == 0) ? 2 : (L == 1) ? 3 : (L == 3) ? 4 : -1; }
+  static constexpr int slot0 = 2;
+};
+// the two robots of the family: joints per lane (= per body side) and where their constants live
+struct ModelHector {
+  static constexpr int NL = HX_LEG_NJ, NB = HX_LEG_NJ, NSHAPE = 2; static constexpr bool ARMS = false;
+  static constexpr int STRIDE = HX_LEGC_STRIDE;
+  HXD static const float* side_table() { return HXM_LEGC; }
+  HXD static const float* base_pts() { return HXM_CONTACT_PTS; }
+  HXD static float io(int k) { return HXM_IO[k]; }
+  HXD static float h(int k) { return HXM_H[k]; }
+  HXD static float mass0() { return HXM_MASS[0]; }
+};
+template <int L> struct LegAxis { static constexpr int value = LegChain::axis(L); };
+#define HX_LDS_CONST_FLOATS_OF(M) (2 * M::STRIDE + 24)
+#define HX_LDS_CONST_FLOATS HX_LDS_CONST_FLOATS_OF(ModelHector)
 
-// stage the per-leg table and the base collision corners into LDS (call with all threads, then __syncthreads)
-HXD void dyn_stage_constants(float* lds, int tid, int nthreads) {
-  for (int i = tid; i < 2 * HX_LEGC_STRIDE; i += nthreads) lds[i] = HXM_LEGC[i];
-  for (int i = tid; i < 24; i += nthreads) lds[2 * HX_LEGC_STRIDE + i] = HXM_CONTACT_PTS[i];
+// stage the per-side table and the base collision corners into LDS (call with all threads, then __syncthreads)
+template <class M> HXD void dyn_stage_constants(float* lds, int tid, int nthreads) {
+  for (int i = tid; i < 2 * M::STRIDE; i += nthreads) lds[i] = M::side_table()[i];
+  for (int i = tid; i < 24; i += nthreads) lds[2 * M::STRIDE + i] = M::base_pts()[i];
 }
 
-// this lane's view of the constants
-struct LegConst {
-  const float* t;      // LDS, leg table of this lane
+// this lane's view of the constants: NB bodies of 16 floats, then the collision corner blocks (24 floats per shape slot)
+template <class M> struct SideConst {
+  const float* t;      // LDS, side table of this lane
   const float* basept; // LDS, 8 base corners
   HXD V3 off(int b) const { return mk(t[b * 16], t[b * 16 + 1], t[b * 16 + 2]); }
   HXD V3 h(int b) const { return mk(t[b * 16 + 3], t[b * 16 + 4], t[b * 16 + 5]); }
@@ -146,9 +172,9 @@ struct LegConst {
     r.M = m3zero(); r.M.m[0] = m; r.M.m[4] = m; r.M.m[8] = m;
     return r;
   }
-  HXD const float* thigh_pts() const { return t + 80; }
-  HXD const float* toe_pts() const { return t + 104; }
+  HXD const float* pts(int slot) const { return t + M::NB * 16 + slot * 24; }
 };
+typedef SideConst<ModelHector> LegConst;
 
 // v x* (I v) for a rigid body with spatial inertia `in` (H = skew(h), M = m 1)
 HXD SV rb_bias(const SI& in, V3 hh, float m, SV v) {
@@ -158,14 +184,14 @@ HXD SV rb_bias(const SI& in, V3 hh, float m, SV v) {
   return p;
 }
 
-HXD SI base_inertia(float s) {
+template <class M> HXD SI base_inertia(float s) {
   SI r;
-  const float xx = HXM_IO[0], yy = HXM_IO[1], zz = HXM_IO[2], xy = HXM_IO[3], xz = HXM_IO[4], yz = HXM_IO[5];
+  const float xx = M::io(0), yy = M::io(1), zz = M::io(2), xy = M::io(3), xz = M::io(4), yz = M::io(5);
   r.A.m[0] = s * xx; r.A.m[1] = s * xy; r.A.m[2] = s * xz; r.A.m[3] = s * xy; r.A.m[4] = s * yy; r.A.m[5] = s * yz;
   r.A.m[6] = s * xz; r.A.m[7] = s * yz; r.A.m[8] = s * zz;
-  const V3 hh = s * mk(HXM_H[0], HXM_H[1], HXM_H[2]);
+  const V3 hh = s * mk(M::h(0), M::h(1), M::h(2));
   r.H.m[0] = 0.f; r.H.m[1] = -hh.z; r.H.m[2] = hh.y; r.H.m[3] = hh.z; r.H.m[4] = 0.f; r.H.m[5] = -hh.x; r.H.m[6] = -hh.y; r.H.m[7] = hh.x; r.H.m[8] = 0.f;
-  const float m = s * HXM_MASS[0];
+  const float m = s * M::mass0();
   r.M = m3zero(); r.M.m[0] = m; r.M.m[4] = m; r.M.m[8] = m;
   return r;
 }
@@ -282,11 +308,12 @@ HXD void solve6(float (&a)[6][6], float (&b)[6]) {
 HXD float xchg(float x) { return __shfl_xor(x, 1); }     // the other leg's lane of the same robot
 HXD V3 xchg(V3 a) { return mk(xchg(a.x), xchg(a.y), xchg(a.z)); }
 
-struct DynState {
+template <class M> struct DynStateT {
   V3 pos; float quat[4];   // base: xyzw, body->world (identical on both lanes of a robot)
   V3 linvel, angvel;       // base, world frame
-  float q[HX_LEG_NJ], qd[HX_LEG_NJ];   // this lane's leg
+  float q[M::NL], qd[M::NL];   // this lane's side: leg joints, then (hector_full) arm joints
 };
+typedef DynStateT<ModelHector> DynState;
 
 HXD M3 quat_to_mat(const float* q) {
   const float x = q[0], y = q[1], z = q[2], w = q[3];
@@ -297,74 +324,80 @@ HXD M3 quat_to_mat(const float* q) {
   return r;
 }
 
-struct LegForces { V3 base, thigh, toe; };   // world frame; base = whole-base total (same on both lanes)
+// world-frame net contact forces: base = whole-base total (same on both lanes), shape[slot] = this lane's shapes
+// (slot 0 thigh, 1 toe, and with arms 2 twist, 3 shoulder, 4 elbow)
+template <class M> struct SideForcesT { V3 base; V3 shape[M::NSHAPE]; };
+typedef SideForcesT<ModelHector> LegForces;
 
-// One 1 ms substep of this lane's half of the robot.  target/kp/kd/tau_lim: this leg's 5 joints.
-HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg, const float* target, const float* kp,
-                     const float* kd, const float* tau_lim, float mass_scale, float* tau_out, bool want_forces, LegForces& F) {
-  SV v[HX_LEG_NJ + 1];       // index 0 = base, 1..5 = leg bodies
-  float cs_c[HX_LEG_NJ + 1], cs_s[HX_LEG_NJ + 1];
-  M3 R_thigh, R_toe;           // body -> world of the two leg bodies that carry collision shapes
-  V3 p_thigh, p_toe;
-  const M3 R0 = quat_to_mat(S.quat);
-  // ---- pass 1: kinematics down the leg
-  const V3 nb_base = row(R0, 2);
-  v[0].w = mulT(R0, S.angvel);
-  v[0].v = mulT(R0, S.linvel);
-  {
-    M3 Rc = R0; V3 pc = S.pos;
-    static_for<HX_LEG_NJ>([&](auto ic) {
-      constexpr int L = decltype(ic)::value;      // local body 0..4, state index L+1
-      constexpr int K = LegAxis<L>::value;
-      float s, c;
-      joint_sincos(S.q[L], &s, &c);
-      cs_c[L + 1] = c; cs_s[L + 1] = s;
-      const V3 r = C.off(L);
-      const V3 t = v[L].v + cross(v[L].w, r);
-      v[L + 1].w = rotT<K>(c, s, v[L].w);
-      v[L + 1].v = rotT<K>(c, s, t);
-      if (K == 0) v[L + 1].w.x += S.qd[L];
-      if (K == 1) v[L + 1].w.y += S.qd[L];
-      if (K == 2) v[L + 1].w.z += S.qd[L];
-      pc = pc + mul(Rc, r);
-      for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
-      if (L == 2) { R_thigh = Rc; p_thigh = pc; }
-      if (L == 4) { R_toe = Rc; p_toe = pc; }
-    });
-  }
+// per-chain working set of one substep
+template <class CH> struct ChainWork {
+  SV v[CH::NJ + 1];                            // [0] = base, [L+1] = local body L
+  float cs_c[CH::NJ + 1], cs_s[CH::NJ + 1];
+  SV U[CH::NJ + 1]; float Dinv[CH::NJ + 1], uu[CH::NJ + 1];
+  M3 Rs[CH::NS]; V3 ps[CH::NS];                // body -> world rotation / origin of the bodies that carry collision shapes
+  SV a[CH::NJ + 1];                            // accelerations relative to the gravity field
+};
 
-  // ---- pass 2: articulated inertias, toe -> hip
-  SV U[HX_LEG_NJ + 1];
-  float Dinv[HX_LEG_NJ + 1], uu[HX_LEG_NJ + 1];
-  SI accI; SV accP;            // what this chain hands to its parent
+// ---- pass 1: kinematics down the chain
+template <class CH, class M>
+HXD void chain_pass1(ChainWork<CH>& W, const DynStateT<M>& S, const SideConst<M>& C, SV v0, const M3& R0) {
+  W.v[0] = v0;
+  M3 Rc = R0; V3 pc = S.pos;
+  static_for<CH::NJ>([&](auto ic) {
+    constexpr int L = decltype(ic)::value;      // local body 0.., state index L+1
+    constexpr int K = CH::axis(L);
+    constexpr int B = CH::B0 + L;               // body / joint index on this side
+    float s, c;
+    joint_sincos(S.q[B], &s, &c);
+    W.cs_c[L + 1] = c; W.cs_s[L + 1] = s;
+    const V3 r = C.off(B);
+    const V3 t = W.v[L].v + cross(W.v[L].w, r);
+    W.v[L + 1].w = rotT<K>(c, s, W.v[L].w);
+    W.v[L + 1].v = rotT<K>(c, s, t);
+    if (K == 0) W.v[L + 1].w.x += S.qd[B];
+    if (K == 1) W.v[L + 1].w.y += S.qd[B];
+    if (K == 2) W.v[L + 1].w.z += S.qd[B];
+    pc = pc + mul(Rc, r);
+    for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
+    if constexpr (CH::slot(L) >= 0) { W.Rs[CH::slot(L) - CH::slot0] = Rc; W.ps[CH::slot(L) - CH::slot0] = pc; }
+  });
+}
+
+// ---- pass 2: articulated inertias, leaf -> root of the chain; hands (accI, accP) to the base.
+// target/kp/kd/tau_lim/tau_out are indexed by the side-local joint index B.
+template <class CH, class M>
+HXD void chain_pass2(ChainWork<CH>& W, const DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const float* target,
+                     const float* kp, const float* kd, const float* tau_lim, float* tau_out, SI& accI, SV& accP) {
   accI.A = m3zero(); accI.H = m3zero(); accI.M = m3zero();
   accP.w = mk(0, 0, 0); accP.v = mk(0, 0, 0);
-  static_for<HX_LEG_NJ>([&](auto ic) {
-    constexpr int L = HX_LEG_NJ - 1 - decltype(ic)::value;     // 4..0
-    constexpr int K = LegAxis<L>::value;
-    SI IA = C.inertia(L);
-    SV pA = rb_bias(IA, C.h(L), C.mass(L), v[L + 1]);
-    if (L < HX_LEG_NJ - 1) {
+  static_for<CH::NJ>([&](auto ic) {
+    constexpr int L = CH::NJ - 1 - decltype(ic)::value;     // last .. 0
+    constexpr int K = CH::axis(L);
+    constexpr int B = CH::B0 + L;
+    SI IA = C.inertia(B);
+    SV pA = rb_bias(IA, C.h(B), C.mass(B), W.v[L + 1]);
+    if (L < CH::NJ - 1) {
       IA.A = IA.A + accI.A; IA.H = IA.H + accI.H; IA.M = IA.M + accI.M;
       pA = pA + accP;
     }
-    if (L == 2 || L == 4) {
-      const M3& Rb = (L == 2) ? R_thigh : R_toe;
+    if constexpr (CH::slot(L) >= 0) {
+      constexpr int SL = CH::slot(L);
+      const M3& Rb = W.Rs[SL - CH::slot0];
       SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
-      SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-      contact_points(P, (L == 2) ? C.thigh_pts() : C.toe_pts(), 8, v[L + 1], Rb, (L == 2) ? p_thigh : p_toe, f0, B, nullptr);
-      IA.A = IA.A + B.A; IA.H = IA.H + B.H; IA.M = IA.M + B.M;
+      SI Bc; Bc.A = m3zero(); Bc.H = m3zero(); Bc.M = m3zero();
+      contact_points(P, C.pts(SL), 8, W.v[L + 1], Rb, W.ps[SL - CH::slot0], f0, Bc, nullptr);
+      IA.A = IA.A + Bc.A; IA.H = IA.H + Bc.H; IA.M = IA.M + Bc.M;
       SV g; g.w = mk(0, 0, 0); g.v = P.gz * row(Rb, 2);
-      pA = pA - f0 + mulSI(B, g);
+      pA = pA - f0 + mulSI(Bc, g);
     }
     // joint-space terms: PD torque (reference legged_robot.py:339-355) + soft limits, linearly implicit
-    const float q = S.q[L], qd = S.qd[L];
-    const float raw = kp[L] * (target[L] - q) - kd[L] * qd;
-    const float tau = fminf(fmaxf(raw, -tau_lim[L]), tau_lim[L]);
-    tau_out[L] = tau;
-    float beta = (raw == tau) ? P.dt * (kd[L] + P.dt * kp[L]) : 0.f;
+    const float q = S.q[B], qd = S.qd[B];
+    const float raw = kp[B] * (target[B] - q) - kd[B] * qd;
+    const float tau = fminf(fmaxf(raw, -tau_lim[B]), tau_lim[B]);
+    tau_out[B] = tau;
+    float beta = (raw == tau) ? P.dt * (kd[B] + P.dt * kp[B]) : 0.f;
     const float c_lim = P.lim_d + P.lim_k * P.dt;
-    const float lo_pen = C.qlo(L) - q, hi_pen = q - C.qhi(L);
+    const float lo_pen = C.qlo(B) - q, hi_pen = q - C.qhi(B);
     const float t_lo = P.lim_k * lo_pen - c_lim * qd;
     const float t_hi = -P.lim_k * hi_pen - c_lim * qd;
     const bool act_lo = (lo_pen > 0.f) && (t_lo > 0.f);
@@ -376,7 +409,7 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
     const float D = get(Ui.w, K) + beta;
     const float di = 1.0f / D;
     const float ui = tau_j - get(pA.w, K);
-    U[L + 1] = Ui; Dinv[L + 1] = di; uu[L + 1] = ui;
+    W.U[L + 1] = Ui; W.Dinv[L + 1] = di; W.uu[L + 1] = ui;
     // Ia = IA - U U^T / D ; pa = pA + Ia c + U ui / D
     addouter(IA.A, -di, Ui.w, Ui.w);
     addouter(IA.H, -di, Ui.w, Ui.v);
@@ -384,13 +417,13 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
     SV cI;   // c_i = v_i x (S qd)
     {
       const V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
-      cI.w = cross(v[L + 1].w, w2); cI.v = cross(v[L + 1].v, w2);
+      cI.w = cross(W.v[L + 1].w, w2); cI.v = cross(W.v[L + 1].v, w2);
     }
     SV pa = pA + mulSI(IA, cI);
     pa.w = pa.w + (ui * di) * Ui.w; pa.v = pa.v + (ui * di) * Ui.v;
     // transform to the parent frame:  X^T Ia X,  X^T pa
-    const float c = cs_c[L + 1], s = cs_s[L + 1];
-    const V3 r = C.off(L);
+    const float c = W.cs_c[L + 1], s = W.cs_s[L + 1];
+    const V3 r = C.off(B);
     const M3 A1 = rotM<K>(c, s, IA.A), H1 = rotM<K>(c, s, IA.H), M1 = rotM<K>(c, s, IA.M);
     const M3 G = crossM(r, M1);                       // rx M'
     const M3 T1 = crossM(r, transpose(H1));           // rx H'^T
@@ -401,18 +434,79 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
     accP.v = rot<K>(c, s, pa.v);
     accP.w = rot<K>(c, s, pa.w) + cross(r, accP.v);
   });
-  // ---- base: each lane adds HALF of the base corners to its chain's contribution, then the two lanes of the
+}
+
+// ---- pass 3: accelerations, root -> leaf (W.a[0] = base acceleration)
+template <class CH, class M>
+HXD void chain_pass3(ChainWork<CH>& W, const DynStateT<M>& S, const SideConst<M>& C, float* qdd) {
+  static_for<CH::NJ>([&](auto ic) {
+    constexpr int L = decltype(ic)::value;
+    constexpr int K = CH::axis(L);
+    constexpr int B = CH::B0 + L;
+    const float c = W.cs_c[L + 1], s = W.cs_s[L + 1];
+    const V3 r = C.off(B);
+    const float qd = S.qd[B];
+    SV ai;
+    ai.w = rotT<K>(c, s, W.a[L].w);
+    ai.v = rotT<K>(c, s, W.a[L].v + cross(W.a[L].w, r));
+    const V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
+    ai.w = ai.w + cross(W.v[L + 1].w, w2);
+    ai.v = ai.v + cross(W.v[L + 1].v, w2);
+    const float dd = W.Dinv[L + 1] * (W.uu[L + 1] - (dot(W.U[L + 1].w, ai.w) + dot(W.U[L + 1].v, ai.v)));
+    qdd[B] = dd;
+    if (K == 0) ai.w.x += dd;
+    if (K == 1) ai.w.y += dd;
+    if (K == 2) ai.w.z += dd;
+    W.a[L + 1] = ai;
+  });
+}
+
+// implicit-consistent net contact forces of the chain's shapes (world frame), last substep of an env step only
+template <class CH, class M>
+HXD void chain_forces(const ChainWork<CH>& W, const DynParams& P, const SideConst<M>& C, V3* shape_force) {
+  static_for<CH::NJ>([&](auto ic) {
+    constexpr int L = decltype(ic)::value;
+    if constexpr (CH::slot(L) >= 0) {
+      constexpr int SL = CH::slot(L);
+      const M3& Rb = W.Rs[SL - CH::slot0];
+      SV dmy; SI dmyB;
+      SV at = W.a[L + 1]; at.v = at.v + P.gz * row(Rb, 2);     // true spatial acceleration
+      shape_force[SL] = mul(Rb, contact_points(P, C.pts(SL), 8, W.v[L + 1], Rb, W.ps[SL - CH::slot0], dmy, dmyB, &at));
+    }
+  });
+}
+
+// One 1 ms substep of this lane's side of the robot.  target/kp/kd/tau_lim/tau_out: this side's joints (leg, then arm).
+template <class M>
+HXD void dyn_substep(DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, int leg, const float* target, const float* kp,
+                     const float* kd, const float* tau_lim, float mass_scale, float* tau_out, bool want_forces, SideForcesT<M>& F) {
+  ChainWork<LegChain> WL;
+  ChainWork<ArmChain> WA;                      // untouched (and removed by the compiler) without arms
+  const M3 R0 = quat_to_mat(S.quat);
+  const V3 nb_base = row(R0, 2);
+  SV v0; v0.w = mulT(R0, S.angvel); v0.v = mulT(R0, S.linvel);
+  chain_pass1<LegChain, M>(WL, S, C, v0, R0);
+  if constexpr (M::ARMS) chain_pass1<ArmChain, M>(WA, S, C, v0, R0);
+  SI accI; SV accP;
+  chain_pass2<LegChain, M>(WL, S, P, C, target, kp, kd, tau_lim, tau_out, accI, accP);
+  if constexpr (M::ARMS) {
+    SI aI; SV aP;
+    chain_pass2<ArmChain, M>(WA, S, P, C, target, kp, kd, tau_lim, tau_out, aI, aP);
+    accI.A = accI.A + aI.A; accI.H = accI.H + aI.H; accI.M = accI.M + aI.M;
+    accP = accP + aP;
+  }
+  // ---- base: each lane adds HALF of the base corners to its side's contribution, then the two lanes of the
   //      robot exchange and sum (a + b == b + a bitwise, so both lanes hold the identical base system)
   const SV g0 = [&] { SV g; g.w = mk(0, 0, 0); g.v = P.gz * nb_base; return g; }();
   {
     SV f0; f0.w = mk(0, 0, 0); f0.v = mk(0, 0, 0);
     SI B; B.A = m3zero(); B.H = m3zero(); B.M = m3zero();
-    contact_points(P, C.basept + 12 * leg, 4, v[0], R0, S.pos, f0, B, nullptr);
+    contact_points(P, C.basept + 12 * leg, 4, v0, R0, S.pos, f0, B, nullptr);
     accI.A = accI.A + B.A; accI.H = accI.H + B.H; accI.M = accI.M + B.M;
     accP = accP - f0 + mulSI(B, g0);
   }
-  SI baseI = base_inertia(mass_scale);
-  SV baseP = rb_bias(baseI, mass_scale * mk(HXM_H[0], HXM_H[1], HXM_H[2]), mass_scale * HXM_MASS[0], v[0]);
+  SI baseI = base_inertia<M>(mass_scale);
+  SV baseP = rb_bias(baseI, mass_scale * mk(M::h(0), M::h(1), M::h(2)), mass_scale * M::mass0(), v0);
   for (int i = 0; i < 9; ++i) {
     baseI.A.m[i] += accI.A.m[i] + xchg(accI.A.m[i]);
     baseI.H.m[i] += accI.H.m[i] + xchg(accI.H.m[i]);
@@ -420,7 +514,7 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
   }
   baseP.w = baseP.w + (accP.w + xchg(accP.w));
   baseP.v = baseP.v + (accP.v + xchg(accP.v));
-  SV a[HX_LEG_NJ + 1];       // accelerations relative to the gravity field
+  SV a0;
   {
     float Am[6][6], bm[6];
     for (int i = 0; i < 3; ++i)
@@ -433,52 +527,31 @@ HXD void dyn_substep(DynState& S, const DynParams& P, const LegConst& C, int leg
     bm[0] = -baseP.w.x; bm[1] = -baseP.w.y; bm[2] = -baseP.w.z;
     bm[3] = -baseP.v.x; bm[4] = -baseP.v.y; bm[5] = -baseP.v.z;
     solve6(Am, bm);
-    a[0].w = mk(bm[0], bm[1], bm[2]);
-    a[0].v = mk(bm[3], bm[4], bm[5]);
+    a0.w = mk(bm[0], bm[1], bm[2]);
+    a0.v = mk(bm[3], bm[4], bm[5]);
   }
-  // ---- pass 3: accelerations, hip -> toe
-  float qdd[HX_LEG_NJ];
-  static_for<HX_LEG_NJ>([&](auto ic) {
-    constexpr int L = decltype(ic)::value;
-    constexpr int K = LegAxis<L>::value;
-    const float c = cs_c[L + 1], s = cs_s[L + 1];
-    const V3 r = C.off(L);
-    const float qd = S.qd[L];
-    SV ai;
-    ai.w = rotT<K>(c, s, a[L].w);
-    ai.v = rotT<K>(c, s, a[L].v + cross(a[L].w, r));
-    const V3 w2 = mk(K == 0 ? qd : 0.f, K == 1 ? qd : 0.f, K == 2 ? qd : 0.f);
-    ai.w = ai.w + cross(v[L + 1].w, w2);
-    ai.v = ai.v + cross(v[L + 1].v, w2);
-    const float dd = Dinv[L + 1] * (uu[L + 1] - (dot(U[L + 1].w, ai.w) + dot(U[L + 1].v, ai.v)));
-    qdd[L] = dd;
-    if (K == 0) ai.w.x += dd;
-    if (K == 1) ai.w.y += dd;
-    if (K == 2) ai.w.z += dd;
-    a[L + 1] = ai;
-  });
-  // ---- net contact forces (implicit-consistent), last substep of an env step only; rotations rebuilt here
+  float qdd[M::NL];
+  WL.a[0] = a0;
+  chain_pass3<LegChain, M>(WL, S, C, qdd);
+  if constexpr (M::ARMS) { WA.a[0] = a0; chain_pass3<ArmChain, M>(WA, S, C, qdd); }
+  // ---- net contact forces (implicit-consistent), last substep of an env step only
   if (want_forces) {
     SV dmy; SI dmyB;
     {
-      SV at = a[0]; at.v = at.v + g0.v;
-      const V3 part = contact_points(P, C.basept + 12 * leg, 4, v[0], R0, S.pos, dmy, dmyB, &at);
+      SV at = a0; at.v = at.v + g0.v;
+      const V3 part = contact_points(P, C.basept + 12 * leg, 4, v0, R0, S.pos, dmy, dmyB, &at);
       F.base = mul(R0, part + xchg(part));
     }
-    {
-      SV at = a[3]; at.v = at.v + P.gz * row(R_thigh, 2);     // true spatial acceleration
-      F.thigh = mul(R_thigh, contact_points(P, C.thigh_pts(), 8, v[3], R_thigh, p_thigh, dmy, dmyB, &at));
-      at = a[5]; at.v = at.v + P.gz * row(R_toe, 2);
-      F.toe = mul(R_toe, contact_points(P, C.toe_pts(), 8, v[5], R_toe, p_toe, dmy, dmyB, &at));
-    }
+    chain_forces<LegChain, M>(WL, P, C, F.shape);
+    if constexpr (M::ARMS) chain_forces<ArmChain, M>(WA, P, C, F.shape);
   }
   // ---- integrate (semi-implicit Euler); the base update is identical on both lanes
   {
-    const V3 a_ang = a[0].w;
-    const V3 a_lin = a[0].v + g0.v + cross(v[0].w, v[0].v);
+    const V3 a_ang = a0.w;
+    const V3 a_lin = a0.v + g0.v + cross(v0.w, v0.v);
     S.angvel = S.angvel + P.dt * mul(R0, a_ang);
     S.linvel = S.linvel + P.dt * mul(R0, a_lin);
-    for (int j = 0; j < HX_LEG_NJ; ++j) {
+    for (int j = 0; j < M::NL; ++j) {
       const float nqd = S.qd[j] + P.dt * qdd[j];
       const float vm = C.vmax(j);
       S.qd[j] = fminf(fmaxf(nqd, -vm), vm);
@@ -520,7 +593,7 @@ HXD void mat_to_quat(const M3& R, float* q) {
   const float sg = qw < 0.f ? -1.f : 1.f;
   q[0] = sg * qx; q[1] = sg * qy; q[2] = sg * qz; q[3] = sg * qw;
 }
-HXD void dyn_body_states(const DynState& S, const LegConst& C, BodyOut& calf, BodyOut& toe) {
+template <class M> HXD void dyn_body_states(const DynStateT<M>& S, const SideConst<M>& C, BodyOut& calf, BodyOut& toe) {
   M3 Rc = quat_to_mat(S.quat);
   V3 pc = S.pos;
   SV vc; vc.w = mulT(Rc, S.angvel); vc.v = mulT(Rc, S.linvel);

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   __shared__ float lds_const[HX_LDS_CONST_FLOATS];
   __shared__ float lds_patch[32 * HX_PATCH * HX_PATCH];
   __shared__ int lds_patch_org[32][2];
-  dyn_stage_constants(lds_const, threadIdx.x, 64);
+  dyn_stage_constants<ModelHector>(lds_const, threadIdx.x, 64);
   const hx_sim_cfg& cfg = *cfgp;
   const int n = cfg.num_envs;
   const int e = (blockIdx.x * 64 + threadIdx.x) >> 1;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
 
   float tau_leg[5];
   for (int j = 0; j < 5; ++j) tau_leg[j] = 0.f;
-  LegForces F; F.base = mk(0, 0, 0); F.thigh = mk(0, 0, 0); F.toe = mk(0, 0, 0);
+  LegForces F; F.base = mk(0, 0, 0); F.shape[0] = mk(0, 0, 0); F.shape[1] = mk(0, 0, 0);
   bool reset = false, time_out = false, blown = false;
   float rew_total = 0.f;
 
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
         for (int k = 0; k < 4; ++k) S.quat[k] = cfg.base_init_state[3 + k];
         S.linvel = mk(0, 0, 0); S.angvel = mk(0, 0, 0);
         for (int j = 0; j < 5; ++j) { S.q[j] = cfg.default_dof_pos[leg * 5 + j]; S.qd[j] = 0.f; tau_leg[j] = 0.f; }
-        F.base = mk(0, 0, 0); F.thigh = mk(0, 0, 0); F.toe = mk(0, 0, 0);
+        F.base = mk(0, 0, 0); F.shape[0] = mk(0, 0, 0); F.shape[1] = mk(0, 0, 0);
       }
     }
   }
@@ -274,10 +274,10 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   }
   V3 shape_force[5];     // base, L_thigh, L_toe, R_thigh, R_toe
   {
-    const V3 oth = xchg(F.thigh), oto = xchg(F.toe);
+    const V3 oth = xchg(F.shape[0]), oto = xchg(F.shape[1]);       // slot 0 thigh, slot 1 toe
     shape_force[0] = F.base;
-    shape_force[1] = leg ? oth : F.thigh; shape_force[3] = leg ? F.thigh : oth;
-    shape_force[2] = leg ? oto : F.toe;   shape_force[4] = leg ? F.toe : oto;
+    shape_force[1] = leg ? oth : F.shape[0]; shape_force[3] = leg ? F.shape[0] : oth;
+    shape_force[2] = leg ? oto : F.shape[1]; shape_force[4] = leg ? F.shape[1] : oto;
   }
 
   // ---- glue state
