@@ -34,7 +34,9 @@
 extern "C" {
 #endif
 
-#define HX_NUM_DOF 10
+#define HX_NUM_DOF 10          /* hector */
+#define HX_MAX_DOF 18          /* hector_full (legs + arms, hector_w_arm_config.py:17); selected by hx_sim_cfg.num_dof */
+#define HX_MAX_OBS_FRAME 65    /* 11 + 3 * 18 (hector_w_arm_config.py:12) */
 #define HX_NUM_BODIES 11
 #define HX_OBS_FRAME 41        /* num_single_obs, hector_config.py:12 */
 #define HX_PRIV_FRAME 70       /* single_num_privileged_obs, hector_config.py:14 */
@@ -78,16 +80,16 @@ typedef struct hx_sim_cfg {
   float action_scale;            /* 0.25 */
   float clip_actions;            /* 100 */
   float clip_observations;       /* 100 */
-  float default_dof_pos[HX_NUM_DOF];
-  float p_gains[HX_NUM_DOF];
-  float d_gains[HX_NUM_DOF];
-  float torque_limits[HX_NUM_DOF];   /* effort * safety.torque_limit */
+  float default_dof_pos[HX_MAX_DOF]; /* first num_dof entries are used */
+  float p_gains[HX_MAX_DOF];
+  float d_gains[HX_MAX_DOF];
+  float torque_limits[HX_MAX_DOF];   /* effort * safety.torque_limit */
   /* domain randomisation / noise */
   float action_delay;            /* 0.0 */
   float action_noise;            /* 0.02 */
   int32_t add_noise;
   float noise_level;             /* 0.6 */
-  float noise_scale_vec[HX_OBS_FRAME];
+  float noise_scale_vec[HX_MAX_OBS_FRAME];   /* first 11 + 3 * num_dof entries */
   int32_t push_robots;
   int32_t push_interval;         /* ceil(push_interval_s / dt) = 400 */
   float max_push_vel_xy;         /* 0.3 */
@@ -114,6 +116,11 @@ typedef struct hx_sim_cfg {
   /* this object simulates envs [env_id_offset, env_id_offset + num_envs) of a larger logical batch: only the
    * random streams depend on it (Philox is keyed by the global env id) */
   int32_t env_id_offset;
+  /* 10 (or 0) = hector; 18 = hector_full: observation frames 65 / 94 wide, buffers [N][976] / [N][1412], q / qd / action /
+   * torque vectors of 18 in Isaac Gym's DoF order (L leg, L arm, R leg, R arm), 19 bodies in HX_BUF_CONTACT, and one more
+   * reward ingredient (the arm term of default_joint_pos, hector_w_arm_env.py:371-378).  Random packs then follow the same
+   * field order with 18-wide action-noise / reset rows and a 65-wide observation-noise block. */
+  int32_t num_dof;
 } hx_sim_cfg;
 
 typedef struct hx_sim hx_sim;

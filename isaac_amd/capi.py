@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhx.so")
 
 NUM_DOF = 10
+MAX_DOF, MAX_OBS_FRAME = 18, 65          # hector_full (include/hx_sim.h)
 OBS_FRAME, PRIV_FRAME, FRAME_STACK = 41, 70, 15
 NUM_OBS, NUM_PRIV = 615, 1050
 OBS_LD, PRIV_LD = 616, 1052
@@ -30,10 +31,10 @@ class SimCfg(C.Structure):
     _fields_ = [
         ("num_envs", C.c_int32), ("decimation", C.c_int32), ("sim_dt", C.c_float), ("gravity_z", C.c_float),
         ("action_scale", C.c_float), ("clip_actions", C.c_float), ("clip_observations", C.c_float),
-        ("default_dof_pos", C.c_float * NUM_DOF), ("p_gains", C.c_float * NUM_DOF), ("d_gains", C.c_float * NUM_DOF),
-        ("torque_limits", C.c_float * NUM_DOF),
+        ("default_dof_pos", C.c_float * MAX_DOF), ("p_gains", C.c_float * MAX_DOF), ("d_gains", C.c_float * MAX_DOF),
+        ("torque_limits", C.c_float * MAX_DOF),
         ("action_delay", C.c_float), ("action_noise", C.c_float), ("add_noise", C.c_int32), ("noise_level", C.c_float),
-        ("noise_scale_vec", C.c_float * OBS_FRAME),
+        ("noise_scale_vec", C.c_float * MAX_OBS_FRAME),
         ("push_robots", C.c_int32), ("push_interval", C.c_int32), ("max_push_vel_xy", C.c_float),
         ("max_push_ang_vel", C.c_float),
         ("resample_interval", C.c_int32), ("heading_command", C.c_int32), ("cmd_range", (C.c_float * 2) * 4),
@@ -47,7 +48,7 @@ class SimCfg(C.Structure):
         ("cycle_time", C.c_float), ("tracking_sigma", C.c_float), ("max_contact_force", C.c_float),
         ("contact_kn", C.c_float), ("contact_dn", C.c_float), ("friction_veps", C.c_float),
         ("limit_k", C.c_float), ("limit_d", C.c_float), ("terrain_mu", C.c_float),
-        ("env_id_offset", C.c_int32),
+        ("env_id_offset", C.c_int32), ("num_dof", C.c_int32),
     ]
 
 

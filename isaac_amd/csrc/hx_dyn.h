@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 #include "hx_model_data.h"
+#include "hx_model_data_full.h"
 
 #define HXD __device__ __forceinline__
 
@@ -141,6 +142,15 @@ struct ModelHector {
   HXD static float io(int k) { return HXM_IO[k]; }
   HXD static float h(int k) { return HXM_H[k]; }
   HXD static float mass0() { return HXM_MASS[0]; }
+};
+struct ModelFull {          // hector with arms (task hector_full): one leg and one arm per body side
+  static constexpr int NL = HX_LEG_NJ + HX_ARM_NJ, NB = HX_LEG_NJ + HX_ARM_NJ, NSHAPE = 5; static constexpr bool ARMS = true;
+  static constexpr int STRIDE = HXF_SIDE_STRIDE;
+  HXD static const float* side_table() { return HXF_SIDEC; }
+  HXD static const float* base_pts() { return HXF_BASE_PTS; }
+  HXD static float io(int k) { return HXF_IO[k]; }
+  HXD static float h(int k) { return HXF_H[k]; }
+  HXD static float mass0() { return HXF_MASS0; }
 };
 template <int L> struct LegAxis { static constexpr int value = LegChain::axis(L); };
 #define HX_LDS_CONST_FLOATS_OF(M) (2 * M::STRIDE + 24)

@@ -19,12 +19,16 @@
 #include "hx_common.h"
 
 // ---------------------------------------------------------------- state layout (floats per env)
-enum {
-  S_ROOT_POS = 0, S_ROOT_QUAT = 3, S_LINVEL = 7, S_ANGVEL = 10, S_Q = 13, S_QD = 23,
-  S_ACT = 33, S_LAST_ACT = 43, S_LAST_LAST_ACT = 53, S_LAST_DOF_VEL = 63, S_LAST_ROOT_VEL = 73,
-  S_CMD = 79, S_AIR = 83, S_LAST_CONTACT = 85, S_FEET_H = 87, S_LAST_FEET_Z = 89, S_PUSH_F = 91,
-  S_PUSH_T = 93, S_FRICTION = 96, S_BASE_MASS = 97, S_ORIGIN = 98, S_BLV = 101, S_BAV = 104, S_EP_RET = 107,
-  S_STATE_SIZE = 108
+// (10 DoF: q 13, qd 23, act 33, last_act 43, last_last_act 53, last_dof_vel 63, last_root_vel 73, cmd 79, ... size 108)
+struct SLay {
+  int ROOT_POS, ROOT_QUAT, LINVEL, ANGVEL, Q, QD, ACT, LAST_ACT, LAST_LAST_ACT, LAST_DOF_VEL, LAST_ROOT_VEL, CMD, AIR, LAST_CONTACT,
+      FEET_H, LAST_FEET_Z, PUSH_F, PUSH_T, FRICTION, BASE_MASS, ORIGIN, BLV, BAV, EP_RET, SIZE;
+  __host__ __device__ constexpr SLay(int nd)
+      : ROOT_POS(0), ROOT_QUAT(3), LINVEL(7), ANGVEL(10), Q(13), QD(13 + nd), ACT(13 + 2 * nd), LAST_ACT(13 + 3 * nd),
+        LAST_LAST_ACT(13 + 4 * nd), LAST_DOF_VEL(13 + 5 * nd), LAST_ROOT_VEL(13 + 6 * nd), CMD(19 + 6 * nd), AIR(23 + 6 * nd),
+        LAST_CONTACT(25 + 6 * nd), FEET_H(27 + 6 * nd), LAST_FEET_Z(29 + 6 * nd), PUSH_F(31 + 6 * nd), PUSH_T(33 + 6 * nd),
+        FRICTION(36 + 6 * nd), BASE_MASS(37 + 6 * nd), ORIGIN(38 + 6 * nd), BLV(41 + 6 * nd), BAV(44 + 6 * nd), EP_RET(47 + 6 * nd),
+        SIZE(48 + 6 * nd) {}
 };
 
 struct SimPtrs {
@@ -130,13 +134,24 @@ struct StepArgs {
 #define LD(f) (p.st[(size_t)(f) * n + e])
 #define ST(f, val) (p.st[(size_t)(f) * n + e] = (val))
 
+template <class M>
 __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim_cfg* __restrict__ cfgp, const float* __restrict__ actions,
                                                          const float* __restrict__ pack, StepArgs A) {
   // lane pair (2e, 2e+1) = (left leg, right leg) of robot e; 32 robots per 64-lane workgroup
-  __shared__ float lds_const[HX_LDS_CONST_FLOATS];
+  constexpr int NL = M::NL, ND = 2 * NL, OBSF = 11 + 3 * ND, PRIVF = 40 + 3 * ND, PB = 5 + 3 * ND;   // joints per lane / robot, frame widths
+  constexpr SLay SL(ND);
+  constexpr int S_ROOT_POS = SL.ROOT_POS, S_ROOT_QUAT = SL.ROOT_QUAT, S_LINVEL = SL.LINVEL, S_ANGVEL = SL.ANGVEL, S_Q = SL.Q, S_QD = SL.QD,
+                S_ACT = SL.ACT, S_LAST_ACT = SL.LAST_ACT, S_LAST_LAST_ACT = SL.LAST_LAST_ACT, S_LAST_DOF_VEL = SL.LAST_DOF_VEL,
+                S_LAST_ROOT_VEL = SL.LAST_ROOT_VEL, S_CMD = SL.CMD, S_AIR = SL.AIR, S_LAST_CONTACT = SL.LAST_CONTACT, S_FEET_H = SL.FEET_H,
+                S_LAST_FEET_Z = SL.LAST_FEET_Z, S_PUSH_F = SL.PUSH_F, S_PUSH_T = SL.PUSH_T, S_FRICTION = SL.FRICTION,
+                S_BASE_MASS = SL.BASE_MASS, S_ORIGIN = SL.ORIGIN, S_BLV = SL.BLV, S_BAV = SL.BAV, S_EP_RET = SL.EP_RET;
+  // random-pack rows (include/hx_sim.h HX_RP_* are these for 10 DoF)
+  constexpr int RP_DELAY = 0, RP_ACT_NOISE = 1, RP_CMD_A = 1 + ND, RP_PUSH = 4 + ND, RP_RESET_Q = 9 + ND, RP_RESET_XY = 9 + 2 * ND,
+                RP_CMD_B = 11 + 2 * ND, RP_OBS_NOISE = 14 + 2 * ND, RP_LEVEL = 14 + 2 * ND + OBSF;
+  __shared__ float lds_const[HX_LDS_CONST_FLOATS_OF(M)];
   __shared__ float lds_patch[32 * HX_PATCH * HX_PATCH];
   __shared__ int lds_patch_org[32][2];
-  dyn_stage_constants<ModelHector>(lds_const, threadIdx.x, 64);
+  dyn_stage_constants<M>(lds_const, threadIdx.x, 64);
   const hx_sim_cfg& cfg = *cfgp;
   const int n = cfg.num_envs;
   const int e = (blockIdx.x * 64 + threadIdx.x) >> 1;
@@ -166,39 +181,40 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   __syncthreads();
   if (e >= n) return;                      // both lanes of a pair leave together
   const bool writer = (leg == 0);          // env-level results are computed by both lanes, stored by one
-  LegConst C; C.t = lds_const + leg * HX_LEGC_STRIDE; C.basept = lds_const + 2 * HX_LEGC_STRIDE;
+  SideConst<M> C; C.t = lds_const + leg * M::STRIDE; C.basept = lds_const + 2 * M::STRIDE;
   Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
 
   // ---- load state: base (both lanes) + this lane's leg
-  DynState S;
+  DynStateT<M> S;
   S.pos = mk(LD(S_ROOT_POS), LD(S_ROOT_POS + 1), LD(S_ROOT_POS + 2));
   for (int i = 0; i < 4; ++i) S.quat[i] = LD(S_ROOT_QUAT + i);
   S.linvel = mk(LD(S_LINVEL), LD(S_LINVEL + 1), LD(S_LINVEL + 2));
   S.angvel = mk(LD(S_ANGVEL), LD(S_ANGVEL + 1), LD(S_ANGVEL + 2));
-  for (int j = 0; j < 5; ++j) { S.q[j] = LD(S_Q + leg * 5 + j); S.qd[j] = LD(S_QD + leg * 5 + j); }
+  for (int j = 0; j < NL; ++j) { S.q[j] = LD(S_Q + leg * NL + j); S.qd[j] = LD(S_QD + leg * NL + j); }
   // only what the physics needs is loaded before the substep loop; the glue state is loaded after it
-  float act[10];
-  for (int j = 0; j < 10; ++j) act[j] = LD(S_ACT + j);
+  float act[ND];
+  for (int j = 0; j < ND; ++j) act[j] = LD(S_ACT + j);
   const float friction = LD(S_FRICTION), base_mass = LD(S_BASE_MASS);
   int ep_len = p.ep_len[e];
 
-  float tau_leg[5];
-  for (int j = 0; j < 5; ++j) tau_leg[j] = 0.f;
-  LegForces F; F.base = mk(0, 0, 0); F.shape[0] = mk(0, 0, 0); F.shape[1] = mk(0, 0, 0);
+  float tau_leg[NL];
+  for (int j = 0; j < NL; ++j) tau_leg[j] = 0.f;
+  SideForcesT<M> F; F.base = mk(0, 0, 0);
+  for (int q = 0; q < M::NSHAPE; ++q) F.shape[q] = mk(0, 0, 0);
   bool reset = false, time_out = false, blown = false;
   float rew_total = 0.f;
 
   if (A.mode == 0) {
     // ---- hector_env.py:158-169 : clip, delay blend, multiplicative noise ; legged_robot.py:90-91 clip
-    float a[10];
-    const float delay = rng.uni(HX_RP_DELAY) * cfg.action_delay;
-    for (int j = 0; j < 10; ++j) {
-      float x = clampf(actions[(size_t)e * 10 + j], -cfg.clip_actions, cfg.clip_actions);
+    float a[ND];
+    const float delay = rng.uni(RP_DELAY) * cfg.action_delay;
+    for (int j = 0; j < ND; ++j) {
+      float x = clampf(actions[(size_t)e * ND + j], -cfg.clip_actions, cfg.clip_actions);
       x = (1.0f - delay) * x + delay * act[j];
-      x = x + cfg.action_noise * rng.nrm(HX_RP_ACT_NOISE + j) * x;
+      x = x + cfg.action_noise * rng.nrm(RP_ACT_NOISE + j) * x;
       a[j] = clampf(x, -cfg.clip_actions, cfg.clip_actions);
     }
-    for (int j = 0; j < 10; ++j) act[j] = a[j];
+    for (int j = 0; j < ND; ++j) act[j] = a[j];
     // ---- legged_robot.py:93-100 : decimation x {PD torque, simulate}
     DynParams P;
     P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
@@ -221,13 +237,13 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
       P.zmax = fmaxf(zm, xchg(zm));
       P.zmax_near = fmaxf(zn, xchg(zn));
     }
-    float target[5], kpl[5], kdl[5], tll[5];
-    for (int j = 0; j < 5; ++j) {
-      const float aj = leg ? act[5 + j] : act[j];
-      target[j] = aj * cfg.action_scale + cfg.default_dof_pos[leg * 5 + j];
-      kpl[j] = cfg.p_gains[leg * 5 + j]; kdl[j] = cfg.d_gains[leg * 5 + j]; tll[j] = cfg.torque_limits[leg * 5 + j];
+    float target[NL], kpl[NL], kdl[NL], tll[NL];
+    for (int j = 0; j < NL; ++j) {
+      const float aj = leg ? act[NL + j] : act[j];
+      target[j] = aj * cfg.action_scale + cfg.default_dof_pos[leg * NL + j];
+      kpl[j] = cfg.p_gains[leg * NL + j]; kdl[j] = cfg.d_gains[leg * NL + j]; tll[j] = cfg.torque_limits[leg * NL + j];
     }
-    const float mass_scale = base_mass / HXM_MASS[0];
+    const float mass_scale = base_mass / M::mass0();
 #pragma unroll 1
     for (int sub = 0; sub < cfg.decimation; ++sub)
       dyn_substep(S, P, C, leg, target, kpl, kdl, tll, mass_scale, tau_leg, sub == cfg.decimation - 1, F);
@@ -237,7 +253,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     {
       float chk = S.pos.x + S.pos.y + S.pos.z + S.quat[0] + S.quat[1] + S.quat[2] + S.quat[3]
                   + S.linvel.x + S.linvel.y + S.linvel.z + S.angvel.x + S.angvel.y + S.angvel.z;
-      for (int j = 0; j < 5; ++j) chk += S.q[j] + S.qd[j];
+      for (int j = 0; j < NL; ++j) chk += S.q[j] + S.qd[j];
       float bad = (fabsf(chk) < 1.0e6f) ? 0.f : 1.f;          // NaN fails the comparison
       bad = fmaxf(bad, xchg(bad));
       if (bad != 0.f) {
@@ -245,8 +261,9 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
         S.pos = mk(cfg.base_init_state[0] + LD(S_ORIGIN), cfg.base_init_state[1] + LD(S_ORIGIN + 1), cfg.base_init_state[2] + LD(S_ORIGIN + 2));
         for (int k = 0; k < 4; ++k) S.quat[k] = cfg.base_init_state[3 + k];
         S.linvel = mk(0, 0, 0); S.angvel = mk(0, 0, 0);
-        for (int j = 0; j < 5; ++j) { S.q[j] = cfg.default_dof_pos[leg * 5 + j]; S.qd[j] = 0.f; tau_leg[j] = 0.f; }
-        F.base = mk(0, 0, 0); F.shape[0] = mk(0, 0, 0); F.shape[1] = mk(0, 0, 0);
+        for (int j = 0; j < NL; ++j) { S.q[j] = cfg.default_dof_pos[leg * NL + j]; S.qd[j] = 0.f; tau_leg[j] = 0.f; }
+        F.base = mk(0, 0, 0);
+        for (int q = 0; q < M::NSHAPE; ++q) F.shape[q] = mk(0, 0, 0);
       }
     }
   }
@@ -264,25 +281,24 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     swap_in(calf, bo[0], bo[2]);
     swap_in(toe, bo[1], bo[3]);
   }
-  // whole-robot joint vectors in DOF order (left 0-4, right 5-9), identical on both lanes
-  float qa[10], qda[10], torques[10];
-  for (int j = 0; j < 5; ++j) {
+  // whole-robot joint vectors in DOF order (left side 0 .. NL-1, right side NL .. ND-1), identical on both lanes
+  float qa[ND], qda[ND], torques[ND];
+  for (int j = 0; j < NL; ++j) {
     const float oq = xchg(S.q[j]), oqd = xchg(S.qd[j]), ot = xchg(tau_leg[j]);
-    qa[j] = leg ? oq : S.q[j];       qa[5 + j] = leg ? S.q[j] : oq;
-    qda[j] = leg ? oqd : S.qd[j];    qda[5 + j] = leg ? S.qd[j] : oqd;
-    torques[j] = leg ? ot : tau_leg[j]; torques[5 + j] = leg ? tau_leg[j] : ot;
+    qa[j] = leg ? oq : S.q[j];       qa[NL + j] = leg ? S.q[j] : oq;
+    qda[j] = leg ? oqd : S.qd[j];    qda[NL + j] = leg ? S.qd[j] : oqd;
+    torques[j] = leg ? ot : tau_leg[j]; torques[NL + j] = leg ? tau_leg[j] : ot;
   }
-  V3 shape_force[5];     // base, L_thigh, L_toe, R_thigh, R_toe
-  {
-    const V3 oth = xchg(F.shape[0]), oto = xchg(F.shape[1]);       // slot 0 thigh, slot 1 toe
-    shape_force[0] = F.base;
-    shape_force[1] = leg ? oth : F.shape[0]; shape_force[3] = leg ? F.shape[0] : oth;
-    shape_force[2] = leg ? oto : F.shape[1]; shape_force[4] = leg ? F.shape[1] : oto;
+  // net contact force per collision shape: [side][slot] (slot 0 thigh, 1 toe, with arms 2 twist, 3 shoulder, 4 elbow)
+  V3 side_force[2][M::NSHAPE];
+  for (int q = 0; q < M::NSHAPE; ++q) {
+    const V3 oth = xchg(F.shape[q]);
+    side_force[0][q] = leg ? oth : F.shape[q]; side_force[1][q] = leg ? F.shape[q] : oth;
   }
 
   // ---- glue state
-  float last_act[10], last_last_act[10], last_dof_vel[10], last_root_vel[6], cmd[4];
-  for (int j = 0; j < 10; ++j) { last_act[j] = LD(S_LAST_ACT + j); last_last_act[j] = LD(S_LAST_LAST_ACT + j); last_dof_vel[j] = LD(S_LAST_DOF_VEL + j); }
+  float last_act[ND], last_last_act[ND], last_dof_vel[ND], last_root_vel[6], cmd[4];
+  for (int j = 0; j < ND; ++j) { last_act[j] = LD(S_LAST_ACT + j); last_last_act[j] = LD(S_LAST_LAST_ACT + j); last_dof_vel[j] = LD(S_LAST_DOF_VEL + j); }
   for (int j = 0; j < 6; ++j) last_root_vel[j] = LD(S_LAST_ROOT_VEL + j);
   for (int j = 0; j < 4; ++j) cmd[j] = LD(S_CMD + j);
   float air[2] = {LD(S_AIR), LD(S_AIR + 1)};
@@ -307,10 +323,10 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     euler = euler_xyz_wrapped(S.quat);
     // ---- callback (legged_robot.py:303-319)
     if (ep_len % cfg.resample_interval == 0) {
-      cmd[0] = (cfg.cmd_range[0][1] - cfg.cmd_range[0][0]) * rng.uni(HX_RP_CMD_A) + cfg.cmd_range[0][0];
-      cmd[1] = (cfg.cmd_range[1][1] - cfg.cmd_range[1][0]) * rng.uni(HX_RP_CMD_A + 1) + cfg.cmd_range[1][0];
-      if (cfg.heading_command) cmd[3] = (cfg.cmd_range[3][1] - cfg.cmd_range[3][0]) * rng.uni(HX_RP_CMD_A + 2) + cfg.cmd_range[3][0];
-      else cmd[2] = (cfg.cmd_range[2][1] - cfg.cmd_range[2][0]) * rng.uni(HX_RP_CMD_A + 2) + cfg.cmd_range[2][0];
+      cmd[0] = (cfg.cmd_range[0][1] - cfg.cmd_range[0][0]) * rng.uni(RP_CMD_A) + cfg.cmd_range[0][0];
+      cmd[1] = (cfg.cmd_range[1][1] - cfg.cmd_range[1][0]) * rng.uni(RP_CMD_A + 1) + cfg.cmd_range[1][0];
+      if (cfg.heading_command) cmd[3] = (cfg.cmd_range[3][1] - cfg.cmd_range[3][0]) * rng.uni(RP_CMD_A + 2) + cfg.cmd_range[3][0];
+      else cmd[2] = (cfg.cmd_range[2][1] - cfg.cmd_range[2][0]) * rng.uni(RP_CMD_A + 2) + cfg.cmd_range[2][0];
       const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.f : 0.f;
       cmd[0] *= keep; cmd[1] *= keep;
     }
@@ -323,10 +339,10 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     }
     if (cfg.push_robots && (A.step_counter % cfg.push_interval == 0)) {
       // hector_env.py:53-68 : overwrite base velocities of every env
-      push_f[0] = 2.f * cfg.max_push_vel_xy * rng.uni(HX_RP_PUSH) - cfg.max_push_vel_xy;
-      push_f[1] = 2.f * cfg.max_push_vel_xy * rng.uni(HX_RP_PUSH + 1) - cfg.max_push_vel_xy;
+      push_f[0] = 2.f * cfg.max_push_vel_xy * rng.uni(RP_PUSH) - cfg.max_push_vel_xy;
+      push_f[1] = 2.f * cfg.max_push_vel_xy * rng.uni(RP_PUSH + 1) - cfg.max_push_vel_xy;
       S.linvel.x = push_f[0]; S.linvel.y = push_f[1];
-      for (int k = 0; k < 3; ++k) push_t[k] = 2.f * cfg.max_push_ang_vel * rng.uni(HX_RP_PUSH + 2 + k) - cfg.max_push_ang_vel;
+      for (int k = 0; k < 3; ++k) push_t[k] = 2.f * cfg.max_push_ang_vel * rng.uni(RP_PUSH + 2 + k) - cfg.max_push_ang_vel;
       S.angvel = mk(push_t[0], push_t[1], push_t[2]);
     }
   } else {
@@ -334,8 +350,8 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   }
 
   // contact forces per body (world): only shape bodies can be non-zero
-  const V3 f_base = shape_force[0], f_lthigh = shape_force[1], f_ltoe = shape_force[2], f_rthigh = shape_force[3], f_rtoe = shape_force[4];
-  const V3 foot_f[2] = {f_ltoe, f_rtoe};
+  const V3 f_base = F.base, f_lthigh = side_force[0][0], f_rthigh = side_force[1][0];
+  const V3 foot_f[2] = {side_force[0][1], side_force[1][1]};
   const V3 foot_pos[2] = {bo[1].pos, bo[3].pos}, foot_vel[2] = {bo[1].linvel, bo[3].linvel};
   const V3 knee_pos[2] = {bo[0].pos, bo[2].pos};
   bool contact[2] = {foot_f[0].z > 5.0f, foot_f[1].z > 5.0f};
@@ -352,14 +368,17 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     // ---- termination (legged_robot.py:155-160)
     const float nb = sqrtf(dot(f_base, f_base)), nl = sqrtf(dot(f_lthigh, f_lthigh)), nr = sqrtf(dot(f_rthigh, f_rthigh));
     reset = (nb > 1.0f) || (nl > 1.0f) || (nr > 1.0f) || blown;
+    if constexpr (M::ARMS)        // terminate_after_contacts_on also names 'shoulder', 'twist', 'roll' (hector_w_arm_config.py:35); roll has no shape
+      for (int sd = 0; sd < 2; ++sd)
+        for (int q = 2; q <= 3; ++q) reset = reset || (sqrtf(dot(side_force[sd][q], side_force[sd][q])) > 1.0f);
     time_out = (float)ep_len > cfg.max_episode_length;
     reset = reset || time_out;
 
     // ---- rewards, alphabetical order (legged_robot.py:216-234 ; functions hector_env.py:264-539)
     float sm[2];
     stance_mask(ep_len, sm);
-    float dq0[10];
-    for (int j = 0; j < 10; ++j) dq0[j] = qa[j] - cfg.default_dof_pos[j];
+    float dq0[ND];
+    for (int j = 0; j < ND; ++j) dq0[j] = qa[j] - cfg.default_dof_pos[j];
     const float* sc = cfg.reward_scale;
     float rsum = 0.f;
     auto add = [&](int id, float r) {
@@ -369,7 +388,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     };
     if (sc[HX_R_ACTION_SMOOTHNESS] != 0.f) {
       float t1 = 0, t2 = 0, t3 = 0;
-      for (int j = 0; j < 10; ++j) {
+      for (int j = 0; j < ND; ++j) {
         const float d1 = last_act[j] - act[j]; t1 += d1 * d1;
         const float d2 = act[j] + last_last_act[j] - 2.f * last_act[j]; t2 += d2 * d2;
         t3 += fabsf(act[j]);
@@ -390,17 +409,23 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     if (sc[HX_R_COLLISION] != 0.f)
       add(HX_R_COLLISION, (nb > 0.1f ? 1.f : 0.f) + (nl > 0.1f ? 1.f : 0.f) + (nr > 0.1f ? 1.f : 0.f));
     if (sc[HX_R_DEFAULT_JOINT_POS] != 0.f) {
-      float yr = sqrtf(dq0[0] * dq0[0] + dq0[1] * dq0[1]) + sqrtf(dq0[5] * dq0[5] + dq0[6] * dq0[6]);
+      float yr = sqrtf(dq0[0] * dq0[0] + dq0[1] * dq0[1]) + sqrtf(dq0[NL] * dq0[NL] + dq0[NL + 1] * dq0[NL + 1]);   // hip yaw / roll
       yr = clampf(yr - 0.1f, 0.f, 50.f);
-      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += dq0[j] * dq0[j];
-      add(HX_R_DEFAULT_JOINT_POS, expf(-yr * 100.f) - 0.01f * sqrtf(s2));
+      float s2 = 0; for (int j = 0; j < ND; ++j) s2 += dq0[j] * dq0[j];
+      float r = expf(-yr * 100.f) - 0.01f * sqrtf(s2);
+      if constexpr (M::ARMS) {      // hector_w_arm_env.py:371-378: shoulder yaw / pitch of both arms
+        float ar = sqrtf(dq0[5] * dq0[5] + dq0[6] * dq0[6]) + sqrtf(dq0[NL + 5] * dq0[NL + 5] + dq0[NL + 6] * dq0[NL + 6]);
+        ar = clampf(ar - 0.1f, 0.f, 25.f);
+        r += expf(-ar * 2.f);
+      }
+      add(HX_R_DEFAULT_JOINT_POS, r);
     }
     if (sc[HX_R_DOF_ACC] != 0.f) {
-      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = (last_dof_vel[j] - qda[j]) / cfg.env_dt; s2 += d * d; }
+      float s2 = 0; for (int j = 0; j < ND; ++j) { const float d = (last_dof_vel[j] - qda[j]) / cfg.env_dt; s2 += d * d; }
       add(HX_R_DOF_ACC, s2);
     }
     if (sc[HX_R_DOF_VEL] != 0.f) {
-      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += qda[j] * qda[j];
+      float s2 = 0; for (int j = 0; j < ND; ++j) s2 += qda[j] * qda[j];
       add(HX_R_DOF_VEL, s2);
     }
     if (sc[HX_R_FEET_AIR_TIME] != 0.f) {
@@ -454,12 +479,12 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
       // compute_observations call; this term is zero-scaled in HectorCfg)
       const float phase = (float)(ep_len) * cfg.env_dt / cfg.cycle_time;
       const float sp = sinf(TWO_PI * phase);
-      float ref[10]; for (int j = 0; j < 10; ++j) ref[j] = 0.f;
+      float ref[ND]; for (int j = 0; j < ND; ++j) ref[j] = 0.f;      // indices 2-4 / 7-9 whatever the DoF count (hector_w_arm_env.py:107-114)
       const float s1 = cfg.target_joint_pos_scale, s2c = 2.f * s1;
       const float l = sp > 0.f ? 0.f : sp, r_ = sp < 0.f ? 0.f : sp;
       ref[2] = l * s1; ref[3] = l * s2c; ref[4] = l * s1; ref[7] = r_ * s1; ref[8] = r_ * s2c; ref[9] = r_ * s1;
-      if (fabsf(sp) < 0.1f) for (int j = 0; j < 10; ++j) ref[j] = 0.f;
-      float s2 = 0; for (int j = 0; j < 10; ++j) { const float d = qa[j] - ref[j]; s2 += d * d; }
+      if (fabsf(sp) < 0.1f) for (int j = 0; j < ND; ++j) ref[j] = 0.f;
+      float s2 = 0; for (int j = 0; j < ND; ++j) { const float d = qa[j] - ref[j]; s2 += d * d; }
       const float nn = sqrtf(s2);
       add(HX_R_JOINT_POS, expf(-2.f * nn) - 0.2f * clampf(nn, 0.f, 0.5f));
     }
@@ -481,7 +506,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
       add(HX_R_ORIENTATION, (a1 + b1) / 2.f);
     }
     if (sc[HX_R_TORQUES] != 0.f) {
-      float s2 = 0; for (int j = 0; j < 10; ++j) s2 += torques[j] * torques[j];
+      float s2 = 0; for (int j = 0; j < ND; ++j) s2 += torques[j] * torques[j];
       add(HX_R_TORQUES, s2);
     }
     if (sc[HX_R_TRACK_VEL_HARD] != 0.f) {
@@ -519,31 +544,31 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
       const bool up = dist > p.cur_up_dist;
       const bool down = (dist < sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) * p.cur_down_scale) && !up;
       int lvl = p.cur_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
-      if (lvl >= p.cur_rows) lvl = min((int)(rng.uni(HX_RP_LEVEL) * (float)p.cur_rows), p.cur_rows - 1);
+      if (lvl >= p.cur_rows) lvl = min((int)(rng.uni(RP_LEVEL) * (float)p.cur_rows), p.cur_rows - 1);
       else lvl = max(lvl, 0);
       const float* o = p.cur_origins + ((size_t)lvl * p.cur_cols + p.cur_types[e]) * 3;
       origin = mk(o[0], o[1], o[2]);
       if (writer) { p.cur_levels[e] = lvl; ST(S_ORIGIN, origin.x); ST(S_ORIGIN + 1, origin.y); ST(S_ORIGIN + 2, origin.z); }
     }
-    for (int j = 0; j < 10; ++j) {
-      qa[j] = cfg.default_dof_pos[j] + (0.3f * rng.uni(HX_RP_RESET_Q + j) - 0.15f);
+    for (int j = 0; j < ND; ++j) {
+      qa[j] = cfg.default_dof_pos[j] + (0.3f * rng.uni(RP_RESET_Q + j) - 0.15f);
       qda[j] = 0.f;
     }
     S.pos = mk(cfg.base_init_state[0] + origin.x, cfg.base_init_state[1] + origin.y, cfg.base_init_state[2] + origin.z);
     if (cfg.custom_origins) {
-      S.pos.x += 2.f * rng.uni(HX_RP_RESET_XY) - 1.f;
-      S.pos.y += 2.f * rng.uni(HX_RP_RESET_XY + 1) - 1.f;
+      S.pos.x += 2.f * rng.uni(RP_RESET_XY) - 1.f;
+      S.pos.y += 2.f * rng.uni(RP_RESET_XY + 1) - 1.f;
     }
     for (int k = 0; k < 4; ++k) S.quat[k] = cfg.base_init_state[3 + k];
     S.linvel = mk(cfg.base_init_state[7], cfg.base_init_state[8], cfg.base_init_state[9]);
     S.angvel = mk(cfg.base_init_state[10], cfg.base_init_state[11], cfg.base_init_state[12]);
-    cmd[0] = (cfg.cmd_range[0][1] - cfg.cmd_range[0][0]) * rng.uni(HX_RP_CMD_B) + cfg.cmd_range[0][0];
-    cmd[1] = (cfg.cmd_range[1][1] - cfg.cmd_range[1][0]) * rng.uni(HX_RP_CMD_B + 1) + cfg.cmd_range[1][0];
-    if (cfg.heading_command) cmd[3] = (cfg.cmd_range[3][1] - cfg.cmd_range[3][0]) * rng.uni(HX_RP_CMD_B + 2) + cfg.cmd_range[3][0];
-    else cmd[2] = (cfg.cmd_range[2][1] - cfg.cmd_range[2][0]) * rng.uni(HX_RP_CMD_B + 2) + cfg.cmd_range[2][0];
+    cmd[0] = (cfg.cmd_range[0][1] - cfg.cmd_range[0][0]) * rng.uni(RP_CMD_B) + cfg.cmd_range[0][0];
+    cmd[1] = (cfg.cmd_range[1][1] - cfg.cmd_range[1][0]) * rng.uni(RP_CMD_B + 1) + cfg.cmd_range[1][0];
+    if (cfg.heading_command) cmd[3] = (cfg.cmd_range[3][1] - cfg.cmd_range[3][0]) * rng.uni(RP_CMD_B + 2) + cfg.cmd_range[3][0];
+    else cmd[2] = (cfg.cmd_range[2][1] - cfg.cmd_range[2][0]) * rng.uni(RP_CMD_B + 2) + cfg.cmd_range[2][0];
     const float keep = (sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > 0.2f) ? 1.f : 0.f;
     cmd[0] *= keep; cmd[1] *= keep;
-    for (int j = 0; j < 10; ++j) { act[j] = 0.f; last_act[j] = 0.f; last_last_act[j] = 0.f; last_dof_vel[j] = 0.f; }
+    for (int j = 0; j < ND; ++j) { act[j] = 0.f; last_act[j] = 0.f; last_last_act[j] = 0.f; last_dof_vel[j] = 0.f; }
     air[0] = 0.f; air[1] = 0.f;
     const int finished_len = ep_len;
     ep_len = 0;
@@ -572,40 +597,40 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     const float sp = sinf(TWO_PI * phase), cp = cosf(TWO_PI * phase);
     float sm[2];
     stance_mask(ep_len, sm);
-    float f[HX_PRIV_FRAME];
+    float f[PRIVF];
     f[0] = sp; f[1] = cp;
     f[2] = cmd[0] * cfg.obs_scale_lin_vel; f[3] = cmd[1] * cfg.obs_scale_lin_vel; f[4] = cmd[2] * cfg.obs_scale_ang_vel;
-    for (int j = 0; j < 10; ++j) {
+    for (int j = 0; j < ND; ++j) {
       f[5 + j] = (qa[j] - cfg.default_dof_pos[j]) * cfg.obs_scale_dof_pos;
-      f[15 + j] = qda[j] * cfg.obs_scale_dof_vel;
-      f[25 + j] = act[j];
+      f[5 + ND + j] = qda[j] * cfg.obs_scale_dof_vel;
+      f[5 + 2 * ND + j] = act[j];
     }
     // obs41 = [cmd5, q10, dq10, a10, ang_vel3, euler3]
-    float o[HX_OBS_FRAME];
-    for (int k = 0; k < 35; ++k) o[k] = f[k];
-    o[35] = base_ang_vel.x * cfg.obs_scale_ang_vel; o[36] = base_ang_vel.y * cfg.obs_scale_ang_vel; o[37] = base_ang_vel.z * cfg.obs_scale_ang_vel;
-    o[38] = euler.x * cfg.obs_scale_quat; o[39] = euler.y * cfg.obs_scale_quat; o[40] = euler.z * cfg.obs_scale_quat;
+    float o[OBSF];
+    for (int k = 0; k < PB; ++k) o[k] = f[k];
+    o[PB] = base_ang_vel.x * cfg.obs_scale_ang_vel; o[PB + 1] = base_ang_vel.y * cfg.obs_scale_ang_vel; o[PB + 2] = base_ang_vel.z * cfg.obs_scale_ang_vel;
+    o[PB + 3] = euler.x * cfg.obs_scale_quat; o[PB + 4] = euler.y * cfg.obs_scale_quat; o[PB + 5] = euler.z * cfg.obs_scale_quat;
     if (cfg.add_noise)
-      for (int k = 0; k < HX_OBS_FRAME; ++k) {
+      for (int k = 0; k < OBSF; ++k) {
         const float sv = cfg.noise_scale_vec[k];
-        if (sv != 0.f) o[k] = o[k] + rng.nrm(HX_RP_OBS_NOISE + k) * sv * cfg.noise_level;
+        if (sv != 0.f) o[k] = o[k] + rng.nrm(RP_OBS_NOISE + k) * sv * cfg.noise_level;
       }
-    if (writer) for (int k = 0; k < HX_OBS_FRAME; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
-    f[35] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[36] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[37] = base_lin_vel.z * cfg.obs_scale_lin_vel;
-    f[38] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[39] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[40] = base_ang_vel.z * cfg.obs_scale_ang_vel;
-    f[41] = euler.x * cfg.obs_scale_quat; f[42] = euler.y * cfg.obs_scale_quat; f[43] = euler.z * cfg.obs_scale_quat;
-    f[44] = foot_pos[0].x; f[45] = foot_pos[0].y; f[46] = foot_pos[0].z; f[47] = foot_pos[1].x; f[48] = foot_pos[1].y; f[49] = foot_pos[1].z;
-    f[50] = foot_vel[0].x; f[51] = foot_vel[0].y; f[52] = foot_vel[0].z; f[53] = foot_vel[1].x; f[54] = foot_vel[1].y; f[55] = foot_vel[1].z;
-    f[56] = S.pos.x; f[57] = S.pos.y; f[58] = S.pos.z;
-    f[59] = push_f[0]; f[60] = push_f[1]; f[61] = push_t[0]; f[62] = push_t[1]; f[63] = push_t[2];
-    f[64] = friction; f[65] = base_mass / 30.f;
-    f[66] = sm[0]; f[67] = sm[1]; f[68] = contact[0] ? 1.f : 0.f; f[69] = contact[1] ? 1.f : 0.f;
-    if (writer) for (int k = 0; k < HX_PRIV_FRAME; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+    if (writer) for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
+    f[PB + 0] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[PB + 1] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[PB + 2] = base_lin_vel.z * cfg.obs_scale_lin_vel;
+    f[PB + 3] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[PB + 4] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[PB + 5] = base_ang_vel.z * cfg.obs_scale_ang_vel;
+    f[PB + 6] = euler.x * cfg.obs_scale_quat; f[PB + 7] = euler.y * cfg.obs_scale_quat; f[PB + 8] = euler.z * cfg.obs_scale_quat;
+    f[PB + 9] = foot_pos[0].x; f[PB + 10] = foot_pos[0].y; f[PB + 11] = foot_pos[0].z; f[PB + 12] = foot_pos[1].x; f[PB + 13] = foot_pos[1].y; f[PB + 14] = foot_pos[1].z;
+    f[PB + 15] = foot_vel[0].x; f[PB + 16] = foot_vel[0].y; f[PB + 17] = foot_vel[0].z; f[PB + 18] = foot_vel[1].x; f[PB + 19] = foot_vel[1].y; f[PB + 20] = foot_vel[1].z;
+    f[PB + 21] = S.pos.x; f[PB + 22] = S.pos.y; f[PB + 23] = S.pos.z;
+    f[PB + 24] = push_f[0]; f[PB + 25] = push_f[1]; f[PB + 26] = push_t[0]; f[PB + 27] = push_t[1]; f[PB + 28] = push_t[2];
+    f[PB + 29] = friction; f[PB + 30] = base_mass / 30.f;
+    f[PB + 31] = sm[0]; f[PB + 32] = sm[1]; f[PB + 33] = contact[0] ? 1.f : 0.f; f[PB + 34] = contact[1] ? 1.f : 0.f;
+    if (writer) for (int k = 0; k < PRIVF; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
   }
 
   // ---- bookkeeping (legged_robot.py:146-150) and store
   if (A.mode == 0) {
-    for (int j = 0; j < 10; ++j) { last_last_act[j] = last_act[j]; last_act[j] = act[j]; last_dof_vel[j] = qda[j]; }
+    for (int j = 0; j < ND; ++j) { last_last_act[j] = last_act[j]; last_act[j] = act[j]; last_dof_vel[j] = qda[j]; }
     last_root_vel[0] = S.linvel.x; last_root_vel[1] = S.linvel.y; last_root_vel[2] = S.linvel.z;
     last_root_vel[3] = S.angvel.x; last_root_vel[4] = S.angvel.y; last_root_vel[5] = S.angvel.z;
   }
@@ -614,7 +639,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   for (int i = 0; i < 4; ++i) ST(S_ROOT_QUAT + i, S.quat[i]);
   ST(S_LINVEL, S.linvel.x); ST(S_LINVEL + 1, S.linvel.y); ST(S_LINVEL + 2, S.linvel.z);
   ST(S_ANGVEL, S.angvel.x); ST(S_ANGVEL + 1, S.angvel.y); ST(S_ANGVEL + 2, S.angvel.z);
-  for (int j = 0; j < 10; ++j) {
+  for (int j = 0; j < ND; ++j) {
     ST(S_Q + j, qa[j]); ST(S_QD + j, qda[j]); ST(S_ACT + j, act[j]); ST(S_LAST_ACT + j, last_act[j]);
     ST(S_LAST_LAST_ACT + j, last_last_act[j]); ST(S_LAST_DOF_VEL + j, last_dof_vel[j]);
     p.torques[(size_t)j * n + e] = torques[j];
@@ -632,11 +657,16 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   p.reset[e] = reset ? 1 : 0;
   p.timeout[e] = time_out ? 1 : 0;
   // diagnostic tensors (contact_forces / rigid_state views of the reference)
-  const int shape_body[5] = {0, 3, 5, 8, 10};
-  for (int s = 0; s < 5; ++s) {
-    p.contact[(size_t)(shape_body[s] * 3 + 0) * n + e] = shape_force[s].x;
-    p.contact[(size_t)(shape_body[s] * 3 + 1) * n + e] = shape_force[s].y;
-    p.contact[(size_t)(shape_body[s] * 3 + 2) * n + e] = shape_force[s].z;
+  {
+    p.contact[(size_t)0 * n + e] = F.base.x; p.contact[(size_t)1 * n + e] = F.base.y; p.contact[(size_t)2 * n + e] = F.base.z;
+    const int slot_body[5] = {2, 4, 5, 6, 8};       // side-local body of a shape slot: thigh, toe, twist, shoulder, elbow
+    for (int sd = 0; sd < 2; ++sd)
+      for (int q = 0; q < M::NSHAPE; ++q) {
+        const int body = 1 + sd * NL + slot_body[q];
+        p.contact[(size_t)(body * 3 + 0) * n + e] = side_force[sd][q].x;
+        p.contact[(size_t)(body * 3 + 1) * n + e] = side_force[sd][q].y;
+        p.contact[(size_t)(body * 3 + 2) * n + e] = side_force[sd][q].z;
+      }
   }
   for (int b = 0; b < 4; ++b) {
     float* o = p.bodies + (size_t)(b * 13) * n + e;
@@ -659,12 +689,13 @@ struct StackArgs {
   const int* num_reset; int* num_reset_next;
   const float* rew; float* rew_out; unsigned char* done_out; unsigned char* timeout_out;
   int n; float clip;
+  int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, or 65 / 94 with arms) and row strides
 };
 __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
   const int e = blockIdx.x;
   const bool rst = a.reset[e] != 0;
   {
-    const int F = HX_OBS_FRAME, ld = HX_OBS_LD, keep = (HX_FRAME_STACK - 1) * F;
+    const int F = a.obs_f, ld = a.obs_ld, keep = (HX_FRAME_STACK - 1) * F;
     const float* s = a.obs_src + (size_t)e * ld;
     float* d = a.obs_dst + (size_t)e * ld;
     for (int k = threadIdx.x; k < ld; k += blockDim.x) {
@@ -675,7 +706,7 @@ __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
     }
   }
   {
-    const int F = HX_PRIV_FRAME, ld = HX_PRIV_LD, keep = (HX_FRAME_STACK - 1) * F;
+    const int F = a.priv_f, ld = a.priv_ld, keep = (HX_FRAME_STACK - 1) * F;
     const float* s = a.priv_src + (size_t)e * ld;
     float* d = a.priv_dst + (size_t)e * ld;
     for (int k = threadIdx.x; k < ld; k += blockDim.x) {
@@ -703,6 +734,9 @@ extern "C" int hx_version(void) { return 100; }
 extern "C" int hx_sync(void* stream) { HX_CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 
 struct hx_sim {
+  int nd;                          // DoF count of the robot: 10 (hector) or 18 (hector with arms)
+  int obs_f, priv_f, obs_ld, priv_ld;
+  SLay L{10};                      // state layout for nd
   hx_sim_cfg cfg;
   hx_sim_cfg* cfg_d;
   hipStream_t stream;
@@ -744,6 +778,11 @@ extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, con
 static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const float* base_mass_h, const float* origins_h,
                            const float* start_pos_h, uint64_t seed, void* stream, hx_sim* s) {
   s->cfg = *cfg;
+  s->nd = cfg->num_dof ? cfg->num_dof : HX_NUM_DOF;
+  if (s->nd != HX_NUM_DOF && s->nd != HX_MAX_DOF) { hx_set_error("hx_sim_create: num_dof must be 10 (hector) or 18 (hector_full)"); return -2; }
+  s->L = SLay(s->nd);
+  s->obs_f = 11 + 3 * s->nd; s->priv_f = 40 + 3 * s->nd;
+  s->obs_ld = (HX_FRAME_STACK * s->obs_f + 3) / 4 * 4; s->priv_ld = (HX_FRAME_STACK * s->priv_f + 3) / 4 * 4;
   s->seed = seed;
   s->step_counter = 0;
   s->rng_step = 0;
@@ -763,14 +802,14 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   }
   const size_t n = cfg->num_envs;
   int rc = 0;
-  rc |= dalloc(s, &s->p.st, (size_t)S_STATE_SIZE * n);
+  rc |= dalloc(s, &s->p.st, (size_t)s->L.SIZE * n);
   rc |= dalloc(s, &s->p.ep_len, n);
   rc |= dalloc(s, &s->p.ep_sums, (size_t)HX_NUM_REWARDS * n);
-  rc |= dalloc(s, &s->p.torques, 10 * n);
-  rc |= dalloc(s, &s->p.contact, 33 * n);
+  rc |= dalloc(s, &s->p.torques, (size_t)s->nd * n);
+  rc |= dalloc(s, &s->p.contact, (size_t)(1 + s->nd) * 3 * n);
   rc |= dalloc(s, &s->p.bodies, 52 * n);
-  rc |= dalloc(s, &s->p.obs_frame, (size_t)HX_OBS_FRAME * n);
-  rc |= dalloc(s, &s->p.priv_frame, (size_t)HX_PRIV_FRAME * n);
+  rc |= dalloc(s, &s->p.obs_frame, (size_t)s->obs_f * n);
+  rc |= dalloc(s, &s->p.priv_frame, (size_t)s->priv_f * n);
   rc |= dalloc(s, &s->p.rew, n);
   rc |= dalloc(s, &s->p.reset, n);
   rc |= dalloc(s, &s->p.timeout, n);
@@ -779,21 +818,22 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS + 2);
   rc |= dalloc(s, &s->p.stat_cnt, 1);
   rc |= dalloc(s, &s->timeout_visible, n);
-  for (int i = 0; i < 2; ++i) { rc |= dalloc(s, &s->obs[i], n * HX_OBS_LD); rc |= dalloc(s, &s->priv[i], n * HX_PRIV_LD); }
+  for (int i = 0; i < 2; ++i) { rc |= dalloc(s, &s->obs[i], n * s->obs_ld); rc |= dalloc(s, &s->priv[i], n * s->priv_ld); }
   if (rc) return -3;
   s->obs_cur = s->obs[0]; s->priv_cur = s->priv[0];
   // initial state: actor creation pose, identity orientation, everything else zero; last_feet_z = 0.05 (hector_env.py:48)
-  std::vector<float> st((size_t)S_STATE_SIZE * n, 0.f);
+  const SLay& SL_ = s->L;
+  std::vector<float> st((size_t)SL_.SIZE * n, 0.f);
   for (size_t e = 0; e < n; ++e) {
     for (int k = 0; k < 3; ++k) {
-      st[(size_t)(S_ROOT_POS + k) * n + e] = start_pos_h ? start_pos_h[e * 3 + k] : 0.f;
-      st[(size_t)(S_ORIGIN + k) * n + e] = origins_h ? origins_h[e * 3 + k] : 0.f;
+      st[(size_t)(SL_.ROOT_POS + k) * n + e] = start_pos_h ? start_pos_h[e * 3 + k] : 0.f;
+      st[(size_t)(SL_.ORIGIN + k) * n + e] = origins_h ? origins_h[e * 3 + k] : 0.f;
     }
-    st[(size_t)(S_ROOT_QUAT + 3) * n + e] = 1.f;
-    st[(size_t)S_LAST_FEET_Z * n + e] = 0.05f;
-    st[(size_t)(S_LAST_FEET_Z + 1) * n + e] = 0.05f;
-    st[(size_t)S_FRICTION * n + e] = friction_h ? friction_h[e] : 1.f;
-    st[(size_t)S_BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : HXM_MASS[0];
+    st[(size_t)(SL_.ROOT_QUAT + 3) * n + e] = 1.f;
+    st[(size_t)SL_.LAST_FEET_Z * n + e] = 0.05f;
+    st[(size_t)(SL_.LAST_FEET_Z + 1) * n + e] = 0.05f;
+    st[(size_t)SL_.FRICTION * n + e] = friction_h ? friction_h[e] : 1.f;
+    st[(size_t)SL_.BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : (s->nd == HX_NUM_DOF ? HXM_MASS[0] : HXF_MASS0);
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
   if (dalloc(s, &s->cfg_d, 1)) return -3;
@@ -866,7 +906,8 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   A.rng_step = s->rng_step++;
   // reset counter: ping-pong pair; the stack kernel of step t zeroes the counter step t+1 will use
   s->p.num_reset = s->num_reset2[s->parity];
-  hipLaunchKernelGGL(hx_env_step_kernel, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
+  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
   if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }
@@ -878,6 +919,7 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   k.num_reset = s->num_reset2[s->parity]; k.num_reset_next = s->num_reset2[s->parity ^ 1];
   k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
   k.n = n; k.clip = s->cfg.clip_observations;
+  k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld;
   hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
   s->obs_cur = od; s->priv_cur = pd;
   s->parity ^= 1;
@@ -908,13 +950,13 @@ extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
     case HX_BUF_TIMEOUT: *dptr = s->p.timeout; break;
     case HX_BUF_TIMEOUT_VISIBLE: *dptr = s->timeout_visible; break;
     case HX_BUF_EP_LEN: *dptr = s->p.ep_len; break;
-    case HX_BUF_COMMANDS: *dptr = s->p.st + (size_t)S_CMD * s->cfg.num_envs; break;
+    case HX_BUF_COMMANDS: *dptr = s->p.st + (size_t)s->L.CMD * s->cfg.num_envs; break;
     case HX_BUF_TORQUES: *dptr = s->p.torques; break;
     case HX_BUF_CONTACT: *dptr = s->p.contact; break;
     case HX_BUF_BODY_STATE: *dptr = s->p.bodies; break;
     case HX_BUF_EPISODE_SUMS: *dptr = s->p.ep_sums; break;
-    case HX_BUF_FEET_AIR_TIME: *dptr = s->p.st + (size_t)S_AIR * s->cfg.num_envs; break;
-    case HX_BUF_FEET_HEIGHT: *dptr = s->p.st + (size_t)S_FEET_H * s->cfg.num_envs; break;
+    case HX_BUF_FEET_AIR_TIME: *dptr = s->p.st + (size_t)s->L.AIR * s->cfg.num_envs; break;
+    case HX_BUF_FEET_HEIGHT: *dptr = s->p.st + (size_t)s->L.FEET_H * s->cfg.num_envs; break;
     case HX_BUF_NUM_RESET: *dptr = s->num_reset2[s->parity ^ 1]; break;
     default: hx_set_error("hx_sim_buffer: unknown id"); return -2;
   }
@@ -923,23 +965,25 @@ extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
 
 extern "C" int hx_sim_get_state(hx_sim* s, float* root_h, float* q_h, float* qd_h) {
   const size_t n = s->cfg.num_envs;
-  std::vector<float> st((size_t)33 * n);
+  const int nd = s->nd;
+  std::vector<float> st((size_t)(13 + 2 * nd) * n);
   HX_CHECK(hipStreamSynchronize(s->stream));
   HX_CHECK(hipMemcpy(st.data(), s->p.st, st.size() * sizeof(float), hipMemcpyDeviceToHost));
   for (size_t e = 0; e < n; ++e) {
     for (int k = 0; k < 13; ++k) root_h[e * 13 + k] = st[(size_t)k * n + e];
-    for (int j = 0; j < 10; ++j) { q_h[e * 10 + j] = st[(size_t)(S_Q + j) * n + e]; qd_h[e * 10 + j] = st[(size_t)(S_QD + j) * n + e]; }
+    for (int j = 0; j < nd; ++j) { q_h[e * nd + j] = st[(size_t)(s->L.Q + j) * n + e]; qd_h[e * nd + j] = st[(size_t)(s->L.QD + j) * n + e]; }
   }
   return 0;
 }
 
 extern "C" int hx_sim_set_state(hx_sim* s, const float* root_h, const float* q_h, const float* qd_h) {
   const size_t n = s->cfg.num_envs;
-  std::vector<float> st((size_t)33 * n);
+  const int nd = s->nd;
+  std::vector<float> st((size_t)(13 + 2 * nd) * n);
   HX_CHECK(hipStreamSynchronize(s->stream));
   for (size_t e = 0; e < n; ++e) {
     for (int k = 0; k < 13; ++k) st[(size_t)k * n + e] = root_h[e * 13 + k];
-    for (int j = 0; j < 10; ++j) { st[(size_t)(S_Q + j) * n + e] = q_h[e * 10 + j]; st[(size_t)(S_QD + j) * n + e] = qd_h[e * 10 + j]; }
+    for (int j = 0; j < nd; ++j) { st[(size_t)(s->L.Q + j) * n + e] = q_h[e * nd + j]; st[(size_t)(s->L.QD + j) * n + e] = qd_h[e * nd + j]; }
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
   return 0;
@@ -951,7 +995,7 @@ extern "C" int hx_sim_set_commands(hx_sim* s, const float* cmd_h) {
   for (size_t e = 0; e < n; ++e)
     for (int k = 0; k < 4; ++k) c[(size_t)k * n + e] = cmd_h[e * 4 + k];
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipMemcpy(s->p.st + (size_t)S_CMD * n, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
+  HX_CHECK(hipMemcpy(s->p.st + (size_t)s->L.CMD * n, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -959,7 +1003,7 @@ extern "C" int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h)
   const size_t n = s->cfg.num_envs;
   std::vector<float> v(6 * n);
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipMemcpy(v.data(), s->p.st + (size_t)S_BLV * n, v.size() * sizeof(float), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(v.data(), s->p.st + (size_t)s->L.BLV * n, v.size() * sizeof(float), hipMemcpyDeviceToHost));
   for (size_t e = 0; e < n; ++e)
     for (int k = 0; k < 3; ++k) { lin_h[e * 3 + k] = v[(size_t)k * n + e]; ang_h[e * 3 + k] = v[(size_t)(3 + k) * n + e]; }
   return 0;

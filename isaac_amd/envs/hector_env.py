@@ -30,14 +30,14 @@ BASE_MASS = 8.15528                                    # collapsed base link (to
 PHYS = dict(contact_kn=4.0e4, contact_dn=4.0e2, friction_veps=2.0e-2, limit_k=2.0e3, limit_d=2.0e1)
 
 
-def creation_randomisation(cfg, num_envs, env_origins):
+def creation_randomisation(cfg, num_envs, env_origins, base_mass=BASE_MASS):
     """Per-env friction, base mass and start pose, drawn with the same generators in the same order as the
     reference's _create_envs loop (legged_robot.py:650-664 with callbacks :244-301), so equal seeds give
     equal robots.  torch's CPU generator is used when torch is importable (plumbing only)."""
     fr = cfg.domain_rand
     start = np.array(env_origins, np.float32).copy()
     friction = np.ones(num_envs, np.float32)
-    mass = np.full(num_envs, BASE_MASS, np.float32)
+    mass = np.full(num_envs, base_mass, np.float32)
     try:
         import torch
         rand = lambda *s: torch.rand(*s).numpy()
@@ -57,11 +57,14 @@ def creation_randomisation(cfg, num_envs, env_origins):
             friction[i] = coeffs[i]
         if getattr(fr, "randomize_base_mass", False):
             lo, hi = fr.added_mass_range
-            mass[i] = np.float32(BASE_MASS + np.random.uniform(lo, hi))
+            mass[i] = np.float32(base_mass + np.random.uniform(lo, hi))
     return friction, mass, start
 
 
 class HectorFreeEnv(VecEnv):
+    # what a sibling task of the family overrides (HectorFullFreeEnv below)
+    DOF_NAMES, BODY_NAMES, URDF_EFFORT, BASE_MASS = DOF_NAMES, BODY_NAMES, URDF_EFFORT, BASE_MASS
+
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, stream=None,
                  creation=None, init_pack=None, env_range=None):
         """env_range=(lo, hi): this object simulates envs lo..hi-1 of the logical batch of cfg.env.num_envs robots
@@ -97,19 +100,25 @@ class HectorFreeEnv(VecEnv):
         self.num_obs = cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
-        self.num_dof = self.num_dofs = 10
-        self.num_bodies = 11
+        DOF_NAMES, BODY_NAMES, URDF_EFFORT = self.DOF_NAMES, self.BODY_NAMES, self.URDF_EFFORT
+        nd = len(DOF_NAMES)
+        self.num_dof = self.num_dofs = nd
+        self.num_bodies = len(BODY_NAMES)
         self.dof_names, self.body_names = DOF_NAMES, BODY_NAMES
-        if (self.num_obs, self.num_privileged_obs, self.num_actions) != (capi.NUM_OBS, capi.NUM_PRIV, 10):
-            raise ValueError("HectorFreeEnv serves the hector layout only: 615 / 1050 / 10")
+        self.obs_frame, self.priv_frame = 11 + 3 * nd, 40 + 3 * nd                     # 41 / 70, with arms 65 / 94
+        self.obs_ld, self.priv_ld = -(-15 * self.obs_frame // 4) * 4, -(-15 * self.priv_frame // 4) * 4
+        if (self.num_obs, self.num_privileged_obs, self.num_actions) != (15 * self.obs_frame, 15 * self.priv_frame, nd):
+            raise ValueError(f"{type(self).__name__} serves the {15 * self.obs_frame} / {15 * self.priv_frame} / {nd} layout only")
         self.feet_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.foot_name in n]
         self.knee_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.knee_name in n]
         self.termination_contact_indices = [i for k in cfg.asset.terminate_after_contacts_on
                                             for i, n in enumerate(BODY_NAMES) if k in n]
         self.penalised_contact_indices = [i for k in cfg.asset.penalize_contacts_on
                                           for i, n in enumerate(BODY_NAMES) if k in n]
-        assert self.feet_indices == [5, 10] and self.knee_indices == [4, 9]
-        assert sorted(self.termination_contact_indices) == [0, 3, 8] == sorted(self.penalised_contact_indices)
+        nl = nd // 2
+        assert self.feet_indices == [5, nl + 5] and self.knee_indices == [4, nl + 4]
+        assert sorted(self.penalised_contact_indices) == [0, 3, nl + 3]
+        assert sorted(self.termination_contact_indices) == ([0, 3, 8] if nd == 10 else [0, 3, 6, 7, 8, 12, 15, 16, 17])
 
         # ---- create_sim (hector_env.py:114-133): terrain first, then the robots
         n = self.total_envs
@@ -133,7 +142,7 @@ class HectorFreeEnv(VecEnv):
                 self.env_origins = self._terrain_origins(cfg, n, self.terrain)
             else:
                 self.env_origins = self._grid_origins(cfg, n)
-            friction, mass, start = creation_randomisation(cfg, n, self.env_origins)
+            friction, mass, start = creation_randomisation(cfg, n, self.env_origins, self.BASE_MASS)
         self._terrain_grid = terrain_grid
         if env_range is not None:
             sl = slice(self.env_lo, self.env_hi)
@@ -151,14 +160,15 @@ class HectorFreeEnv(VecEnv):
         c.clip_actions = cfg.normalization.clip_actions
         c.clip_observations = cfg.normalization.clip_observations
         self.default_dof_pos = np.array([cfg.init_state.default_joint_angles[nm] for nm in DOF_NAMES], np.float32)
-        self.p_gains, self.d_gains = np.zeros(10, np.float32), np.zeros(10, np.float32)
+        self.p_gains, self.d_gains = np.zeros(nd, np.float32), np.zeros(nd, np.float32)
         for i, nm in enumerate(DOF_NAMES):           # substring match, legged_robot.py:486-500
             for key in cfg.control.stiffness:
                 if key in nm:
                     self.p_gains[i] = cfg.control.stiffness[key]
                     self.d_gains[i] = cfg.control.damping[key]
         self.torque_limits = (np.array(URDF_EFFORT, np.float32) * np.float32(cfg.safety.torque_limit)).astype(np.float32)
-        for j in range(10):
+        c.num_dof = nd
+        for j in range(nd):
             c.default_dof_pos[j] = self.default_dof_pos[j]
             c.p_gains[j], c.d_gains[j] = self.p_gains[j], self.d_gains[j]
             c.torque_limits[j] = self.torque_limits[j]
@@ -168,12 +178,8 @@ class HectorFreeEnv(VecEnv):
         c.add_noise = int(cfg.noise.add_noise)
         c.noise_level = cfg.noise.noise_level
         ns, os_ = cfg.noise.noise_scales, self.obs_scales
-        self.noise_scale_vec = np.zeros(capi.OBS_FRAME, np.float32)      # hector_env.py:135-155
-        self.noise_scale_vec[5:15] = ns.dof_pos * os_.dof_pos
-        self.noise_scale_vec[15:25] = ns.dof_vel * os_.dof_vel
-        self.noise_scale_vec[35:38] = ns.ang_vel * os_.ang_vel
-        self.noise_scale_vec[38:41] = ns.quat * os_.quat
-        for k in range(capi.OBS_FRAME):
+        self.noise_scale_vec = self._noise_scale_vec(ns, os_)
+        for k in range(self.obs_frame):
             c.noise_scale_vec[k] = self.noise_scale_vec[k]
         c.push_robots = int(dr.push_robots)
         c.push_interval = int(dr.push_interval)
@@ -243,6 +249,15 @@ class HectorFreeEnv(VecEnv):
         # constructor tail: reset_idx(all) + compute_observations (hector_env.py:50-51)
         self._reset_all(init_pack)
 
+    def _noise_scale_vec(self, ns, os_):
+        """hector_env.py:135-155 (the last slice is [38:42] on a 41-vector there)"""
+        v = np.zeros(self.obs_frame, np.float32)
+        v[5:15] = ns.dof_pos * os_.dof_pos
+        v[15:25] = ns.dof_vel * os_.dof_vel
+        v[35:38] = ns.ang_vel * os_.ang_vel
+        v[38:41] = ns.quat * os_.quat
+        return v
+
     def _terrain_origins(self, cfg, n, terrain):
         """legged_robot.py:687-697: a random level per robot, tile type by robot index."""
         max_init_level = cfg.terrain.max_init_terrain_level
@@ -277,8 +292,8 @@ class HectorFreeEnv(VecEnv):
 
     def _refresh_views(self):
         n = self.num_envs
-        self.obs_buf = self._buf(capi.BUF_OBS, (n, capi.NUM_OBS), strides=(capi.OBS_LD * 4, 4))
-        self.privileged_obs_buf = self._buf(capi.BUF_PRIV, (n, capi.NUM_PRIV), strides=(capi.PRIV_LD * 4, 4))
+        self.obs_buf = self._buf(capi.BUF_OBS, (n, self.num_obs), strides=(self.obs_ld * 4, 4))
+        self.privileged_obs_buf = self._buf(capi.BUF_PRIV, (n, self.num_privileged_obs), strides=(self.priv_ld * 4, 4))
         self.rew_buf = self._buf(capi.BUF_REW, (n,))
         self.reset_buf = self._buf(capi.BUF_RESET, (n,), np.uint8)
         self.time_out_buf = self._buf(capi.BUF_TIMEOUT, (n,), np.uint8)
@@ -331,7 +346,7 @@ class HectorFreeEnv(VecEnv):
     # ------------------------------------------------------------------ state access (tests, play-style scripts)
     def get_state(self):
         n = self.num_envs
-        root, q, qd = np.empty((n, 13), np.float32), np.empty((n, 10), np.float32), np.empty((n, 10), np.float32)
+        root, q, qd = np.empty((n, 13), np.float32), np.empty((n, self.num_dof), np.float32), np.empty((n, self.num_dof), np.float32)
         capi.check(self._L.hx_sim_get_state(self._h, capi.ptr(root), capi.ptr(q), capi.ptr(qd)), "get_state")
         return root, q, qd
 
@@ -380,11 +395,11 @@ class HectorFreeEnv(VecEnv):
 
     @property
     def torques(self):
-        return self._buf(capi.BUF_TORQUES, (10, self.num_envs)).numpy().T
+        return self._buf(capi.BUF_TORQUES, (self.num_dof, self.num_envs)).numpy().T
 
     @property
     def contact_forces(self):
-        return self._buf(capi.BUF_CONTACT, (11, 3, self.num_envs)).numpy().transpose(2, 0, 1)
+        return self._buf(capi.BUF_CONTACT, (self.num_bodies, 3, self.num_envs)).numpy().transpose(2, 0, 1)
 
     def episode_stats(self):
         """extras['episode'] of legged_robot.py:198-201 averaged over the envs that reset since the last call,
@@ -509,3 +524,28 @@ class PipelinedHectorEnv(VecEnv):
     def close(self):
         for s in self.shards:
             s.close()
+
+
+class HectorFullFreeEnv(HectorFreeEnv):
+    """Task `hector_full` (reference humanoid/envs/custom/hector_w_arm_env.py HectorFullFreeEnv): the same biped with its
+    two 4-joint arms actuated, 18 DoF in Isaac Gym's order (L leg, L arm, R leg, R arm), observation frames 65 / 94 wide.
+    Same kernel source as hector, instantiated with the arm chains (hx_sim_cfg.num_dof = 18)."""
+    DOF_NAMES = ["L_hip_joint", "L_hip_roll_joint", "L_thigh_joint", "L_calf_joint", "L_toe_joint",
+                 "L_shoulder_yaw_joint", "L_shoulder_pitch_joint", "L_shoulder_roll_joint", "L_elbow_joint",
+                 "R_hip_joint", "R_hip_roll_joint", "R_thigh_joint", "R_calf_joint", "R_toe_joint",
+                 "R_shoulder_yaw_joint", "R_shoulder_pitch_joint", "R_shoulder_roll_joint", "R_elbow_joint"]
+    BODY_NAMES = ["base", "L_hip", "L_hip2", "L_thigh", "L_calf", "L_toe", "L_twist", "L_shoulder", "L_roll", "L_elbow",
+                  "R_hip", "R_hip2", "R_thigh", "R_calf", "R_toe", "R_twist", "R_shoulder", "R_roll", "R_elbow"]
+    # robot_w_arm.urdf <limit effort=...>: the right elbow carries 24 where the other arm joints carry 17
+    URDF_EFFORT = [33.5, 33.5, 33.5, 67.0, 33.5, 17.0, 17.0, 17.0, 17.0, 33.5, 33.5, 33.5, 67.0, 33.5, 17.0, 17.0, 17.0, 24.0]
+    BASE_MASS = 4.982                                   # collapsed base link of robot_w_arm.urdf (tools/compile_urdf.py --full)
+
+    def _noise_scale_vec(self, ns, os_):
+        """hector_w_arm_env.py:157-161, overlapping slices included (index 58 ends up with the angular-velocity scale)"""
+        v = np.zeros(self.obs_frame, np.float32)
+        v[5:23] = ns.dof_pos * os_.dof_pos
+        v[23:41] = ns.dof_vel * os_.dof_vel
+        v[41:59] = 0.0
+        v[58:61] = ns.ang_vel * os_.ang_vel
+        v[61:65] = ns.quat * os_.quat
+        return v

@@ -210,6 +210,43 @@ def main_full():
              "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": contacts}
     with open(os.path.join(ROOT, "isaac_amd/assets/hector_full_model.json"), "w") as f:
         json.dump(model, f, indent=1)
+    # ---- C header for the kernels: per-side table (leg 5 + arm 4 bodies of 16 floats, then 5 corner blocks of 24
+    #      floats: thigh, toe, twist, shoulder, elbow) and the base constants
+    def flit(v):
+        t = "%.9g" % v
+        if "." not in t and "e" not in t and "n" not in t:
+            t += ".0"
+        return t + "f"
+
+    def Io(bd):
+        c = np.array(bd["com"]); m = bd["mass"]
+        I = np.array(bd["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
+        return [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+
+    by_body = {c["body"]: c for c in contacts}
+    sidec = []
+    for side in range(2):
+        row = []
+        for k in range(9):
+            bd = bodies[1 + side * 9 + k]
+            row += list(bd["offset"]) + list(bd["mass"] * np.array(bd["com"])) + Io(bd) + [bd["mass"], bd["lower"], bd["upper"], bd["velocity"]]
+        for nm in ("thigh", "toe", "twist", "shoulder", "elbow"):
+            c = by_body.get(name_to_idx[("L_" if side == 0 else "R_") + nm])
+            assert c is not None, nm
+            row += [x for pt in c["points"] for x in pt]
+        assert len(row) == 9 * 16 + 5 * 24
+        sidec += row
+    L = ["// GENERATED by tools/compile_urdf.py --full from the reference's robot_w_arm.urdf -- do not edit.",
+         "// 19 collapsed bodies / 18 revolute joints in Isaac Gym order: L leg, L arm, R leg, R arm.",
+         "#pragma once", "#define HXF_SIDE_STRIDE 264",
+         "__device__ static const float HXF_SIDEC[528] = {%s};" % ", ".join(flit(v) for v in sidec),
+         "__device__ static const float HXF_BASE_PTS[24] = {%s};" % ", ".join(flit(x) for pt in contacts[0]["points"] for x in pt),
+         "static constexpr float HXF_IO[6] = {%s};" % ", ".join(flit(v) for v in Io(bodies[0])),
+         "static constexpr float HXF_H[3] = {%s};" % ", ".join(flit(bodies[0]["mass"] * x) for x in bodies[0]["com"]),
+         "static constexpr float HXF_MASS0 = %s;" % flit(bodies[0]["mass"]),
+         "static constexpr float HXF_EFFORT[18] = {%s};" % ", ".join(flit(b["effort"]) for b in bodies[1:])]
+    with open(os.path.join(ROOT, "isaac_amd/csrc/hx_model_data_full.h"), "w") as f:
+        f.write("\n".join(L) + "\n")
     for i, b in enumerate(bodies):
         print(i, b["name"], "parent", b["parent"], "m=%.5f" % b["mass"], b.get("joint"), b.get("axis"))
     print("total mass %.5f" % model["total_mass"])
