@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--task", default="hector", choices=["hector", "hector_full"],
+                    help="hector is BASELINE.json's metric config; hector_full (18 DoF, SURVEY 8f-4) is a side measurement")
     ap.add_argument("--shards", type=int, default=1, help="env shards per GPU driven round-robin on separate streams (1 = off; measured slower than the deferred-critic overlap, see DESIGN.md)")
     ap.add_argument("--terrain", default="trimesh", choices=["trimesh", "heightfield", "plane"],
                     help="terrain.mesh_type; 'trimesh' is the reference's default for the hector task (hector_config.py:45)")
@@ -116,8 +118,8 @@ def main():
     __graft_entry__.build()
     from isaac_amd import capi
     from isaac_amd.parallel import init_comm
-    from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO
-    from isaac_amd.envs.hector_env import HectorFreeEnv, PipelinedHectorEnv, class_to_dict
+    from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO, HectorFullCfg, HectorFullCfgPPO
+    from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv, PipelinedHectorEnv, class_to_dict
     from isaac_amd.algo.on_policy_runner import OnPolicyRunner
     from isaac_amd.utils.helpers import set_seed
 
@@ -130,14 +132,17 @@ def main():
     local = comm.local_rank % ndev       # one rank per GPU under the driver; wraps only in the one-GPU gloo-staged rehearsal
     capi.check(capi.lib().hx_set_device(local), "hx_set_device")
 
-    env_cfg, train_cfg = HectorCfg(), HectorCfgPPO()
+    full = args.task == "hector_full"
+    if full and args.shards > 1:
+        raise SystemExit("--shards applies to the hector task only")
+    env_cfg, train_cfg = (HectorFullCfg(), HectorFullCfgPPO()) if full else (HectorCfg(), HectorCfgPPO())
     env_cfg.env.num_envs = args.envs
     env_cfg.terrain.mesh_type = args.terrain
     env_cfg.seed = set_seed(train_cfg.seed + comm.rank)
     if args.shards > 1:
         env = PipelinedHectorEnv(env_cfg, sim_device=f"cuda:{local}", headless=True, num_shards=args.shards)
     else:
-        env = HectorFreeEnv(env_cfg, sim_device=f"cuda:{local}", headless=True)
+        env = (HectorFullFreeEnv if full else HectorFreeEnv)(env_cfg, sim_device=f"cuda:{local}", headless=True)
     tcfg = class_to_dict(train_cfg)
     if args.dtype != "f32":
         tcfg["algorithm"]["mlp_dtype"] = args.dtype          # extra PPO keyword of this build (hx_ppo_set_compute_dtype)
@@ -168,11 +173,13 @@ def main():
     if comm.rank == 0:
         env_steps = T * args.envs * world * args.steps
         value = env_steps / elapsed
-        out = {"metric": f"env-steps/sec (whole node), hector {args.envs} envs/GPU", "value": value, "unit": "env-steps/s",
+        dims = lambda d: "[" + ",".join(str(x) for x in d) + "]"
+        out = {"metric": f"env-steps/sec (whole node), {args.task} {args.envs} envs/GPU", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": f"hector {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
-                                      "update 2 epochs x 4 minibatches, fp32 HIP sim + MLP actor [512,256,128] / critic [768,256,128]"
+               "config": {"workload": f"{args.task} {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
+                                      f"update {train_cfg.algorithm.num_learning_epochs} epochs x {train_cfg.algorithm.num_mini_batches} minibatches, fp32 HIP sim + MLP actor {dims(train_cfg.policy.actor_hidden_dims)} / "
+                                      f"critic {dims(train_cfg.policy.critic_hidden_dims)}"
                                       + ("" if args.dtype == "f32" else " (bf16 forward/dgrad MFMA, fp32 master weights)"),
                           "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
                           "terrain": args.terrain, "env_shards": args.shards, "collection_s": runner.last_perf.get("collection_time"),
@@ -180,7 +187,7 @@ def main():
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            traffic, traffic_detail = pmc_traffic(k["name"]) if (args.envs == 4096 and args.terrain == "trimesh" and args.shards == 1) else (None, None)
+            traffic, traffic_detail = pmc_traffic(k["name"]) if (args.envs == 4096 and args.terrain == "trimesh" and args.shards == 1 and not full) else (None, None)
             # bf16 mode: the same kernel ids run on the bf16 matrix cores (dense peak 2.5 PFLOP/s); with fp32 operands in HBM
             # those products are memory-bound, which is what the small fraction of that peak says
             peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0
@@ -191,8 +198,8 @@ def main():
                                "flop_per_launch": k["flops"] / max(1, k["launches"]),
                                "all_gemm_kernels": (prof_all or prof)["kernels"],
                                "all_gemm_kernels_from": "warm-up iterations (all launches bracketed)" if prof_all else "timed region",
-                               "whole_iteration_mfma_frac": value / world * FLOP_PER_ENV_STEP / (peak * 1e12)}
-        if not args.no_cpu_baseline and world == 1:            # rank 0 at N = 1 only; other ranks wait at the barrier below
+                               "whole_iteration_mfma_frac": None if full else value / world * FLOP_PER_ENV_STEP / (peak * 1e12)}
+        if not args.no_cpu_baseline and world == 1 and not full:            # rank 0 at N = 1 only; other ranks wait at the barrier below
             try:
                 out["cpu_baseline"] = cpu_baseline(terrain=args.terrain)
             except Exception as e:                        # the baseline must never take the GPU number down with it

@@ -22,7 +22,6 @@ from datetime import datetime
 
 import numpy as np
 
-from .. import capi
 from .ppo import PPO, ActorCritic
 
 _CLASSES = {"ActorCritic": ActorCritic, "PPO": PPO}
@@ -48,7 +47,7 @@ class OnPolicyRunner:
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions],
-                              obs_ld=capi.OBS_LD, priv_ld=capi.PRIV_LD)
+                              obs_ld=getattr(env, "obs_ld", None), priv_ld=getattr(env, "priv_ld", None))
         self.log_dir = log_dir
         self.writer = None
         self.tot_timesteps = 0

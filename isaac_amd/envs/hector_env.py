@@ -471,6 +471,7 @@ class PipelinedHectorEnv(VecEnv):
                                      env_range=(i * per, (i + 1) * per)) for i in range(num_shards)]
         s0 = self.shards[0]
         self.cfg, self.num_envs, self.num_obs, self.num_privileged_obs, self.num_actions = cfg, n, s0.num_obs, s0.num_privileged_obs, s0.num_actions
+        self.obs_ld, self.priv_ld = s0.obs_ld, s0.priv_ld
         self.max_episode_length, self.dt, self.device = s0.max_episode_length, s0.dt, s0.device
         self.reward_names = s0.reward_names
         self.stream = s0.stream

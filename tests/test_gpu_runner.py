@@ -129,3 +129,26 @@ def test_c_rollout_equals_stepwise_api(hxlib):
     np.testing.assert_allclose(a["rewards"], b["rewards"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(a["final_obs"], b["final_obs"], rtol=0, atol=5e-3)
     np.testing.assert_allclose(a["adv"], b["adv"], rtol=0, atol=5e-3)
+
+
+def test_hector_full_trains_through_the_registry(hxlib, tmp_path):
+    """The 18-DoF sibling task (reference humanoid/envs/__init__.py:49, hector_w_arm_config.py) end to end: registry ->
+    HectorFullFreeEnv (kernel instantiated with the arm chains) -> runner with its actor [768,512,128] / critic [768]*3."""
+    from isaac_amd.envs import task_registry
+    from isaac_amd.utils import get_args
+    args = get_args(["--task=hector_full", "--headless", "--num_envs", "128", "--max_iterations", "2", "--seed", "3"])
+    env, env_cfg = task_registry.make_env("hector_full", args=args)
+    assert (env.num_obs, env.num_privileged_obs, env.num_actions) == (975, 1410, 18)
+    runner, train_cfg = task_registry.make_alg_runner(env, name="hector_full", args=args, log_root=str(tmp_path))
+    runner.learn(2, init_at_random_ep_len=True)
+    rows = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
+    assert len(rows) == 2 and np.isfinite(rows[-1]["Loss/value_function"]) and np.isfinite(rows[-1]["Loss/surrogate"])
+    sd = runner.alg.actor_critic.state_dict()
+    assert sd["actor.0.weight"].shape == (768, 975) and sd["critic.0.weight"].shape == (768, 1410) and sd["std"].shape == (18,)
+    obs = env.get_observations().numpy()
+    assert obs.shape == (128, 975) and np.all(np.isfinite(obs))
+    act = runner.get_inference_policy()(env.get_observations()).numpy()
+    assert act.shape == (128, 18) and np.all(np.isfinite(act))
+    root, q, qd = env.get_state()
+    assert q.shape == (128, 18) and np.all(np.isfinite(q)) and np.all(np.isfinite(root))
+    env.close()

@@ -14,8 +14,8 @@ import numpy as np
 import pytest
 
 from isaac_amd import capi
-from isaac_amd.envs.configs import HectorCfg
-from isaac_amd.envs.hector_env import HectorFreeEnv
+from isaac_amd.envs.configs import HectorCfg, HectorFullCfg
+from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -23,7 +23,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def make_env(fx):
     n, steps, seed, sc0, noise = (int(x) for x in fx["meta"])
-    cfg = HectorCfg()
+    full = "task" in fx and str(fx["task"]) == "hector_full"          # fixture G: the 18-DoF sibling task
+    cfg = HectorFullCfg() if full else HectorCfg()
     cfg.env.num_envs = n
     cfg.noise.add_noise = bool(noise)
     cfg.seed = seed
@@ -50,11 +51,11 @@ def make_env(fx):
             cfg.terrain.num_rows, cfg.terrain.num_cols = (int(x) for x in fx["terrain_origins"].shape[:2])
             cfg.terrain.terrain_length = cfg.terrain.terrain_width = float(fx["terrain_env_length"])
             creation["terrain_levels"], creation["terrain_origins"] = fx["init_terrain_levels"], fx["terrain_origins"]
-    env = HectorFreeEnv(cfg, sim_device="cuda:0", creation=creation, init_pack=fx["packs"][0])
+    env = (HectorFullFreeEnv if full else HectorFreeEnv)(cfg, sim_device="cuda:0", creation=creation, init_pack=fx["packs"][0])
     return env, n, steps, sc0
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_g"])
 def test_constructor_reset_and_first_observation(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -66,7 +67,8 @@ def test_constructor_reset_and_first_observation(hxlib, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_e", "env_rollout_f"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_e", "env_rollout_f",
+                                  "env_rollout_g"])
 def test_teacher_forced_steps(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -79,7 +81,7 @@ def test_teacher_forced_steps(hxlib, name):
             env.set_state(fx["root"][t - 1].astype(np.float32), fx["q"][t - 1].astype(np.float32), fx["qd"][t - 1].astype(np.float32))
         obs, priv, rew, reset, extras = env.step(fx["actions"][t], pack=fx["packs"][t + 1])
         o, p = obs.numpy(), priv.numpy()
-        e = dict(obs=np.abs(o[:, -41:] - fx["obs41"][t]).max(), priv=np.abs(p[:, -70:] - fx["priv70"][t]).max(),
+        e = dict(obs=np.abs(o[:, -env.obs_frame:] - fx["obs41"][t]).max(), priv=np.abs(p[:, -env.priv_frame:] - fx["priv70"][t]).max(),
                  rew=np.abs(rew.numpy() - fx["rew"][t]).max(), tau=np.abs(env.torques - fx["torques"][t]).max(),
                  contact=np.abs(env.contact_forces - fx["contact"][t]).max())
         for k, v in e.items():
