@@ -8,35 +8,42 @@ import pytest
 
 from isaac_amd import capi
 from isaac_amd.algo.ppo import PPO, ActorCritic
-from isaac_amd.envs.configs import HectorCfg
-from isaac_amd.envs.hector_env import HectorFreeEnv, creation_randomisation
+from isaac_amd.envs.configs import HectorCfg, HectorFullCfg
+from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv, creation_randomisation
 from isaac_amd.utils.helpers import set_seed
 
 pytestmark = pytest.mark.gpu
 N, T = 4096, 60
 
 
-def _creation(seed, n):
+TASKS = {"hector": (HectorCfg, HectorFreeEnv), "hector_full": (HectorFullCfg, HectorFullFreeEnv)}
+
+
+def _creation(seed, n, task="hector"):
     """Creation data of the default config (tile map) for n robots, drawn once on the host."""
     from isaac_amd.envs.terrain import HumanoidTerrain
-    cfg = HectorCfg()
+    cfg_cls, env_cls = TASKS[task]
+    cfg = cfg_cls()
+    cfg.terrain.mesh_type = "trimesh"                    # HectorFullCfg's own default is the plane
     cfg.env.num_envs = n
     set_seed(seed)
     ter = HumanoidTerrain(cfg.terrain, n)
-    probe = HectorFreeEnv.__new__(HectorFreeEnv)
+    probe = env_cls.__new__(env_cls)
     origins = probe._terrain_origins(cfg, n, ter)
-    fr, ms, start = creation_randomisation(cfg, n, origins)
+    fr, ms, start = creation_randomisation(cfg, n, origins, env_cls.BASE_MASS)
     grid = dict(heights=ter.heightsamples, horizontal_scale=cfg.terrain.horizontal_scale,
                 vertical_scale=cfg.terrain.vertical_scale, border_size=cfg.terrain.border_size)
     return dict(friction=fr, mass=ms, origins=origins, start=start, terrain=grid,
                 terrain_levels=probe.terrain_levels, terrain_types=probe.terrain_types)
 
 
-def _env(creation, lo, hi, seed):
-    cfg = HectorCfg()
+def _env(creation, lo, hi, seed, task="hector"):
+    cfg_cls, env_cls = TASKS[task]
+    cfg = cfg_cls()
+    cfg.terrain.mesh_type = "trimesh"
     cfg.env.num_envs = len(creation["friction"])
     cfg.seed = seed
-    return HectorFreeEnv(cfg, creation=creation, env_range=(lo, hi))
+    return env_cls(cfg, creation=creation, env_range=(lo, hi))
 
 
 def _roll(env, actions, ep_len):
@@ -48,24 +55,25 @@ def _roll(env, actions, ep_len):
     return out
 
 
-def test_full_batch_is_deterministic_and_batch_independent(hxlib):
+@pytest.mark.parametrize("task", list(TASKS))
+def test_full_batch_is_deterministic_and_batch_independent(hxlib, task):
     """4096 robots on the default tile map, 12 steps with resets and time-outs in them:
     (1) two runs from the same seed are bit-identical; (2) robots 1024..1087 simulated alone (a 64-robot simulator with
     env_id_offset 1024) produce bit-identical observations, rewards and resets -- nothing in a robot's step depends on
     the batch it is in (random streams are keyed by the global env id)."""
     seed = 5
-    cr = _creation(seed, N)
+    cr = _creation(seed, N, task)
     rng = np.random.default_rng(1)
-    acts = (0.6 * rng.standard_normal((12, N, 10))).astype(np.float32)
+    acts = (0.6 * rng.standard_normal((12, N, 10 if task == "hector" else 18))).astype(np.float32)
     ep = rng.integers(0, 2400, N).astype(np.int32)
     ep[::97] = 2398                                      # time-outs inside the window
-    a = _env(cr, 0, N, seed); ra = _roll(a, acts, ep); a.close()
-    b = _env(cr, 0, N, seed); rb = _roll(b, acts, ep); b.close()
+    a = _env(cr, 0, N, seed, task); ra = _roll(a, acts, ep); a.close()
+    b = _env(cr, 0, N, seed, task); rb = _roll(b, acts, ep); b.close()
     for (o1, p1, r1, d1), (o2, p2, r2, d2) in zip(ra, rb):
         assert np.array_equal(o1, o2) and np.array_equal(p1, p2) and np.array_equal(r1, r2) and np.array_equal(d1, d2)
     assert sum(int(d.sum()) for *_, d in ra) > 20        # the window does contain resets
     lo, hi = 1024, 1088
-    c = _env(cr, lo, hi, seed); rc = _roll(c, acts[:, lo:hi], ep[lo:hi]); c.close()
+    c = _env(cr, lo, hi, seed, task); rc = _roll(c, acts[:, lo:hi], ep[lo:hi]); c.close()
     for t, ((o1, p1, r1, d1), (o3, p3, r3, d3)) in enumerate(zip(ra, rc)):
         # one documented coupling: extras["time_outs"] staleness is per simulator, it does not enter obs / reward / done
         assert np.array_equal(o1[lo:hi], o3), f"obs differ at step {t}"
