@@ -42,6 +42,26 @@ def test_play_with_onnx_actor(hxlib, tmp_path):
     assert logger.state_log["dof_pos"]
 
 
+def test_play_hector_full(hxlib, tmp_path):
+    """The same script on the 18-DoF sibling task: overrides, a [975 -> 768 -> 512 -> 128 -> 18] actor from ONNX, traces."""
+    from isaac_amd.scripts.play import play
+    from isaac_amd.utils import get_args, onnx_io
+    rng = np.random.default_rng(4)
+    dims = [975, 768, 512, 128, 18]
+    layers = [((rng.standard_normal((o, i)) / np.sqrt(i)).astype(np.float32), (0.01 * rng.standard_normal(o)).astype(np.float32))
+              for i, o in zip(dims[:-1], dims[1:])]
+    src = onnx_io.save_actor(str(tmp_path / "full.onnx"), layers)
+    out = str(tmp_path / "out_full")
+    logger = play(get_args(["--task=hector_full", "--headless", "--onnx", src, "--play_steps", "30", "--play_out", out]))
+    d = np.load(os.path.join(out, "play_states.npz"))
+    assert d["dof_pos"].shape == (30,) and np.all(np.isfinite(d["base_vel_x"])) and np.all(np.isfinite(d["dof_torque"]))
+    np.testing.assert_allclose(d["command_x"], 0.5)
+    exported = onnx_io.load_actor(os.path.join(out, "policies", "locomotion_net.onnx"))
+    for (W, b), (W2, b2) in zip(layers, exported):
+        assert np.array_equal(W, W2) and np.array_equal(b, b2)
+    assert logger.state_log["dof_pos"]
+
+
 def test_device_inference_equals_onnx_chain(hxlib, tmp_path):
     """ActorCritic.load_actor_from_onnx + act_inference (hx_ppo_inference) against the numpy chain."""
     from isaac_amd.algo.ppo import PPO, ActorCritic
