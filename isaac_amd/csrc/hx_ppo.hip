@@ -448,17 +448,27 @@ struct HeadArgs {
   const float* row_mb; int M, A;
   float clip, vcoef, ecoef; int use_clipped_value_loss;
   float* dz3a; float* dz3c; float* slab; int slab_w;
+  int stage_c;    // 1: the critic's rows are staged in LDS like the actor's (narrow critics; hector).  0: a wide critic
+                  // (hector_full's 768) would need 130 KB and leave one workgroup per CU, so its rows are reduced to the
+                  // value while they stream in and re-read from L2 for the two later uses
 };
+// dynamic LDS of the loss head: staged rows of the actor (and of the critic when stage_c), both head weights, per-row results
+static inline size_t head_lds_bytes(int hw, int hwc, int A, bool stage_c) {
+  return (size_t)(HEAD_ROWS * (hw + 1) + (stage_c ? HEAD_ROWS * (hwc + 1) : 0) + A * hw + hwc + HEAD_ROWS * (A + 1) +
+                  HEAD_ROWS * (4 + A) + HEAD_ROWS) * sizeof(float);
+}
 template <int MA>   // register-array bound on the action count (16 for hector's 10, 32 otherwise): loops over MA are unrolled
 __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int hw = g.hw, hwc = g.hwc, A = g.A, hp = hw + 1, hpc = hwc + 1;
   float* sHa = sm;                       // [rows][hw+1]
-  float* sHc = sHa + HEAD_ROWS * hp;     // [rows][hwc+1]
-  float* sW = sHc + HEAD_ROWS * hpc;     // [A][hw]
+  const bool stage_c = g.stage_c != 0;
+  float* sHc = sHa + HEAD_ROWS * hp;     // [rows][hwc+1]   (empty when the critic is not staged)
+  float* sW = sHc + (stage_c ? HEAD_ROWS * hpc : 0);     // [A][hw]
   float* sWc = sW + A * hw;              // [hwc]
   float* sD = sWc + hwc;                 // [rows][A+1]  dmu, dv
   float* sL = sD + HEAD_ROWS * (A + 1);  // [rows][4+A]  kl, vloss, sloss, entropy, dsigma[A]
+  float* sV = sL + HEAD_ROWS * (4 + A);  // [rows]  value dot product of a critic that is not staged
   const int r0 = blockIdx.x * HEAD_ROWS;
   const int tid = threadIdx.x;
   // half a wave per row, 16 bytes per lane (widths are multiples of 64 floats): coalesced, no integer divisions
@@ -466,6 +476,7 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   for (int r = 2 * wave + (lane >> 5); r < HEAD_ROWS; r += 8) {
     const bool ok = (r0 + r) < g.M;
     const size_t grow = (size_t)(ok ? r0 + r : 0);
+    float vp = 0.f;
     for (int k = 4 * (lane & 31); k < hmax; k += 128) {      // one loop for both nets: two loads in flight per trip
       if (k < hw) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3a + grow * hw + k);
@@ -474,9 +485,19 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
       }
       if (k < hwc) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3c + grow * hwc + k);
+        if (stage_c) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sHc[r * hpc + k + q] = ok ? x[q] : 0.f;
+          for (int q = 0; q < 4; ++q) sHc[r * hpc + k + q] = ok ? x[q] : 0.f;
+        } else {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(g.W4c + k);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) vp = fmaf(x[q], w[q], vp);
+        }
       }
+    }
+    if (!stage_c) {                                          // uniform: the 32 lanes of the row's half-wave sum their parts
+      for (int o = 16; o > 0; o >>= 1) vp += __shfl_xor(vp, o);
+      if ((lane & 31) == 0) sV[r] = ok ? vp : 0.f;
     }
   }
   for (int i = tid; i < A * hw; i += 256) sW[i] = g.W4[i];
@@ -491,7 +512,7 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
 #pragma unroll
     for (int j = 0; j < MA; ++j) mu[j] = 0.f;
     float v = 0.f;
-    if (hw == hwc) {           // one pass over k for both nets (hector: 128 / 128)
+    if (hw == hwc && stage_c) {           // one pass over k for both nets (hector: 128 / 128)
       for (int k = part * per; k < (part + 1) * per; ++k) {
         const float x = sHa[r * hp + k];
         for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
@@ -502,7 +523,8 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
         const float x = sHa[r * hp + k];
         for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
       }
-      for (int k = part * perc; k < (part + 1) * perc; ++k) v = fmaf(sHc[r * hpc + k], sWc[k], v);
+      if (stage_c) { for (int k = part * perc; k < (part + 1) * perc; ++k) v = fmaf(sHc[r * hpc + k], sWc[k], v); }
+      else v = (part == 0) ? sV[r] : 0.f;
     }
     for (int o = 4; o > 0; o >>= 1) {
       for (int j = 0; j < A; ++j) mu[j] += __shfl_xor(mu[j], o);
@@ -597,8 +619,15 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
       if (k < hwc) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(sWc + k);
         f32x4 o;
+        f32x4 hc4;
+        if (stage_c) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float hc = sHc[r * hpc + k + q]; o[q] = dv * w[q] * (hc > 0.f ? 1.f : hc + 1.f); }
+          for (int q = 0; q < 4; ++q) hc4[q] = sHc[r * hpc + k + q];
+        } else {
+          hc4 = *reinterpret_cast<const f32x4*>(g.h3c + (size_t)(r0 + r) * hwc + k);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float hc = hc4[q]; o[q] = dv * w[q] * (hc > 0.f ? 1.f : hc + 1.f); }
         *reinterpret_cast<f32x4*>(g.dz3c + (size_t)(r0 + r) * hwc + k) = o;
       }
     }
@@ -613,7 +642,12 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   }
   for (int k = tid; k < hwc; k += 256) {
     float s = 0.f;
-    for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + A], sHc[r * hpc + k], s);
+    if (stage_c) {
+      for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sD[r * (A + 1) + A], sHc[r * hpc + k], s);
+    } else {
+      const int rows = (g.M - r0) < HEAD_ROWS ? (g.M - r0) : HEAD_ROWS;      // rows past M carry dv = 0 and are not read
+      for (int r = 0; r < rows; ++r) s = fmaf(sD[r * (A + 1) + A], g.h3c[(size_t)(r0 + r) * hwc + k], s);
+    }
     slab[A * hw + A + k] = s;
   }
   if (tid < A) {
@@ -1281,8 +1315,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   { const char* e = getenv("HX_ACTOR_WAVES"); s->actor_waves = (e && atoi(e) == 4) ? 4 : 8; }
   {
     const int ha_ = cfg->actor_hidden[2], hc_ = cfg->critic_hidden[2];
-    const size_t head_lds = (size_t)(HEAD_ROWS * (ha_ + 1) + HEAD_ROWS * (hc_ + 1) + A * ha_ + hc_ + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
-    if (head_lds > 64 * 1024) {      // only wide critics need the opt-in; hector's 43 KB launch keeps the default
+    const size_t head_lds = head_lds_bytes(ha_, hc_, A, head_lds_bytes(ha_, hc_, A, true) <= 64 * 1024);
+    if (head_lds > 64 * 1024) {      // a wide ACTOR last layer (the critic is then not staged); hector's 43 KB launch keeps the default
       HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
@@ -1586,7 +1620,8 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   h.stdp = s->params + s->std_off; h.sigma_old = s->sigma_old; h.row_mb = s->row_mb; h.M = M; h.A = A;
   h.clip = c.clip_param; h.vcoef = c.value_loss_coef; h.ecoef = c.entropy_coef; h.use_clipped_value_loss = c.use_clipped_value_loss;
   h.dz3a = s->dz_a[2]; h.dz3c = s->dz_c[2]; h.slab = s->head_slab; h.slab_w = s->head_slab_w;
-  const size_t shm = (size_t)(HEAD_ROWS * (hw + 1) + HEAD_ROWS * (hwc + 1) + A * hw + hwc + HEAD_ROWS * (A + 1) + HEAD_ROWS * (4 + A)) * sizeof(float);
+  h.stage_c = head_lds_bytes(hw, hwc, A, true) <= 64 * 1024;
+  const size_t shm = head_lds_bytes(hw, hwc, A, h.stage_c != 0);
   if (A <= 16) hipLaunchKernelGGL(hx_loss_head_kernel<16>, dim3(hblocks), dim3(256), shm, st, h);
   else hipLaunchKernelGGL(hx_loss_head_kernel<32>, dim3(hblocks), dim3(256), shm, st, h);
   HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw, hwc};
