@@ -415,8 +415,9 @@ class HectorCfgPPO(LeggedRobotCfgPPO):
 # ------------------------------------------------------------------------------------------------------------------
 # hector_full (reference humanoid/envs/custom/hector_w_arm_config.py): the same biped with its two 4-joint arms freed,
 # 18 DoF.  Written as what differs from HectorCfg; every value is pinned by tests/golden/configs.json.  The learner
-# runs this task's network shapes (tests/test_gpu_ppo_shapes.py) and the oracle reproduces its env glue
-# (tests/golden/env_rollout_g.npz); its env-step kernel is not built yet, so the task is not registered.
+# runs this task's network shapes (tests/test_gpu_ppo_shapes.py), the oracle reproduces its env glue
+# (tests/golden/env_rollout_g.npz) and the env-step kernel's 18-DoF instantiation replays that fixture
+# (tests/test_gpu_sim.py); registered as task `hector_full`.
 class HectorFullCfg(HectorCfg):
     class env(HectorCfg.env):
         num_single_obs = 65
@@ -494,3 +495,91 @@ class HectorFullCfgPPO(HectorCfgPPO):
 
     class runner(HectorCfgPPO.runner):
         experiment_name = 'hector_arm'
+
+
+# ---- sibling task `humanoid_ppo` (reference humanoid/envs/custom/humanoid_config.py: XBot-L, 12 DoF, 47 x 15 observations,
+# 73 x 3 privileged).  Configs only: written as what differs from HectorCfg (which the reference derived from this
+# one), every value pinned by tests/golden/configs.json.  The learner runs its network shapes
+# (tests/test_gpu_ppo_shapes.py); its env step is not built, so the task is not registered.
+class XBotLCfg(HectorCfg):
+    class env(HectorCfg.env):
+        num_single_obs = 47
+        num_observations = int(HectorCfg.env.frame_stack * num_single_obs)
+        single_num_privileged_obs = 73
+        c_frame_stack = 3
+        num_privileged_obs = int(c_frame_stack * single_num_privileged_obs)
+        num_actions = 12
+
+    class safety(HectorCfg.safety):
+        pos_limit = 1.0
+        vel_limit = 1.0
+
+    class asset(HectorCfg.asset):
+        file = '{LEGGED_GYM_ROOT_DIR}/resources/robots/XBot/urdf/XBot-L.urdf'
+        name = "XBot-L"
+        foot_name = "ankle_roll"
+        knee_name = "knee"
+        terminate_after_contacts_on = ['base_link']
+        penalize_contacts_on = ["base_link"]
+        self_collisions = 0
+
+    class terrain(HectorCfg.terrain):
+        terrain_proportions = [0.2, 0.2, 0.4, 0.1, 0.1, 0, 0]
+
+    class init_state(HectorCfg.init_state):
+        pos = [0.0, 0.0, 0.95]
+        default_joint_angles = {f'{side}_{j}_joint': 0. for side in ('left', 'right')
+                                for j in ('leg_roll', 'leg_yaw', 'leg_pitch', 'knee', 'ankle_pitch', 'ankle_roll')}
+
+    class control(HectorCfg.control):
+        stiffness = {'leg_roll': 200.0, 'leg_yaw': 200.0, 'leg_pitch': 350.0, 'knee': 350.0, 'ankle': 15}
+        damping = {'leg_roll': 10, 'leg_yaw': 10, 'leg_pitch': 10, 'knee': 10, 'ankle': 10}
+
+    class sim(HectorCfg.sim):
+        class physx(HectorCfg.sim.physx):
+            num_velocity_iterations = 1
+
+    class domain_rand(HectorCfg.domain_rand):
+        friction_range = [0.1, 2.0]
+        added_mass_range = [-5., 5.]
+        max_push_vel_xy = 0.2
+        action_delay = 0.5
+
+    class commands(HectorCfg.commands):
+        class ranges(HectorCfg.commands.ranges):
+            lin_vel_x = [-0.3, 0.6]
+
+    class rewards(HectorCfg.rewards):
+        base_height_target = 0.89
+        min_dist = 0.2
+        max_contact_force = 700
+
+        class scales(HectorCfg.rewards.scales):
+            joint_pos = 1.6
+            feet_clearance = 1.
+            feet_contact_number = 1.2
+            feet_air_time = 1.
+            feet_contact_forces = -0.01
+            tracking_lin_vel = 1.2
+            tracking_ang_vel = 1.1
+            vel_mismatch_exp = 0.5
+            low_speed = 0.2
+            track_vel_hard = 0.5
+            default_joint_pos = 0.5
+            orientation = 1.
+            base_height = 0.2
+            base_acc = 0.2
+            action_smoothness = -0.002
+            dof_vel = -5e-4
+            dof_acc = -1e-7
+            collision = -1.
+
+    class normalization(HectorCfg.normalization):
+        clip_observations = 18.
+        clip_actions = 18.
+
+
+class XBotLCfgPPO(HectorCfgPPO):
+    class runner(HectorCfgPPO.runner):
+        experiment_name = 'XBot_ppo'
+        max_iterations = 3001

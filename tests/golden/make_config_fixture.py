@@ -15,6 +15,9 @@ out = {"HectorCfg": helpers.class_to_dict(cfg_mod.HectorCfg()), "HectorCfgPPO": 
 _, cfg_full, _ = loader.load_env("hector_full")          # sibling task (reference hector_w_arm_config.py), SURVEY 8f-4
 out["HectorFullCfg"] = helpers.class_to_dict(cfg_full.HectorFullCfg())
 out["HectorFullCfgPPO"] = helpers.class_to_dict(cfg_full.HectorFullCfgPPO())
+_, cfg_x, _ = loader.load_env("humanoid_ppo")         # sibling task (reference humanoid_config.py): configs only so far
+out["XBotLCfg"] = helpers.class_to_dict(cfg_x.XBotLCfg())
+out["XBotLCfgPPO"] = helpers.class_to_dict(cfg_x.XBotLCfgPPO())
 with open(os.path.join(HERE, "configs.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 print("reward order:", [k for k, v in out["HectorCfg"]["rewards"]["scales"].items() if v != 0])

@@ -51,7 +51,9 @@ def load_env(task="hector"):
         _pkg("humanoid.envs.custom", os.path.join(REF, "humanoid/envs/custom"))
         lr = importlib.import_module("humanoid.envs.base.legged_robot")
         e.LeggedRobot = lr.LeggedRobot
-    stem = "hector_w_arm" if task == "hector_full" else "hector"
+    stem = {"hector_full": "hector_w_arm", "humanoid_ppo": "humanoid"}.get(task, "hector")
+    if task == "humanoid_ppo":             # configs only: this task's env glue is not restated yet
+        return None, importlib.import_module("humanoid.envs.custom.humanoid_config"), importlib.import_module("humanoid.utils.helpers")
     env_mod = importlib.import_module(f"humanoid.envs.custom.{stem}_env")
     cfg_mod = importlib.import_module(f"humanoid.envs.custom.{stem}_config")
     helpers = importlib.import_module("humanoid.utils.helpers")

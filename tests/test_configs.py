@@ -54,3 +54,15 @@ def test_hector_full_cfgs_match_reference():
     assert HECTOR_FULL.opts["cmd_ranges"]["lin_vel_x"] == tuple(HectorFullCfg.commands.ranges.lin_vel_x)
     assert HECTOR_FULL.opts["max_push_vel_xy"] == HectorFullCfg.domain_rand.max_push_vel_xy
     assert HECTOR_FULL.max_contact_force == HectorFullCfg.rewards.max_contact_force and HECTOR_FULL.min_dist == HectorFullCfg.rewards.min_dist
+
+
+def test_humanoid_ppo_configs_equal_reference():
+    """XBotLCfg / XBotLCfgPPO (reference humanoid_config.py; written here as overrides of the hector classes) leaf by leaf.
+    Configs only: this sibling's env step is not built, and the registry must not pretend otherwise."""
+    from isaac_amd.envs.configs import XBotLCfg, XBotLCfgPPO
+    from isaac_amd.envs import task_registry
+    ref = json.load(open(GOLD))
+    assert _diff(json.loads(json.dumps(class_to_dict(XBotLCfg()))), ref["XBotLCfg"]) == []
+    assert _diff(json.loads(json.dumps(class_to_dict(XBotLCfgPPO()))), ref["XBotLCfgPPO"]) == []
+    assert XBotLCfg.env.num_observations == 705 and XBotLCfg.env.num_privileged_obs == 219
+    assert "humanoid_ppo" not in task_registry.task_classes and "hector_full" in task_registry.task_classes
