@@ -108,12 +108,20 @@ def main():
                          "(forward/dgrad products on the bf16 matrix cores, fp32 master weights and wgrads) -- a different "
                          "configuration, reported with dtype 'bf16' and never as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="diagnostic, one rank only: walk the N > 1 code path (RCCL all-reduce per optimiser step, as identity) "
+                         "to see what the distributed orchestration costs before any link time")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
 
     import contextlib
-    real_stdout = sys.stdout
-    sys.stdout = sys.stderr              # stdout carries exactly one line: the result JSON
+    # stdout carries exactly one line: the result JSON.  Python-level prints go to stderr, and so does file descriptor 1
+    # itself while the job runs: RCCL prints a version banner to fd 1 from native code when its first communicator comes up.
+    sys.stdout.flush()
+    real_fd = os.dup(1)
+    os.dup2(2, 1)
+    real_stdout = os.fdopen(real_fd, "w")
+    sys.stdout = sys.stderr
     import __graft_entry__
     __graft_entry__.build()
     from isaac_amd import capi
@@ -127,7 +135,13 @@ def main():
     if world != args.gpus:
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
-    comm = init_comm()
+    if args.force_collectives and world == 1:
+        from isaac_amd.parallel import TorchComm
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+        comm = TorchComm("nccl")
+        comm.force_collectives = True
+    else:
+        comm = init_comm()
     ndev = max(1, capi.lib().hx_device_count())
     local = comm.local_rank % ndev       # one rank per GPU under the driver; wraps only in the one-GPU gloo-staged rehearsal
     capi.check(capi.lib().hx_set_device(local), "hx_set_device")
@@ -182,7 +196,7 @@ def main():
                                       f"critic {dims(train_cfg.policy.critic_hidden_dims)}"
                                       + ("" if args.dtype == "f32" else " (bf16 forward/dgrad MFMA, fp32 master weights)"),
                           "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
-                          "terrain": args.terrain, "env_shards": args.shards, "collection_s": runner.last_perf.get("collection_time"),
+                          "terrain": args.terrain, "env_shards": args.shards, **({"forced_collectives": True} if args.force_collectives else {}), "collection_s": runner.last_perf.get("collection_time"),
                           "learn_s": runner.last_perf.get("learn_time")}}
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])
@@ -207,6 +221,7 @@ def main():
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), file=real_stdout, flush=True)
     comm.barrier()
+    comm.close()
 
 
 if __name__ == "__main__":

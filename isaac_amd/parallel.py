@@ -46,6 +46,9 @@ class Comm:
     def sum_over_ranks(self, x):
         return x
 
+    def close(self):
+        pass
+
 
 class TorchComm(Comm):
     def __init__(self, backend=None):
@@ -91,6 +94,8 @@ class TorchComm(Comm):
         if self.staged:
             return None
         self._grad = self.torch.zeros(int(count), dtype=self.torch.float32, device=self.device)
+        if self.backend == "nccl":
+            self.torch.cuda.current_stream().synchronize()      # the fill ran on torch's stream; the library uses its own
         return self._grad.data_ptr()
 
     def _sync_streams(self, stream):
@@ -144,6 +149,11 @@ class TorchComm(Comm):
         t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
+
+    def close(self):
+        """Tear the process group down (the nccl backend warns at exit otherwise)."""
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
 
 
 def init_comm(backend=None):

@@ -19,7 +19,12 @@ def main(out_path, iters):
     from isaac_amd.envs.hector_env import HectorFreeEnv
     from isaac_amd.parallel import init_comm
     from isaac_amd.utils.helpers import set_seed
-    comm = init_comm()
+    if os.environ.get("HX_DP_FORCE_RCCL") == "1":      # one rank, real RCCL: every collective of the N > 1 path runs (as identity)
+        from isaac_amd.parallel import TorchComm
+        comm = TorchComm("nccl")
+        comm.force_collectives = True
+    else:
+        comm = init_comm()
     capi.check(capi.lib().hx_set_device(0), "set_device")
     env_cfg, train_cfg = HectorCfg(), HectorCfgPPO()
     env_cfg.env.num_envs = 256

@@ -69,7 +69,7 @@ def test_learning_signal_sanity(hxlib):
 
 
 def test_pipelined_runner_trains(hxlib):
-    """The shard-pipelined rollout loop (bench.py's default) produces a valid PPO iteration."""
+    """The shard-pipelined rollout loop (bench.py --shards 2) produces a valid PPO iteration."""
     from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO
     from isaac_amd.envs.hector_env import PipelinedHectorEnv, class_to_dict
     from isaac_amd.algo.on_policy_runner import OnPolicyRunner
