@@ -11,6 +11,8 @@ def train(args):
     env, env_cfg = task_registry.make_env(name=args.task, args=args, comm=comm)
     ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, comm=comm)
     ppo_runner.learn(num_learning_iterations=train_cfg.runner.max_iterations, init_at_random_ep_len=True)
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == "__main__":
