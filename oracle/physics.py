@@ -31,6 +31,7 @@ MODEL_JSON = os.path.join(os.path.dirname(_HERE), "isaac_amd", "assets", "hector
 # hector with arms (task hector_full, reference hector_w_arm_config.py:29): 19 bodies / 18 DoF, DoF order L leg, L arm,
 # R leg, R arm; no collision shapes compiled yet (tools/compile_urdf.py --full)
 MODEL_FULL_JSON = os.path.join(os.path.dirname(_HERE), "isaac_amd", "assets", "hector_full_model.json")
+MODEL_XBOT_JSON = MODEL_FULL_JSON.replace("hector_full_model.json", "xbot_model.json")   # XBot-L, 12 DoF (oracle only)
 
 # ---- simulation constants (mirrored in isaac_amd/csrc/hx_sim.hip; DESIGN.md lists them) ----
 GRAVITY = -9.81           # reference legged_robot_config.py:184
@@ -139,6 +140,7 @@ class HectorPhysics:
         self.parent = [b["parent"] for b in B]
         self.axis = [b.get("axis", -1) for b in B]
         self.offset = np.array([b.get("offset", [0, 0, 0]) for b in B], dtype)
+        self.rot = [np.array(b["rot"], dtype) if "rot" in b else None for b in B]
         self.q_lo = np.array([b["lower"] for b in B[1:]], dtype)
         self.q_hi = np.array([b["upper"] for b in B[1:]], dtype)
         self.v_max = np.array([b["velocity"] for b in B[1:]], dtype)
@@ -186,6 +188,8 @@ class HectorPhysics:
         for i in range(1, nb):
             lam, k = self.parent[i], self.axis[i]
             Rj = axis_rot(k, s.q[:, i - 1])          # child -> parent
+            if self.rot[i] is not None:              # joint frame rotated against the parent's (XBot-L; never for hector)
+                Rj = self.rot[i] @ Rj
             E = np.swapaxes(Rj, -1, -2)             # parent -> child coordinates
             r = np.broadcast_to(self.offset[i], (n, 3))
             Xup[i, :, :3, :3] = E

@@ -122,3 +122,61 @@ def test_tree_generic_on_the_arm_model():
     mg = ph.mass.sum(0)[:, None] * np.array([0, 0, GRAVITY])
     np.testing.assert_allclose(P1 - P0, mg * dt * steps, atol=1e-4)
     np.testing.assert_allclose((L1 - L0)[:, 2], 0, atol=1e-4)
+
+
+def test_rotated_joint_frames_on_the_xbot_model():
+    """SURVEY 8f-4 groundwork for `humanoid_ppo`: XBot-L's twelve revolute joints turn about the local z of frames that are
+    rotated against their parents (and two about -z), which neither hector asset needs.  tools/compile_urdf.py --xbot
+    records the constant rotation per joint ("rot"); the oracle applies it in the kinematics.  Checks: with the base at the
+    reference config's standing height (XBotLCfg.rewards.base_height_target = 0.89) the zero pose has its soles on the ground, the legs are
+    mirror images, and free flight conserves energy and momentum on this tree too."""
+    from oracle.physics import MODEL_XBOT_JSON, load_model
+    model = load_model(MODEL_XBOT_JSON)
+    assert [b["joint"] for b in model["bodies"][1:]] == [f"{s}_{j}_joint" for s in ("left", "right") for j in
+                                                         ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll")]
+    assert all("rot" in b for b in model["bodies"][1:])
+    n = 2
+    ph = HectorPhysics(n, model=model)
+    assert ph.ndof == 12 and abs(ph.mass.sum(0)[0] - model["total_mass"]) < 1e-9
+    s = State(n, ndof=12)
+    s.root_pos[:, 2] = 0.89
+    R, p, _, _ = ph.kinematics(s)
+    feet = {}
+    for body, pts in ph.contacts[1:]:
+        feet[body] = p[body][0] + pts @ R[body][0].T
+    (bl, fl), (br, fr) = sorted(feet.items())
+    assert abs(fl[:, 2].min()) < 0.01 and abs(fr[:, 2].min()) < 0.01            # soles at the ground (measured: 5 mm)
+    assert fl[:, 2].max() < 0.15 and fl[:, 1].mean() > 0.05 > -0.05 > fr[:, 1].mean()
+    np.testing.assert_allclose(np.sort(fl[:, 0]), np.sort(fr[:, 0]), atol=2e-3)   # mirror images in the sagittal plane
+    np.testing.assert_allclose(np.sort(fl[:, 1]), np.sort(-fr[:, 1]), atol=2e-3)
+    for i in range(1, 7):                                                        # every left body mirrors its right twin
+        np.testing.assert_allclose(p[i][0] * [1, -1, 1], p[i + 6][0], atol=2e-3)
+    assert p[4][0][2] < p[3][0][2] < p[1][0][2]                                  # knee below hip pitch below hip roll
+    # a pitch joint moves the foot in the sagittal plane, whichever way its frame is turned
+    s2 = State(n, ndof=12)
+    s2.root_pos[:, 2] = 0.89
+    s2.q[:, 2] = 0.3
+    _, p2, _, _ = ph.kinematics(s2)
+    d = p2[6][0] - p[6][0]
+    assert abs(d[1]) < 1e-3 and abs(d[0]) > 0.1
+    # dynamics on the rotated tree
+    ph.q_lo[:], ph.q_hi[:], ph.v_max[:] = -100, 100, 1e9
+    rng = np.random.default_rng(2)
+    s = State(n, ndof=12)
+    s.root_pos[:, 2] = 5.0
+    s.q[:] = rng.uniform(-.3, .3, (n, 12))
+    s.qd[:] = rng.uniform(-2, 2, (n, 12))
+    s.root_angvel[:] = rng.uniform(-1, 1, (n, 3))
+    s.root_linvel[:] = rng.uniform(-1, 1, (n, 3))
+    z = np.zeros((n, 12))
+    ke, pe = ph.energy(s)
+    P0, L0 = ph.momentum(s)
+    dt, steps = 1e-4, 200
+    for _ in range(steps):
+        ph.substep(s, z, z, z, z + 1000.0, dt=dt)
+    ke1, pe1 = ph.energy(s)
+    P1, L1 = ph.momentum(s)
+    assert np.all(np.abs(ke1 + pe1 - ke - pe) < 2e-2)                             # E ~ 2.6 kJ
+    mg = ph.mass.sum(0)[:, None] * np.array([0, 0, GRAVITY])
+    np.testing.assert_allclose(P1 - P0, mg * dt * steps, atol=5e-4)
+    np.testing.assert_allclose((L1 - L0)[:, 2], 0, atol=5e-4)

@@ -125,7 +125,17 @@ def collapse(urdf_path, sort_children=False):
 
     def build(name, parent_idx, joint, jpos, jrot):
         acc = []
-        movable = collect(name, np.zeros(3), np.eye(3), acc)
+        # A joint about -x/-y/-z becomes one about +x/+y/+z by giving the body a frame turned half a turn about a
+        # perpendicular axis (XBot-L.urdf: the two leg_pitch joints); everything of the body is then collected in that frame.
+        fix, k = np.eye(3), -1
+        if joint is not None:
+            axis = vec(joint.find("axis").get("xyz"))
+            k = int(np.argmax(np.abs(axis)))
+            assert np.allclose(np.abs(axis), np.eye(3)[k]), "joint axes must be along +-x / +-y / +-z of the joint frame"
+            if axis[k] < 0:
+                fix = -np.eye(3)
+                fix[(k + 1) % 3, (k + 1) % 3] = 1.0           # half turn about the next axis: flips k and the third one
+        movable = collect(name, np.zeros(3), fix, acc)
         m = sum(a[0] for a in acc)
         com = sum(a[0] * a[1] for a in acc) / m
         I = np.zeros((3, 3))
@@ -135,14 +145,13 @@ def collapse(urdf_path, sort_children=False):
         body = {"name": name, "parent": parent_idx, "mass": m, "com": com.tolist(),
                 "inertia_com": I.tolist()}
         if joint is not None:
-            assert np.allclose(jrot, np.eye(3)), "rotated joint frames are not supported"
-            axis = vec(joint.find("axis").get("xyz"))
-            k = int(np.argmax(np.abs(axis)))
-            assert np.allclose(axis, np.eye(3)[k]), "joint axes must be +x/+y/+z"
             lim = joint.find("limit")
             body.update({"joint": joint.get("name"), "offset": jpos.tolist(), "axis": k,
                          "lower": float(lim.get("lower")), "upper": float(lim.get("upper")),
                          "velocity": float(lim.get("velocity")), "effort": float(lim.get("effort"))})
+            rot = jrot @ fix                                  # child -> parent rotation at q = 0
+            if not np.allclose(rot, np.eye(3)):               # both hector assets: identity, key absent (files unchanged)
+                body["rot"] = rot.tolist()
         idx = len(bodies)
         bodies.append(body)
         if sort_children:
@@ -252,6 +261,34 @@ def main_full():
     print("total mass %.5f" % model["total_mass"])
 
 
+def main_xbot():
+    """XBot-L (task humanoid_ppo): model data for the oracle only.  Twelve revolute joints about the local z
+    of frames rotated against their parents ("rot"), upper body and hands collapsed into the base."""
+    urdf = os.path.join(REF, "resources/robots/XBot/urdf/XBot-L.urdf")
+    bodies = collapse(urdf)
+    assert len(bodies) == 13, len(bodies)
+    assert [b.get("joint") for b in bodies[1:]] == [f"{s}_{j}_joint" for s in ("left", "right") for j in
+                                                    ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll")]
+    name_to_idx = {b["name"]: i for i, b in enumerate(bodies)}
+    contacts = [{"body": 0, "points": box_corners((0, 0, 0.1), (0.4, 0.4, 0.4)), "source": "XBot-L.urdf base_link collision box"}]
+    for side in ("left", "right"):
+        nm = f"{side}_ankle_roll_link"
+        lo, hi = stl_bbox(os.path.join(os.path.dirname(urdf), "../meshes", nm + ".STL"))
+        b = bodies[name_to_idx[nm]]
+        # the mesh is given in the URDF link frame; a body whose frame was turned (negative axis) would need the same turn
+        # here -- the ankle_roll joints are about +z
+        assert vec(ET.parse(urdf).getroot().find(f"joint[@name='{side}_ankle_roll_joint']").find("axis").get("xyz"))[2] > 0
+        contacts.append({"body": name_to_idx[nm], "points": box_corners((lo + hi) / 2, hi - lo),
+                         "source": nm + ".STL axis-aligned bounding box", "bbox": [lo.tolist(), hi.tolist()]})
+    model = {"source": "resources/robots/XBot/urdf/XBot-L.urdf (collapse_fixed_joints)",
+             "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": contacts}
+    with open(os.path.join(ROOT, "isaac_amd/assets/xbot_model.json"), "w") as f:
+        json.dump(model, f, indent=1)
+    for i, b in enumerate(bodies):
+        print(i, b["name"], "parent", b["parent"], "m=%.5f" % b["mass"], b.get("joint"), b.get("axis"), "rot" in b)
+    print("total mass %.5f" % model["total_mass"])
+
+
 def main():
     bodies = collapse(URDF)
     assert len(bodies) == 11, len(bodies)
@@ -342,4 +379,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main_full() if "--full" in sys.argv else main())
+    sys.exit(main_full() if "--full" in sys.argv else main_xbot() if "--xbot" in sys.argv else main())
