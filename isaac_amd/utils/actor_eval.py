@@ -1,0 +1,85 @@
+"""Zero-shot evaluation of an exported actor on the HIP simulator (the loop of the reference's play.py:133-143 without
+the viewer, at any robot count): fixed command, `steps` env steps, per-robot survival and tracking statistics.
+
+Used by tests/test_gpu_fidelity.py (the actors the reference ships were trained against PhysX; how they fare here is
+the physics-fidelity evidence for SURVEY row a4) and by tools/actor_rollout.py for parameter studies.
+"""
+import numpy as np
+
+from ..algo.ppo import PPO, ActorCritic
+from ..envs.configs import HectorCfg
+from ..envs.hector_env import HectorFreeEnv
+
+
+def load_actor_npz(path):
+    """tests/golden/actors/<name>.npz -> {'actor.0.weight': ..., ...}"""
+    d = np.load(path)
+    return {"actor." + k: np.ascontiguousarray(d[k], np.float32) for k in d.files}
+
+
+def roll_actor(actor_sd, num_envs=4096, steps=1000, command=(0.5, 0.0, 0.0, 0.0), mesh_type="plane", seed=11,
+               cfg_edit=None, phys=None, warm=100, device="cuda:0"):
+    """Returns a dict of statistics.  A robot "falls" when its episode ends before the time limit (contact termination
+    or blow-up guard); statistics of a robot stop at its first fall.  cfg_edit(cfg): optional config changes;
+    phys: optional overrides of the contact-model constants (isaac_amd.envs.hector_env.PHYS)."""
+    from ..envs import hector_env as he
+    cfg = HectorCfg()
+    cfg.env.num_envs = num_envs
+    cfg.terrain.mesh_type = mesh_type
+    cfg.seed = seed
+    if cfg_edit is not None:
+        cfg_edit(cfg)
+    import torch
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    saved = dict(he.PHYS)
+    if phys:
+        he.PHYS.update(phys)
+    try:
+        env = HectorFreeEnv(cfg, sim_device=device, headless=True)
+    finally:
+        he.PHYS.clear()
+        he.PHYS.update(saved)
+    ac = ActorCritic(env.num_obs, env.num_privileged_obs, env.num_actions, actor_hidden_dims=[512, 256, 128],
+                     critic_hidden_dims=[768, 256, 128])
+    alg = PPO(ac, device=device)
+    alg.init_storage(num_envs, 1, [env.num_obs], [env.num_privileged_obs], [env.num_actions], obs_ld=env.obs_ld, priv_ld=env.priv_ld)
+    sd = ac.state_dict()
+    sd.update(actor_sd)
+    ac.load_state_dict(sd)
+    n = num_envs
+    cmd = np.tile(np.asarray(command, np.float32), (n, 1))
+    alive = np.ones(n, bool)
+    first_fall = np.full(n, steps, np.int64)
+    vx_sum, vy_sum, wz_sum, z_sum, cnt = (np.zeros(n) for _ in range(5))
+    x0 = None
+    obs = env.get_observations()
+    for t in range(steps):
+        act = ac.act_inference(obs)
+        env.commands = cmd
+        obs, _, _, dones, _ = env.step(act)
+        d = dones.numpy().astype(bool)
+        to = env.time_out_buf.numpy().astype(bool)
+        fell = d & ~to
+        first_fall = np.where(alive & fell, t, first_fall)
+        alive &= ~fell
+        if t >= warm:
+            lin, ang = env._base_velocities()
+            root = env.get_state()[0]
+            if x0 is None:
+                x0 = root[:, :2].copy()
+            m = alive
+            vx_sum[m] += lin[m, 0]; vy_sum[m] += lin[m, 1]; wz_sum[m] += ang[m, 2]; z_sum[m] += root[m, 2]; cnt[m] += 1
+    ok = cnt > (steps - warm) // 2
+    res = dict(num_envs=n, steps=steps, command=list(map(float, command)),
+               survival=float(alive.mean()),
+               median_first_fall=float(np.median(first_fall)),
+               mean_vx=float((vx_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"),
+               p10_vx=float(np.percentile(vx_sum[ok] / cnt[ok], 10)) if ok.any() else float("nan"),
+               p90_vx=float(np.percentile(vx_sum[ok] / cnt[ok], 90)) if ok.any() else float("nan"),
+               mean_vy=float((vy_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"),
+               mean_wz=float((wz_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"),
+               mean_height=float((z_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"))
+    alg.close()
+    env.close()
+    return res

@@ -1,0 +1,43 @@
+"""GPU: physics fidelity evidence for SURVEY row a4 (`gym.simulate`, parity unpinned -- PhysX is unavailable).
+
+The only PhysX-derived artefacts in the reference are the seven hector actors it ships as ONNX
+(humanoid/locomotion_net*.onnx, locomotion_net.onnx; weights extracted bit-exactly to tests/golden/actors/ by
+tests/golden/make_actor_fixtures.py).  A policy trained on one simulator walking zero-shot on another is the strongest
+statement available without the reference binary, so each actor is rolled on the HIP simulator: 4096 robots, ground
+plane, the default HectorCfg (friction / payload randomisation, observation and action noise, pushes), the play script's
+fixed command vx = 0.5 m/s (play.py:136-140), 10 s.  Thresholds are written in THRESHOLDS below and in DESIGN.md section 4.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ACTORS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "actors")
+
+# actor -> (min survival over 10 s, (lo, hi) band of the mean forward speed of surviving robots in m/s) or "falls"
+THRESHOLDS = {
+    "locomotion_net": (0.90, (0.25, 0.60)),
+}
+
+
+def test_actor_fixtures_are_complete():
+    idx = json.load(open(os.path.join(ACTORS, "index.json")))
+    assert len(idx) == 7
+    for name, meta in idx.items():
+        d = np.load(os.path.join(ACTORS, name + ".npz"))
+        assert [list(d[f"{2 * i}.weight"].shape) for i in range(4)] == meta["shapes"] == [[512, 615], [256, 512], [128, 256], [10, 128]]
+
+
+@pytest.mark.parametrize("name", sorted(THRESHOLDS))
+def test_shipped_actor_walks(hxlib, name):
+    from isaac_amd.utils.actor_eval import load_actor_npz, roll_actor
+    r = roll_actor(load_actor_npz(os.path.join(ACTORS, name + ".npz")), num_envs=4096, steps=1000)
+    print(name, json.dumps(r))
+    want = THRESHOLDS[name]
+    if want == "falls":
+        assert r["survival"] < 0.10, r
+    else:
+        assert r["survival"] >= want[0], r
+        assert want[1][0] <= r["mean_vx"] <= want[1][1], r
