@@ -73,6 +73,14 @@ int hx_ppo_get_opt_state_h(hx_ppo* p, float* exp_avg_h, float* exp_avg_sq_h, int
  *      keeps fp32 transposed copies of the hidden weights for the dgrads. */
 int hx_ppo_set_compute_dtype(hx_ppo* p, int dtype);
 
+/* Random streams of the learner (the reference draws both from torch's global generator, actor_critic.py:117 and
+ * rollout_storage.py:149; here they are counter-based).  sample_seed keys the action noise: data-parallel ranks pass
+ * seed + rank so their exploration is independent; perm_seed keys the minibatch permutation.  The counters are the
+ * positions in the two streams (a checkpoint stores them so that a resumed run does not replay the noise). */
+int hx_ppo_set_seed(hx_ppo* p, uint64_t sample_seed, uint64_t perm_seed);
+int hx_ppo_get_rng_state(hx_ppo* p, uint32_t* act_counter, uint32_t* perm_counter);
+int hx_ppo_set_rng_state(hx_ppo* p, uint32_t act_counter, uint32_t perm_counter);
+
 int hx_ppo_act(hx_ppo* p, const float* obs, const float* priv, const float* eps /*[N][A], nullable*/, float** actions_out);
 int hx_ppo_process_step(hx_ppo* p, const float* rewards, const uint8_t* dones, const uint8_t* time_outs /*nullable*/);
 int hx_ppo_compute_returns(hx_ppo* p, const float* last_priv /*NULL: values set by hx_ppo_last_values_range*/);

@@ -185,8 +185,12 @@ int hx_sim_set_step_counter(hx_sim* s, int64_t common_step_counter);
  * legged_robot.py:132-133) after it.  Host pointers; both synchronise the simulator's stream. */
 int hx_sim_set_commands(hx_sim* s, const float* commands_h);
 int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h);
-/* over the envs that reset since the last call: mean of episode_sum / max_episode_length_s per reward term
- * (legged_robot.py:198-201), then mean episode return and mean episode length (on_policy_runner.py:140-154) */
+/* What the runner logs as Episode/rew_* and Train/mean_*: per step with a reset, extras["episode"]["rew_k"] = mean over
+ * that step's resets of episode_sum_k / max_episode_length_s (legged_robot.py:198-201); the dict persists on steps without
+ * a reset and the runner appends it every step, then averages over the steps of the iteration
+ * (on_policy_runner.py:141-142,181-195) -> mean_h[0..HX_NUM_REWARDS).  mean_h[HX_NUM_REWARDS], [+1]: mean return and length
+ * of the last <= 100 finished episodes (the rewbuffer / lenbuffer deques, on_policy_runner.py:112-113,140-154).
+ * count_h: episodes finished since the last call.  The call starts a new iteration's accumulation. */
 int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS + 2]*/, int32_t* count_h);
 void* hx_sim_stream(hx_sim* s);
 int hx_sync(void* hip_stream);

@@ -42,13 +42,20 @@ class OnPolicyRunner:
         actor_critic = _CLASSES[self.cfg["policy_class_name"]](env.num_obs, num_critic_obs, env.num_actions, **self.policy_cfg)
         if comm is not None and comm.world_size > 1:
             actor_critic.load_state_dict(comm.broadcast_state(actor_critic.state_dict()))
+        alg_kw = dict(self.alg_cfg)
+        if "seed" in train_cfg and "seed" not in alg_kw:      # exploration noise keyed by seed + rank, permutation by seed
+            alg_kw["seed"] = train_cfg["seed"]
         self.alg = _CLASSES[self.cfg["algorithm_class_name"]](actor_critic, device=device, stream=getattr(env, "stream", None),
-                                                              comm=comm, **self.alg_cfg)
+                                                              comm=comm, **alg_kw)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions],
                               obs_ld=getattr(env, "obs_ld", None), priv_ld=getattr(env, "priv_ld", None))
-        self.log_dir = log_dir
+        # one writer per job: ranks other than 0 neither create directories nor write scalars or checkpoints (their
+        # parameters are bit-identical to rank 0's); Episode/* and Train/* scalars are summed over ranks in log()
+        self.is_chief = comm is None or comm.rank == 0
+        self.log_dir = log_dir if self.is_chief else None
+        self.collect_stats = log_dir is not None
         self.writer = None
         self.tot_timesteps = 0
         self.tot_time = 0
@@ -100,12 +107,12 @@ class OnPolicyRunner:
             learn_time = stop - start
             self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
                                   fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
-            if self.log_dir is not None:
-                ep_info, n_ep = env.episode_stats()
+            if self.collect_stats:
+                ep_info, n_ep = self._episode_stats_all_ranks()
                 self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,
                               mean_value_loss=mean_value_loss, mean_surrogate_loss=mean_surrogate_loss,
                               ep_info=ep_info, n_ep=n_ep, rewbuffer=rewbuffer, lenbuffer=lenbuffer))
-                if it % self.save_interval == 0:
+                if self.log_dir is not None and it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
@@ -134,16 +141,28 @@ class OnPolicyRunner:
             learn_time = stop - start
             self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
                                   fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
-            if self.log_dir is not None:
-                ep_info, n_ep = env.episode_stats()
+            if self.collect_stats:
+                ep_info, n_ep = self._episode_stats_all_ranks()
                 self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,
                               mean_value_loss=mean_value_loss, mean_surrogate_loss=mean_surrogate_loss,
                               ep_info=ep_info, n_ep=n_ep, rewbuffer=None, lenbuffer=None))
-                if it % self.save_interval == 0:
+                if self.log_dir is not None and it % self.save_interval == 0:
                     self.save(os.path.join(self.log_dir, "model_{}.pt".format(it)))
         self.current_learning_iteration += num_learning_iterations
         if self.log_dir is not None:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
+
+    def _episode_stats_all_ranks(self):
+        """Episode/* and Train/* scalars over the envs of ALL ranks (mean of the per-rank values: every rank owns the same
+        number of envs).  A collective when world_size > 1, so every rank calls it."""
+        info, n_ep = self.env.episode_stats()
+        self._train_stats = (self.env.last_episode_return, self.env.last_episode_length)
+        if self.comm is not None and self.comm.world_size > 1:
+            w = float(self.comm.world_size)
+            info = {k: self.comm.sum_over_ranks(v) / w for k, v in info.items()}
+            self._train_stats = tuple(self.comm.sum_over_ranks(v) / w for v in self._train_stats)
+            n_ep = int(self.comm.sum_over_ranks(n_ep))
+        return info, n_ep
 
     def log(self, locs, width=80, pad=35):
         world = 1 if self.comm is None else self.comm.world_size
@@ -160,9 +179,8 @@ class OnPolicyRunner:
                         "Perf/total_fps": fps, "Perf/collection time": locs["collection_time"],
                         "Perf/learning_time": locs["learn_time"]})
         if locs["n_ep"] > 0:
-            scalars["Train/mean_reward"] = self.env.last_episode_return
-            scalars["Train/mean_episode_length"] = self.env.last_episode_length
-        if self.writer is not None and (self.comm is None or self.comm.rank == 0):
+            scalars["Train/mean_reward"], scalars["Train/mean_episode_length"] = self._train_stats
+        if self.writer is not None and self.is_chief:
             self.writer.write(json.dumps({"it": locs["it"], "tot_timesteps": self.tot_timesteps, "tot_time": self.tot_time, **scalars}) + "\n")
             self.writer.flush()
         if self.comm is not None and self.comm.rank != 0:
@@ -174,8 +192,8 @@ class OnPolicyRunner:
                  f"{'Surrogate loss:':>{pad}} {locs['mean_surrogate_loss']:.4f}",
                  f"{'Mean action noise std:':>{pad}} {mean_std:.2f}"]
         if locs["n_ep"] > 0:
-            lines += [f"{'Mean reward:':>{pad}} {self.env.last_episode_return:.2f}",
-                      f"{'Mean episode length:':>{pad}} {self.env.last_episode_length:.2f}"]
+            lines += [f"{'Mean reward:':>{pad}} {self._train_stats[0]:.2f}",
+                      f"{'Mean episode length:':>{pad}} {self._train_stats[1]:.2f}"]
         for k, v in locs["ep_info"].items():
             lines.append(f"{'Mean episode ' + k + ':':>{pad}} {v:.4f}")
         lines += ["-" * width, f"{'Total timesteps:':>{pad}} {self.tot_timesteps}",
@@ -201,8 +219,13 @@ class OnPolicyRunner:
     def save(self, path, infos=None):
         import torch
         sd = {k: torch.from_numpy(v) for k, v in self.alg.actor_critic.state_dict().items()}
+        if not self.is_chief:
+            return
+        # the reference's four keys (on_policy_runner.py:278-287) + the positions of the learner's counter-based random
+        # streams, so that a resumed run does not replay the exploration noise and permutations from the start
         torch.save({"model_state_dict": sd, "optimizer_state_dict": self._opt_state_dict(),
-                    "iter": self.current_learning_iteration, "infos": infos}, path)
+                    "iter": self.current_learning_iteration, "infos": infos,
+                    "hx_rng_state": list(self.alg.rng_state())}, path)
 
     def load(self, path, load_optimizer=True):
         import torch
@@ -215,6 +238,8 @@ class OnPolicyRunner:
                 v = np.concatenate([st[i]["exp_avg_sq"].numpy().reshape(-1) for i in sorted(st)])
                 self.alg.load_optimizer_state(m, v, int(float(st[0]["step"])))
             self.alg.learning_rate = loaded["optimizer_state_dict"]["param_groups"][0]["lr"]
+        if loaded.get("hx_rng_state") is not None:
+            self.alg.load_rng_state(*loaded["hx_rng_state"])
         self.current_learning_iteration = loaded["iter"]
         return loaded["infos"]
 

@@ -136,12 +136,13 @@ class PPO:
     def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
                  value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0,
                  use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01, device="cuda:0", stream=None,
-                 comm=None, mlp_dtype="f32"):
+                 comm=None, mlp_dtype="f32", seed=None):
         """mlp_dtype: "f32" (default, the reference's precision) or "bf16" (BASELINE config 4: forward / dgrad products of
         the update and the deferred critic on the bf16 matrix cores, fp32 master weights; hx_ppo_set_compute_dtype)."""
         if mlp_dtype not in ("f32", "bf16"):
             raise ValueError("mlp_dtype must be 'f32' or 'bf16'")
         self.mlp_dtype = mlp_dtype
+        self.seed = seed                  # None: the library's fixed keys (what the reference-fixture tests were generated with)
         self.device = device
         self.actor_critic = actor_critic
         self.desired_kl, self.schedule = desired_kl, schedule
@@ -192,6 +193,9 @@ class PPO:
         if self.mlp_dtype == "bf16":
             capi.check(self._L.hx_ppo_set_compute_dtype(h, 1), "hx_ppo_set_compute_dtype")
         ac.load_state_dict(ac._pending_state)
+        if self.seed is not None:         # exploration noise keyed per rank, permutation keyed by the run's seed
+            rank = self.comm.rank if self.comm is not None else 0
+            capi.check(self._L.hx_ppo_set_seed(h, int(self.seed) + rank, int(self.seed)), "hx_ppo_set_seed")
         self.storage = self          # `alg.storage.clear()` style calls land here
         self.step = 0
 
@@ -354,6 +358,14 @@ class PPO:
 
     def load_optimizer_state(self, m, v, step):
         capi.check(self._L.hx_ppo_set_opt_state_h(self._h, capi.ptr(capi.farr(m)), capi.ptr(capi.farr(v)), int(step)), "set_opt_state")
+
+    def rng_state(self):
+        a, p = capi.C.c_uint32(), capi.C.c_uint32()
+        capi.check(self._L.hx_ppo_get_rng_state(self._h, capi.C.byref(a), capi.C.byref(p)), "get_rng_state")
+        return int(a.value), int(p.value)
+
+    def load_rng_state(self, act_counter, perm_counter):
+        capi.check(self._L.hx_ppo_set_rng_state(self._h, int(act_counter), int(perm_counter)), "set_rng_state")
 
     PROF_KERNELS = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
                     "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)", "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",

@@ -120,6 +120,9 @@ def lib():
     L.hx_ppo_set_compute_dtype.argtypes = [vp, C.c_int]
     L.hx_ppo_set_opt_state_h.argtypes = [vp, vp, vp, C.c_int64]
     L.hx_ppo_get_opt_state_h.argtypes = [vp, vp, vp, C.POINTER(C.c_int64)]
+    L.hx_ppo_set_seed.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.hx_ppo_get_rng_state.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.hx_ppo_set_rng_state.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.hx_ppo_act.argtypes = [vp, vp, vp, vp, C.POINTER(vp)]
     L.hx_ppo_process_step.argtypes = [vp, vp, vp, vp]
     L.hx_ppo_compute_returns.argtypes = [vp, vp]

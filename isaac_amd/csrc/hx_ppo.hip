@@ -807,6 +807,7 @@ struct hx_ppo {
   float *act_a[3], *act_c[3], *dz_a[3], *dz_c[3];
   float *slab, *bias_slab, *head_slab, *head_slab2; size_t slab_floats;
   size_t slab_off[8], bslab_off[8];     // per-layer regions so that all six wgrads finish before one reduce launch
+  int slab_splits[8];                   // split-K partial slabs allocated per layer: gemm_wgrad never writes more
   int head_blocks_max, head_slab_w;
   int* perm; int perm_external;
   double* sumsq; SchedState* sched;
@@ -816,7 +817,7 @@ struct hx_ppo {
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
-  uint32_t seed_lo, seed_hi, act_counter, perm_counter;
+  uint32_t seed_lo, seed_hi, act_counter, perm_counter, perm_key;
   // profiling
   bool prof; std::vector<hipEvent_t> ev; std::vector<int> ev_kid; size_t ev_used; double prof_flops[5]; long prof_launches[5];
   std::vector<void*> allocs;
@@ -930,7 +931,7 @@ static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, cons
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab; *bias_parts = number of
 // partial rows written to bias_slab (splits x the tile_n blocks that share the column-sum work)
 static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab,
-                      int* bias_parts) {
+                      int* bias_parts, int alloc_splits) {
   GemmArgs g{};
   g.A = dZ; g.lda = out; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = Mrows;
   const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
@@ -949,6 +950,9 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   if (splits < 1) splits = 1;
   int max_splits = Mrows / HX_WGRAD_MIN_CHUNK; if (max_splits < 1) max_splits = 1;
   if (splits > max_splits) splits = max_splits;
+  // never more partial slabs than ppo_create_impl allocated for this layer (a larger HX_WGRAD_BLOCKS override or a device
+  // with more CUs would otherwise write past the layer's slab region); rounding the chunk up only lowers the count again
+  if (splits > alloc_splits) splits = alloc_splits;
   int kchunk = rup((Mrows + splits - 1) / splits, 32);
   splits = (Mrows + kchunk - 1) / kchunk;
   if (s->bf16) {                        // K chunks in whole 64-deep tiles for the bf16 kernel
@@ -1286,6 +1290,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     int splits = (1024 + tiles - 1) / tiles + 1;
     int max_splits = s->Mmax / 256; if (max_splits < 1) max_splits = 1;
     if (splits > max_splits + 1) splits = max_splits + 1;
+    s->slab_splits[i] = splits;
     slab_tot += (size_t)splits * Ly.out * Ly.in_ld;
     bslab_tot += (size_t)splits * ((Ly.in_ld + 127) / 128) * Ly.out;
   }
@@ -1322,7 +1327,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     }
   }
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
-  s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0;
+  s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0; s->perm_key = 0xA511E9B3u;
   s->prof = false; s->ev_used = 0;
   for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
   return 0;
@@ -1343,6 +1348,25 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
 }
 
 extern "C" int64_t hx_ppo_num_params(hx_ppo* s) { return s->torch_count; }
+// Keys of the learner's two random streams.  sample_seed keys the action noise of PPO.act (Philox counter = env row,
+// act call, action index): data-parallel ranks pass seed + rank so that their exploration noise is independent.
+// perm_seed keys the minibatch permutation (may be equal on all ranks).  Without this call the keys are fixed constants.
+static uint32_t mix32(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return (uint32_t)x; }
+extern "C" int hx_ppo_set_seed(hx_ppo* s, uint64_t sample_seed, uint64_t perm_seed) {
+  if (!s) { hx_set_error("hx_ppo_set_seed: null learner"); return -2; }
+  s->seed_lo = 0x1234567u ^ mix32(sample_seed); s->seed_hi = 0x89abcdefu ^ mix32(sample_seed + 0x9E3779B97F4A7C15ULL);
+  s->perm_key = 0xA511E9B3u ^ mix32(perm_seed ^ 0xD1B54A32D192ED03ULL);
+  return 0;
+}
+// positions in the two streams (checkpointed so that a resumed run does not replay the noise from counter 0)
+extern "C" int hx_ppo_get_rng_state(hx_ppo* s, uint32_t* act_counter, uint32_t* perm_counter) {
+  if (!s) { hx_set_error("hx_ppo_get_rng_state: null learner"); return -2; }
+  *act_counter = s->act_counter; *perm_counter = s->perm_counter; return 0;
+}
+extern "C" int hx_ppo_set_rng_state(hx_ppo* s, uint32_t act_counter, uint32_t perm_counter) {
+  if (!s) { hx_set_error("hx_ppo_set_rng_state: null learner"); return -2; }
+  s->act_counter = act_counter; s->perm_counter = perm_counter; return 0;
+}
 extern "C" void* hx_ppo_stream(hx_ppo* s) { return (void*)s->stream; }
 
 // torch parameters() order <-> padded device layout
@@ -1576,7 +1600,7 @@ extern "C" int hx_ppo_adv_normalize(hx_ppo* s) {
 extern "C" int hx_ppo_update_begin(hx_ppo* s, const int32_t* perm) {
   const int TN = s->cfg.num_steps * s->cfg.num_envs;
   if (perm) HX_CHECK(hipMemcpyAsync(s->perm, perm, (size_t)TN * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
-  else hipLaunchKernelGGL(hx_perm_kernel, dim3((TN + 255) / 256), dim3(256), 0, s->stream, s->perm, TN, 0xA511E9B3u + 0x9E3779B9u * (s->perm_counter++));
+  else hipLaunchKernelGGL(hx_perm_kernel, dim3((TN + 255) / 256), dim3(256), 0, s->stream, s->perm, TN, s->perm_key + 0x9E3779B9u * (s->perm_counter++));
   SchedState z{};
   // keep lr, clear the loss accumulators
   HX_CHECK(hipMemsetAsync(&s->sched->vloss_sum, 0, 2 * sizeof(float), s->stream));
@@ -1642,7 +1666,7 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       float* slab = s->slab + s->slab_off[net * 4 + l];
       float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
       int bparts = 0;
-      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts);
+      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
       const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
       int k = rt.nseg;
       rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;

@@ -31,6 +31,7 @@ struct SLay {
         SIZE(48 + 6 * nd) {}
 };
 
+#define HX_STAT_RING 100     /* deque(maxlen=100), on_policy_runner.py:112-113 */
 struct SimPtrs {
   float* st;          // [S_STATE_SIZE][N]
   int* ep_len;        // [N]
@@ -44,8 +45,13 @@ struct SimPtrs {
   unsigned char* reset;    // [N]
   unsigned char* timeout;  // [N]
   int* num_reset;     // [1]
-  float* stat_sum;    // [HX_NUM_REWARDS + 2] sums over envs that reset: per-term episode sums, episode return, episode length
-  int* stat_cnt;      // [1]
+  // episode statistics as the runner logs them (legged_robot.py:198-201 + on_policy_runner.py:140-154,181-195):
+  float* stat_sum;    // [HX_NUM_REWARDS] this step's sums of the per-term episode sums over the envs that reset
+  float* stat_last;   // [HX_NUM_REWARDS] extras["episode"] of the most recent step with a reset (the dict persists in between)
+  float* stat_acc;    // [HX_NUM_REWARDS] sum of stat_last over the steps since the last hx_sim_episode_stats call
+  int* stat_steps;    // [2] steps accumulated ; whether stat_last has ever been set
+  float* stat_ring;   // [2][HX_STAT_RING] returns / lengths of the last finished episodes (rewbuffer / lenbuffer deques)
+  int* stat_cnt;      // [2] episodes finished since the last call ; ring head (total episodes ever)
   // terrain height grid (metres), row-major [t_rows][t_cols], node (i, j) at world (t_x0 + i hs, t_y0 + j hs);
   // nullptr = ground plane
   const float* terrain;
@@ -251,10 +257,15 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     // into the observations and from there into every weight.  Such a robot is put back on its start pose with zero
     // forces right here, so nothing downstream sees the bad numbers, and the step ends its episode as a fall.
     {
-      float chk = S.pos.x + S.pos.y + S.pos.z + S.quat[0] + S.quat[1] + S.quat[2] + S.quat[3]
-                  + S.linvel.x + S.linvel.y + S.linvel.z + S.angvel.x + S.angvel.y + S.angvel.z;
-      for (int j = 0; j < NL; ++j) chk += S.q[j] + S.qd[j];
-      float bad = (fabsf(chk) < 1.0e6f) ? 0.f : 1.f;          // NaN fails the comparison
+      // every state component must be finite and below 2^20 in magnitude.  Tested on the exponent bits with integer
+      // operations: this file is built with -ffast-math (finite-math-only), under which a floating-point comparison
+      // may legally be folded as if NaN did not exist.
+      uint32_t emax = 0u;
+      auto chk = [&](float x) { const uint32_t ex = __float_as_uint(x) & 0x7f800000u; emax = ex > emax ? ex : emax; };
+      chk(S.pos.x); chk(S.pos.y); chk(S.pos.z); chk(S.quat[0]); chk(S.quat[1]); chk(S.quat[2]); chk(S.quat[3]);
+      chk(S.linvel.x); chk(S.linvel.y); chk(S.linvel.z); chk(S.angvel.x); chk(S.angvel.y); chk(S.angvel.z);
+      for (int j = 0; j < NL; ++j) { chk(S.q[j]); chk(S.qd[j]); }
+      float bad = (emax >= ((127u + 20u) << 23)) ? 1.f : 0.f;
       bad = fmaxf(bad, xchg(bad));
       if (bad != 0.f) {
         blown = true;
@@ -581,8 +592,9 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     }
     if (A.mode == 0 && writer) {
       // Train/mean_reward and Train/mean_episode_length of the runner (on_policy_runner.py:140-154)
-      atomicAdd(&p.stat_sum[HX_NUM_REWARDS], ep_ret);
-      atomicAdd(&p.stat_sum[HX_NUM_REWARDS + 1], (float)finished_len);
+      const int slot = atomicAdd(p.stat_cnt + 1, 1) % HX_STAT_RING;
+      p.stat_ring[slot] = ep_ret;
+      p.stat_ring[HX_STAT_RING + slot] = (float)finished_len;
       atomicAdd(p.stat_cnt, 1);
       atomicAdd(p.num_reset, 1);
     }
@@ -687,6 +699,7 @@ struct StackArgs {
   const float* priv_src; float* priv_dst; const float* priv_frame;
   const unsigned char* reset; const unsigned char* timeout; unsigned char* timeout_visible;
   const int* num_reset; int* num_reset_next;
+  float* stat_sum; float* stat_last; float* stat_acc; int* stat_steps;
   const float* rew; float* rew_out; unsigned char* done_out; unsigned char* timeout_out;
   int n; float clip;
   int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, or 65 / 94 with arms) and row strides
@@ -722,7 +735,20 @@ __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
     unsigned char tv = a.timeout_visible[e];
     if (*a.num_reset > 0) { tv = a.timeout[e]; a.timeout_visible[e] = tv; }
     if (a.rew_out) { a.rew_out[e] = a.rew[e]; a.done_out[e] = rst ? 1 : 0; a.timeout_out[e] = tv; }
-    if (e == 0) *a.num_reset_next = 0;          // the other counter of the ping-pong pair: free until the next step
+    if (e == 0) {
+      *a.num_reset_next = 0;          // the other counter of the ping-pong pair: free until the next step
+      // extras["episode"] is rebuilt only on steps with a reset and the runner appends the (possibly stale) dict every
+      // step (on_policy_runner.py:141-142): per step the mean over that step's resets, then the mean over steps
+      const int nr = *a.num_reset;
+      if (nr > 0) {
+        for (int r = 0; r < HX_NUM_REWARDS; ++r) { a.stat_last[r] = a.stat_sum[r] / (float)nr; a.stat_sum[r] = 0.f; }
+        a.stat_steps[1] = 1;
+      }
+      if (a.stat_steps[1]) {
+        for (int r = 0; r < HX_NUM_REWARDS; ++r) a.stat_acc[r] += a.stat_last[r];
+        a.stat_steps[0] += 1;
+      }
+    }
   }
 }
 
@@ -815,8 +841,9 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   rc |= dalloc(s, &s->p.timeout, n);
   rc |= dalloc(s, &s->num_reset2[0], 1); rc |= dalloc(s, &s->num_reset2[1], 1);
   s->p.num_reset = s->num_reset2[0]; s->parity = 0;
-  rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS + 2);
-  rc |= dalloc(s, &s->p.stat_cnt, 1);
+  rc |= dalloc(s, &s->p.stat_sum, HX_NUM_REWARDS); rc |= dalloc(s, &s->p.stat_last, HX_NUM_REWARDS); rc |= dalloc(s, &s->p.stat_acc, HX_NUM_REWARDS);
+  rc |= dalloc(s, &s->p.stat_steps, 2); rc |= dalloc(s, &s->p.stat_ring, 2 * HX_STAT_RING);
+  rc |= dalloc(s, &s->p.stat_cnt, 2);
   rc |= dalloc(s, &s->timeout_visible, n);
   for (int i = 0; i < 2; ++i) { rc |= dalloc(s, &s->obs[i], n * s->obs_ld); rc |= dalloc(s, &s->priv[i], n * s->priv_ld); }
   if (rc) return -3;
@@ -917,6 +944,7 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   k.priv_src = s->priv_cur; k.priv_dst = pd; k.priv_frame = s->p.priv_frame;
   k.reset = s->p.reset; k.timeout = s->p.timeout; k.timeout_visible = s->timeout_visible;
   k.num_reset = s->num_reset2[s->parity]; k.num_reset_next = s->num_reset2[s->parity ^ 1];
+  k.stat_sum = s->p.stat_sum; k.stat_last = s->p.stat_last; k.stat_acc = s->p.stat_acc; k.stat_steps = s->p.stat_steps;
   k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
   k.n = n; k.clip = s->cfg.clip_observations;
   k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld;
@@ -942,6 +970,7 @@ extern "C" int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack
 }
 
 extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
+  if (!s || !dptr) { hx_set_error("hx_sim_buffer: null argument"); return -2; }
   switch (which) {
     case HX_BUF_OBS: *dptr = s->obs_cur; break;
     case HX_BUF_PRIV: *dptr = s->priv_cur; break;
@@ -964,6 +993,7 @@ extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {
 }
 
 extern "C" int hx_sim_get_state(hx_sim* s, float* root_h, float* q_h, float* qd_h) {
+  if (!s || !root_h || !q_h || !qd_h) { hx_set_error("hx_sim_get_state: null argument"); return -2; }
   const size_t n = s->cfg.num_envs;
   const int nd = s->nd;
   std::vector<float> st((size_t)(13 + 2 * nd) * n);
@@ -977,6 +1007,7 @@ extern "C" int hx_sim_get_state(hx_sim* s, float* root_h, float* q_h, float* qd_
 }
 
 extern "C" int hx_sim_set_state(hx_sim* s, const float* root_h, const float* q_h, const float* qd_h) {
+  if (!s || !root_h || !q_h || !qd_h) { hx_set_error("hx_sim_set_state: null argument"); return -2; }
   const size_t n = s->cfg.num_envs;
   const int nd = s->nd;
   std::vector<float> st((size_t)(13 + 2 * nd) * n);
@@ -990,6 +1021,7 @@ extern "C" int hx_sim_set_state(hx_sim* s, const float* root_h, const float* q_h
 }
 
 extern "C" int hx_sim_set_commands(hx_sim* s, const float* cmd_h) {
+  if (!s || !cmd_h) { hx_set_error("hx_sim_set_commands: null argument"); return -2; }
   const size_t n = s->cfg.num_envs;
   std::vector<float> c(4 * n);
   for (size_t e = 0; e < n; ++e)
@@ -1000,6 +1032,7 @@ extern "C" int hx_sim_set_commands(hx_sim* s, const float* cmd_h) {
 }
 
 extern "C" int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h) {
+  if (!s || !lin_h || !ang_h) { hx_set_error("hx_sim_get_base_velocities: null argument"); return -2; }
   const size_t n = s->cfg.num_envs;
   std::vector<float> v(6 * n);
   HX_CHECK(hipStreamSynchronize(s->stream));
@@ -1010,6 +1043,7 @@ extern "C" int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h)
 }
 
 extern "C" int hx_sim_set_episode_length(hx_sim* s, const int32_t* h) {
+  if (!s || !h) { hx_set_error("hx_sim_set_episode_length: null argument"); return -2; }
   HX_CHECK(hipStreamSynchronize(s->stream));
   HX_CHECK(hipMemcpy(s->p.ep_len, h, (size_t)s->cfg.num_envs * sizeof(int), hipMemcpyHostToDevice));
   return 0;
@@ -1017,15 +1051,23 @@ extern "C" int hx_sim_set_episode_length(hx_sim* s, const int32_t* h) {
 extern "C" int hx_sim_set_step_counter(hx_sim* s, int64_t c) { s->step_counter = c; return 0; }
 
 extern "C" int hx_sim_episode_stats(hx_sim* s, float* mean_h, int32_t* count_h) {
-  float sum[HX_NUM_REWARDS + 2]; int cnt = 0;
+  if (!s || !mean_h || !count_h) { hx_set_error("hx_sim_episode_stats: null argument"); return -2; }
+  float acc[HX_NUM_REWARDS], ring[2 * HX_STAT_RING]; int steps[2] = {0, 0}, cnt[2] = {0, 0};
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipMemcpy(sum, s->p.stat_sum, sizeof(sum), hipMemcpyDeviceToHost));
-  HX_CHECK(hipMemcpy(&cnt, s->p.stat_cnt, sizeof(int), hipMemcpyDeviceToHost));
-  for (int r = 0; r < HX_NUM_REWARDS; ++r) mean_h[r] = cnt > 0 ? sum[r] / (float)cnt / s->cfg.max_episode_length_s : 0.f;
-  mean_h[HX_NUM_REWARDS] = cnt > 0 ? sum[HX_NUM_REWARDS] / (float)cnt : 0.f;
-  mean_h[HX_NUM_REWARDS + 1] = cnt > 0 ? sum[HX_NUM_REWARDS + 1] / (float)cnt : 0.f;
-  *count_h = cnt;
-  HX_CHECK(hipMemset(s->p.stat_sum, 0, sizeof(sum)));
+  HX_CHECK(hipMemcpy(acc, s->p.stat_acc, sizeof(acc), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(ring, s->p.stat_ring, sizeof(ring), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(steps, s->p.stat_steps, sizeof(steps), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(cnt, s->p.stat_cnt, sizeof(cnt), hipMemcpyDeviceToHost));
+  for (int r = 0; r < HX_NUM_REWARDS; ++r) mean_h[r] = steps[0] > 0 ? acc[r] / (float)steps[0] / s->cfg.max_episode_length_s : 0.f;
+  const int filled = cnt[1] < HX_STAT_RING ? cnt[1] : HX_STAT_RING;
+  double sr = 0, sl = 0;
+  for (int i = 0; i < filled; ++i) { sr += ring[i]; sl += ring[HX_STAT_RING + i]; }
+  mean_h[HX_NUM_REWARDS] = filled > 0 ? (float)(sr / filled) : 0.f;
+  mean_h[HX_NUM_REWARDS + 1] = filled > 0 ? (float)(sl / filled) : 0.f;
+  *count_h = cnt[0];
+  // ep_infos.clear() of the runner (on_policy_runner.py:170); the deques and the stale extras["episode"] persist
+  HX_CHECK(hipMemset(s->p.stat_acc, 0, sizeof(acc)));
+  HX_CHECK(hipMemset(s->p.stat_steps, 0, sizeof(int)));
   HX_CHECK(hipMemset(s->p.stat_cnt, 0, sizeof(int)));
   return 0;
 }

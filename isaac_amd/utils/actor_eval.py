@@ -6,6 +6,7 @@ the physics-fidelity evidence for SURVEY row a4) and by tools/actor_rollout.py f
 """
 import numpy as np
 
+from .. import capi
 from ..algo.ppo import PPO, ActorCritic
 from ..envs.configs import HectorCfg
 from ..envs.hector_env import HectorFreeEnv
@@ -18,7 +19,7 @@ def load_actor_npz(path):
 
 
 def roll_actor(actor_sd, num_envs=4096, steps=1000, command=(0.5, 0.0, 0.0, 0.0), mesh_type="plane", seed=11,
-               cfg_edit=None, phys=None, warm=100, device="cuda:0"):
+               cfg_edit=None, phys=None, warm=100, device="cuda:0", diagnostics=False):
     """Returns a dict of statistics.  A robot "falls" when its episode ends before the time limit (contact termination
     or blow-up guard); statistics of a robot stop at its first fall.  cfg_edit(cfg): optional config changes;
     phys: optional overrides of the contact-model constants (isaac_amd.envs.hector_env.PHYS)."""
@@ -51,7 +52,7 @@ def roll_actor(actor_sd, num_envs=4096, steps=1000, command=(0.5, 0.0, 0.0, 0.0)
     cmd = np.tile(np.asarray(command, np.float32), (n, 1))
     alive = np.ones(n, bool)
     first_fall = np.full(n, steps, np.int64)
-    vx_sum, vy_sum, wz_sum, z_sum, cnt = (np.zeros(n) for _ in range(5))
+    vx_sum, vy_sum, wz_sum, z_sum, cnt, slip_sum, slip_cnt, sat_sum = (np.zeros(n) for _ in range(8))
     x0 = None
     obs = env.get_observations()
     for t in range(steps):
@@ -70,6 +71,15 @@ def roll_actor(actor_sd, num_envs=4096, steps=1000, command=(0.5, 0.0, 0.0, 0.0)
                 x0 = root[:, :2].copy()
             m = alive
             vx_sum[m] += lin[m, 0]; vy_sum[m] += lin[m, 1]; wz_sum[m] += ang[m, 2]; z_sum[m] += root[m, 2]; cnt[m] += 1
+            if diagnostics:
+                bodies = env._buf(capi.BUF_BODY_STATE, (4, 13, n)).numpy()          # L_calf, L_toe, R_calf, R_toe
+                cf = env.contact_forces
+                tq = env.torques
+                for k, b in ((0, 1), (1, 3)):
+                    inc = cf[:, env.feet_indices[k], 2] > 5.0
+                    sp = np.hypot(bodies[b, 7], bodies[b, 8])
+                    slip_sum[m & inc] += sp[m & inc]; slip_cnt[m & inc] += 1
+                sat_sum[m] += (np.abs(tq[m]) >= env.torque_limits[None, :] - 1e-3).mean(axis=1)
     ok = cnt > (steps - warm) // 2
     res = dict(num_envs=n, steps=steps, command=list(map(float, command)),
                survival=float(alive.mean()),
@@ -80,6 +90,14 @@ def roll_actor(actor_sd, num_envs=4096, steps=1000, command=(0.5, 0.0, 0.0, 0.0)
                mean_vy=float((vy_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"),
                mean_wz=float((wz_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"),
                mean_height=float((z_sum[ok] / cnt[ok]).mean()) if ok.any() else float("nan"))
+    if diagnostics:
+        res["stance_foot_speed"] = float(slip_sum.sum() / max(1.0, slip_cnt.sum()))
+        res["stance_fraction_per_foot"] = float(slip_cnt[ok].sum() / max(1.0, 2 * cnt[ok].sum()))
+        res["torque_saturation_fraction"] = float(sat_sum[ok].sum() / max(1.0, cnt[ok].sum()))
+        fr, ms = env.env_frictions, env.body_mass
+        for nm, arr, edges in (("friction", fr, [0.1, 0.3, 0.5, 0.7, 1.01]), ("base_mass", ms, [6.0, 7.5, 9.0, 10.5, 12.3])):
+            res["survival_by_" + nm] = [[edges[i], edges[i + 1], float(alive[(arr >= edges[i]) & (arr < edges[i + 1])].mean()) if ((arr >= edges[i]) & (arr < edges[i + 1])).any() else None]
+                                        for i in range(len(edges) - 1)]
     alg.close()
     env.close()
     return res

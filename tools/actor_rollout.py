@@ -20,6 +20,8 @@ ap.add_argument("--terrain", default="plane")
 ap.add_argument("--vx", type=float, default=0.5)
 ap.add_argument("--phys", action="append", default=[])
 ap.add_argument("--nodr", action="store_true", help="no friction / mass randomisation, no pushes, no noise")
+ap.add_argument("--off", default="", help="comma list of DR components to switch off: friction,mass,push,noise,actnoise")
+ap.add_argument("--diag", action="store_true")
 args = ap.parse_args()
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "actors")
 names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(root, "*.npz"))) if args.actors == "all" else args.actors.split(",")
@@ -27,6 +29,12 @@ variants = [dict((kv.split("=")[0], float(kv.split("=")[1])) for kv in v.split("
 
 
 def edit(cfg):
+    off = set(args.off.split(",")) if args.off else set()
+    if "friction" in off: cfg.domain_rand.randomize_friction = False
+    if "mass" in off: cfg.domain_rand.randomize_base_mass = False
+    if "push" in off: cfg.domain_rand.push_robots = False
+    if "noise" in off: cfg.noise.add_noise = False
+    if "actnoise" in off: cfg.domain_rand.action_noise = 0.0
     if args.nodr:
         cfg.domain_rand.randomize_friction = False
         cfg.domain_rand.randomize_base_mass = False
@@ -38,6 +46,6 @@ def edit(cfg):
 for v in variants:
     for nm in names:
         r = roll_actor(load_actor_npz(os.path.join(root, nm + ".npz")), num_envs=args.envs, steps=args.steps,
-                       command=(args.vx, 0.0, 0.0, 0.0), mesh_type=args.terrain, cfg_edit=edit, phys=v)
-        r.update(actor=nm, phys=v, nodr=args.nodr, terrain=args.terrain)
+                       command=(args.vx, 0.0, 0.0, 0.0), mesh_type=args.terrain, cfg_edit=edit, phys=v, diagnostics=args.diag)
+        r.update(actor=nm, phys=v, nodr=args.nodr, off=args.off, terrain=args.terrain)
         print(json.dumps(r), flush=True)
