@@ -154,10 +154,13 @@ int hx_sim_create(const hx_sim_cfg* cfg, const float* shape_friction_h, const fl
  * heights_h: host int16 [rows][cols] row-major in units of vertical_scale (Terrain.heightsamples); node (i, j) lies
  * at world (x0 + i*horizontal_scale, y0 + j*horizontal_scale) -- the reference passes x0 = y0 = -border_size.
  * Collision surface: two triangles per cell split along (i,j)-(i+1,j+1), as convert_heightfield_to_trimesh emits
- * them (no slope-threshold vertex shift); outside the grid the border continues.  Call before hx_sim_reset_all;
- * heights_h == NULL returns to the ground plane z = 0 (gym.add_ground, legged_robot.py:541-551). */
+ * them; outside the grid the border continues.  wall_height > 0 (mesh_type 'trimesh': slope_treshold * horizontal_scale,
+ * utils/terrain.py:70-73 with legged_robot_config.py:67) reproduces the slope-threshold vertex shift of that function: where
+ * grid neighbours differ by more than wall_height the low ground continues flat up to the high vertices' grid line and a
+ * vertical wall stands there, which collides sideways; 0 (mesh_type 'heightfield') keeps the ramps.  Call before
+ * hx_sim_reset_all; heights_h == NULL returns to the ground plane z = 0 (gym.add_ground, legged_robot.py:541-551). */
 int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t rows, int32_t cols, float horizontal_scale,
-                       float vertical_scale, float x0, float y0);
+                       float vertical_scale, float x0, float y0, float wall_height);
 /* Terrain curriculum, LeggedRobot._update_terrain_curriculum (legged_robot.py:399-419) with the tables of
  * _get_env_origins (legged_robot.py:687-697).  origins_h [rows][cols][3] = terrain.env_origins, levels_h / types_h [N] =
  * terrain_levels / terrain_types, env_length = terrain.env_length, max_episode_length_s as in the config.  Every reset

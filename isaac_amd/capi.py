@@ -93,7 +93,7 @@ def lib():
     L.hx_sim_set_step_counter.argtypes = [vp, C.c_int64]
     L.hx_sim_set_commands.argtypes = [vp, vp]
     L.hx_sim_get_base_velocities.argtypes = [vp, vp, vp]
-    L.hx_sim_set_terrain.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.hx_sim_set_terrain.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
     L.hx_sim_set_terrain_curriculum.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, C.c_float]
     L.hx_sim_get_terrain_levels.argtypes = [vp, vp]
     L.hx_sim_episode_stats.argtypes = [vp, vp, vp]

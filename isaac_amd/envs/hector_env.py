@@ -77,6 +77,12 @@ class HectorFreeEnv(VecEnv):
         L = capi.lib()
         if str(sim_device).startswith("cuda") and ":" in str(sim_device):
             capi.check(L.hx_set_device(int(str(sim_device).split(":")[1])), "hx_set_device")
+        c, friction, mass, start, terrain_grid, rough = self._derive(cfg, sim_params, creation, env_range)
+        self._create(L, c, friction, mass, start, terrain_grid, rough, stream, init_pack)
+
+    def _derive(self, cfg, sim_params, creation, env_range):
+        """Everything the constructor computes on the host before the simulator exists: the flat C config, the
+        creation-time draws, the terrain.  No library call (tests drive the host build of the kernels with it)."""
         # ---- _parse_cfg (legged_robot.py:710-720)
         sim_dt = float(getattr(sim_params, "dt", cfg.sim.dt)) if sim_params is not None else float(cfg.sim.dt)
         self.dt = cfg.control.decimation * sim_dt
@@ -216,7 +222,13 @@ class HectorFreeEnv(VecEnv):
         c.terrain_mu = cfg.terrain.static_friction
         c.env_id_offset = self.env_lo
         self._ccfg = c
+        # slope_treshold of the trimesh conversion (utils/terrain.py:70-73): grid neighbours further apart in height than
+        # slope_threshold * horizontal_scale are joined by a vertical wall; 'heightfield' has no walls
+        self._wall = float(cfg.terrain.slope_treshold) * float(cfg.terrain.horizontal_scale) if (mesh_type == "trimesh" and getattr(cfg.terrain, "slope_treshold", None)) else 0.0
+        return c, friction, mass, start, terrain_grid, rough
 
+    def _create(self, L, c, friction, mass, start, terrain_grid, rough, stream, init_pack):
+        cfg = self.cfg
         seed = int(getattr(cfg, "seed", 0)) & 0xFFFFFFFF
         h = capi.C.c_void_p()
         capi.check(L.hx_sim_create(capi.C.byref(c), capi.ptr(capi.farr(friction)), capi.ptr(capi.farr(mass)),
@@ -229,7 +241,7 @@ class HectorFreeEnv(VecEnv):
             self.height_samples = hts
             capi.check(L.hx_sim_set_terrain(h, hts.ctypes.data, hts.shape[0], hts.shape[1],
                                             float(terrain_grid["horizontal_scale"]), float(terrain_grid["vertical_scale"]),
-                                            -float(terrain_grid["border_size"]), -float(terrain_grid["border_size"])),
+                                            -float(terrain_grid["border_size"]), -float(terrain_grid["border_size"]), self._wall),
                        "hx_sim_set_terrain")
         self._curriculum = bool(rough and cfg.terrain.curriculum)
         if self._curriculum:              # _update_terrain_curriculum (legged_robot.py:399-419) runs inside the env-step kernel

@@ -259,9 +259,9 @@ class HectorPhysics:
                     pen = -pw[:, 2]
                 else:
                     # distance to the plane of the terrain triangle under the point, along its normal
-                    h, nrm_w = self.terrain.query(pw[:, 0], pw[:, 1])
+                    pen, nrm_w = self.terrain.contact(pw[:, 0], pw[:, 1], pw[:, 2])
                     nrm_b = np.einsum("nji,nj->ni", Rb, nrm_w).astype(dtp)
-                    pen = ((h - pw[:, 2]) * nrm_w[:, 2]).astype(dtp)
+                    pen = pen.astype(dtp)
                 vb = v[body][:, 3:] + np.cross(v[body][:, :3], r)     # point velocity, body coords
                 vn = np.einsum("ni,ni->n", vb, nrm_b)
                 fn0 = CONTACT_KN * pen - c_n * vn

@@ -272,12 +272,17 @@ class HeightField:
     """Continuous surface over the grid: world x = i*hs - border, y = j*hs - border (the transform the reference
     gives the mesh, legged_robot.py:561-562,578-579); outside the grid the border row/column continues."""
 
-    def __init__(self, height_field_raw, horizontal_scale, vertical_scale, border_size):
+    def __init__(self, height_field_raw, horizontal_scale, vertical_scale, border_size, wall_height=0.0):
         # heights are held as float32 numbers, the precision of the mesh vertices the reference hands to the
         # simulator (convert_heightfield_to_trimesh returns float32) and of the device copy
         self.h = (np.asarray(height_field_raw, np.float64) * vertical_scale).astype(np.float32).astype(np.float64)
         self.hs = float(horizontal_scale)
         self.x0 = self.y0 = -float(border_size)
+        # mesh_type 'trimesh': slope_treshold * horizontal_scale (utils/terrain.py:70-73, legged_robot_config.py:67).  Where
+        # grid neighbours differ by more than this, convert_heightfield_to_trimesh moves the low vertex under the high one:
+        # the low ground continues flat through the cell and a vertical wall stands on the high vertices' grid line.
+        # 0 = 'heightfield' semantics (ramps).  PARITY UNPINNED like the rest of the contact model (isaacgym is absent).
+        self.wall = float(wall_height)
 
     def query(self, x, y):
         """(height [n], unit normal [n,3]) of the triangle under each (x, y)."""
@@ -290,6 +295,12 @@ class HeightField:
         fu = np.clip(u - i, 0.0, 1.0)
         fv = np.clip(v - j, 0.0, 1.0)
         h00, h10, h01, h11 = self.h[i, j], self.h[i + 1, j], self.h[i, j + 1], self.h[i + 1, j + 1]
+        if self.wall > 0.0:
+            # a cell that contains a wall: its "high" vertices (more than a wall height above the lowest one) have no
+            # surface inside the cell, the low level takes their place
+            lo = np.minimum(np.minimum(h00, h01), np.minimum(h10, h11))
+            cliff = np.maximum(np.maximum(h00, h01), np.maximum(h10, h11)) - lo > self.wall
+            h00, h01, h10, h11 = (np.where(cliff & (h - lo > self.wall), lo, h) for h in (h00, h01, h10, h11))
         upper = fv > fu                      # triangle (v00, v11, v01); otherwise (v00, v10, v11)
         gu = np.where(upper, h11 - h01, h10 - h00)
         gv = np.where(upper, h01 - h00, h11 - h10)
@@ -297,3 +308,34 @@ class HeightField:
         nrm = np.stack([-gu / self.hs, -gv / self.hs, np.ones_like(z)], -1)
         nrm /= np.sqrt(np.einsum("ni,ni->n", nrm, nrm))[:, None]
         return z, nrm
+
+    def contact(self, x, y, z):
+        """(penetration [n], unit normal [n,3]) of world points: distance to the plane of the triangle under the point, or
+        -- for a point below a plateau's surface that is closer to one of the plateau's walls than to the surface above it
+        -- the horizontal distance to that wall with the wall's outward normal (isaac_amd/csrc/hx_dyn.h wall_push)."""
+        h, nrm = self.query(x, y)
+        z = np.asarray(z, np.float64)
+        pen = (h - z) * nrm[:, 2]
+        if self.wall <= 0.0:
+            return pen, nrm
+        rows, cols = self.h.shape
+        u = (np.asarray(x, np.float64) - self.x0) / self.hs
+        v = (np.asarray(y, np.float64) - self.y0) / self.hs
+        i = np.clip(np.floor(u).astype(np.int64), 1, rows - 3)
+        j = np.clip(np.floor(v).astype(np.int64), 1, cols - 3)
+        fu = np.clip(u - i, 0.0, 1.0)
+        fv = np.clip(v - j, 0.0, 1.0)
+        jn = j + (fv > 0.5)
+        i_n = i + (fu > 0.5)
+        g, W = self.h, self.wall
+        best = pen.copy()
+        dirn = np.full(len(pen), -1)
+        for k, (top, low, d) in enumerate(((g[i, jn], g[i - 1, jn], fu * self.hs), (g[i + 1, jn], g[i + 2, jn], (1 - fu) * self.hs),
+                                           (g[i_n, j], g[i_n, j - 1], fv * self.hs), (g[i_n, j + 1], g[i_n, j + 2], (1 - fv) * self.hs))):
+            hit = (pen > 0) & (top - low > W) & (z < top) & (z > low - 0.5 * W) & (d < best)
+            best = np.where(hit, d, best)
+            dirn = np.where(hit, k, dirn)
+        normals = np.array([[-1.0, 0, 0], [1.0, 0, 0], [0, -1.0, 0], [0, 1.0, 0]])
+        hitany = dirn >= 0
+        nrm = np.where(hitany[:, None], normals[np.maximum(dirn, 0)], nrm)
+        return best, nrm

@@ -58,6 +58,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
             obj = getattr(obj, a)
         setattr(obj, parts[-1], v)
     cfg.env.num_envs = n_envs
+    gymapi.Gym.trimesh_wall_height = float(cfg.terrain.slope_treshold) * float(cfg.terrain.horizontal_scale) if cfg.terrain.mesh_type == "trimesh" else 0.0
     cfg.noise.add_noise = add_noise
     cfg.seed = seed
     helpers.set_seed(seed)
@@ -242,6 +243,7 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
         if terrain is not None:
             res["terrain_heights"] = np.asarray(env.terrain.heightsamples).copy()
             res["terrain_params"] = np.array([cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale, cfg.terrain.border_size])
+            res["terrain_wall_height"] = np.array(gymapi.Gym.trimesh_wall_height)
             res["terrain_levels"] = env.terrain_levels.numpy().copy()
             res["terrain_types"] = env.terrain_types.numpy().copy()
             res["terrain_origins"] = env.terrain_origins.numpy().copy()
@@ -264,7 +266,7 @@ if __name__ == "__main__":
     N = 8
     # A: ordinary rollout from the initial reset; falls (contact terminations) happen on their own
     if want("env_rollout_a"):
-        generate("env_rollout_a", N, 120, seed=5, action_std=1.0)
+        generate("env_rollout_a", 64, 60, seed=5, action_std=1.0)      # 64 robots (SURVEY 8d config 1's env count)
     # B: exercises the calendar events: command resampling (ep_len % 800 == 0), time-outs (> 2400),
     #    the global push (counter % 400 == 0); observation noise off so stacks are exact
     if want("env_rollout_b"):
@@ -273,8 +275,8 @@ if __name__ == "__main__":
     # C: rough terrain (the reference's default mesh_type): tile map from the reference's HumanoidTerrain,
     #    env origins on the tiles, reset xy offsets, contact against slopes / blocks / stairs
     if want("env_rollout_c"):
-        generate("env_rollout_c", N, 100, seed=5, action_std=0.6,
-                 ep_len_init=[0, 2350, 0, 0, 2380, 0, 0, 0],
+        generate("env_rollout_c", 64, 50, seed=5, action_std=0.6,
+                 ep_len_init=[0, 2350, 0, 0, 2380, 0, 0, 0] * 8,
                  terrain=dict(mesh_type="trimesh", num_rows=2, num_cols=4, border_size=3.0))
     # E: the four reward terms that HectorCfg zero-scales (joint_pos, low_speed, track_vel_hard, vel_mismatch_exp), switched
     #    on with the scales the sibling config hector_w_arm_config.py uses (:178-182) and humanoid_config's joint_pos 1.6:
@@ -300,10 +302,10 @@ if __name__ == "__main__":
                  ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390)
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others
-    #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 19 shows every
+    #    fall short of half their commanded distance (move down) or, with a zero command, stay.  Seed 21 shows every
     #    branch: 0->1 and 1->2 (up), 1->0 and 2->1 (down), 2->0 twice (past the last row -> random row)
     if want("env_rollout_d"):
-        generate("env_rollout_d", N, 150, seed=19, action_std=0.8,
+        generate("env_rollout_d", N, 150, seed=21, action_std=0.8,
                  ep_len_init=[2290, 2300, 2310, 2320, 0, 2340, 0, 2360],
                  terrain=dict(mesh_type="trimesh", curriculum=True, num_rows=3, num_cols=2, border_size=2.0,
                               terrain_length=1.6, terrain_width=1.6, max_init_terrain_level=2))

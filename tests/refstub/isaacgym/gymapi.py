@@ -118,7 +118,11 @@ class Gym:
         assert rows * cols == v.shape[0] and 2 * (rows - 1) * (cols - 1) == params.nb_triangles
         hs = round(float(v[cols, 0] - v[0, 0]), 6)          # float32 vertex spacing -> the configured scale
         assert params.transform.p.x == params.transform.p.y
-        self.terrain_hf = HeightField(v[:, 2].reshape(rows, cols), hs, 1.0, -params.transform.p.x)
+        # the reference hands over the slope-threshold mesh (utils/terrain.py:70-73): vertices next to a cliff are moved,
+        # which the height function restates as vertical walls (oracle/terrain.py HeightField.contact); the threshold is
+        # not recoverable from the mesh, the fixture generator sets it from the config it runs
+        self.terrain_hf = HeightField(v[:, 2].reshape(rows, cols), hs, 1.0, -params.transform.p.x,
+                                      wall_height=float(getattr(Gym, "trimesh_wall_height", 0.0)))
 
     def load_asset(self, sim, root, file, options):
         # the compiled model of the asset the task names: robot.urdf (hector) or robot_w_arm.urdf (hector_full)

@@ -26,7 +26,9 @@ def test_train_two_iterations_and_checkpoint_roundtrip(hxlib, tmp_path):
     # checkpoint format of on_policy_runner.py:278-287 and load :289-295
     import torch
     ck = torch.load(os.path.join(runner.log_dir, "model_2.pt"), map_location="cpu", weights_only=False)
-    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"} and ck["iter"] == 2
+    # the reference's four keys, plus the positions of the learner's counter-based random streams
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "iter", "infos", "hx_rng_state"} and ck["iter"] == 2
+    assert ck["hx_rng_state"][0] >= 120 and ck["hx_rng_state"][1] == 2        # 2 x 60 act calls, 2 permutations
     assert list(ck["model_state_dict"])[0] == "std" and ck["model_state_dict"]["actor.0.weight"].shape == (512, 615)
     before = runner.alg.actor_critic.state_dict()
     m0, v0, step0 = runner.alg.optimizer_state()

@@ -15,10 +15,17 @@ What "collapse" means here (PhysX does the same on import): every link reached t
 joint is merged into its nearest movable ancestor: masses add, centres of mass combine, inertia
 tensors are rotated into the ancestor frame and shifted with the parallel-axis theorem.
 
-Collision geometry: the reference's collision meshes for trunk / hips / thighs are absent from the
-checkout (.MISSING_LARGE_BLOBS); they fall back to the primitive boxes of const.xacro:17-19,128-133.
-The toe meshes foot_L2.stl / foot_R2.stl are present; their axis-aligned bounding box is used
-(PhysX would use the convex hull; for a flat ground both touch at the sole corners).
+Collision geometry (PhysX collides the convex hull of every collision mesh; a body's shape here is a set of points on
+that hull, tested against the ground):
+  * toes: foot_L2.stl / foot_R2.stl are present -- 12 support points of their convex hull (the sole's two ends, the
+    rounded tips and the top edge, on both side faces of the blade-shaped foot);
+  * base: body.stl is absent -> the trunk box of const.xacro:17-19; plus the six arm meshes that exist
+    (ShoulderYaw / ShoulderPitch / ForeArmPitch, both sides; robot.urdf fixes the arms to the trunk, so with
+    collapse_fixed_joints their shapes belong to the base -- they count for terminate_after_contacts_on=['base', ...]),
+    8 hull support points each; UpperArmRoll_*.stl is absent (no shape), the head's collision is a 1 mm box (ignored);
+  * hips: L_hip1.STL / L_hip2.STL are absent; hip.STL and hip2_L/R.STL of the same directory (simplified solids of these
+    two links, bounding boxes 8 x 5 x 6.5 cm and 7.5 x 5.5 x 5 cm) stand in, 8 hull support points each;
+  * thighs: thigh_combined_*2.stl is absent -> the box of const.xacro:128-133;  calves: no collision in the URDF.
 """
 import json
 import os
@@ -58,8 +65,8 @@ def parse_origin(el):
     return xyz, R
 
 
-def stl_bbox(path):
-    """Axis-aligned bounding box of a binary or ASCII STL."""
+def stl_points(path):
+    """All triangle vertices of a binary or ASCII STL, [n, 3]."""
     with open(path, "rb") as f:
         data = f.read()
     pts = []
@@ -75,7 +82,42 @@ def stl_bbox(path):
             if len(t) == 4 and t[0] == "vertex":
                 pts.append([float(t[1]), float(t[2]), float(t[3])])
         pts = np.array(pts)
+    return np.asarray(pts, np.float64)
+
+
+def stl_bbox(path):
+    """Axis-aligned bounding box of an STL."""
+    pts = stl_points(path)
     return pts.min(0), pts.max(0)
+
+
+DIAG8 = [(sx, sy, sz) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+
+
+def hull_support(pts, dirs):
+    """Support points of the convex hull of `pts` in the given directions (vertices of the hull; duplicates removed,
+    order of first appearance) -- an inner approximation of the hull that is exact along those directions."""
+    out, seen = [], set()
+    for d in dirs:
+        i = int(np.argmax(pts @ np.asarray(d, np.float64)))
+        key = tuple(np.round(pts[i], 6))
+        if key not in seen:
+            seen.add(key)
+            out.append(pts[i].tolist())
+    return out
+
+
+def foot_points(path):
+    """12 points of the foot hull.  The foot is a blade: a 2-D profile in x-z (flat sole 14 cm long at z = -0.04, tips
+    rounded with ~9 mm radius, ridge at z = +0.0125 above the ankle) extruded 1.8 cm in y.  Per side face: the two ends of
+    the flat sole, the two tip points, the two ends of the ridge."""
+    pts = stl_points(path)
+    out = []
+    for ysel in (-1.0, 1.0):
+        e = 1e-3 * ysel
+        out += hull_support(pts, [(-0.08, e, -1.0), (0.08, e, -1.0), (-1.0, e, -0.35), (1.0, e, -0.35), (-0.2, e, 1.0), (0.2, e, 1.0)])
+    assert len(out) == 12, len(out)
+    return out
 
 
 def collapse(urdf_path, sort_children=False):
@@ -168,19 +210,146 @@ def box_corners(center, size):
     return [(c + h * np.array([sx, sy, sz])).tolist() for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
 
 
-def leg_and_base_contacts(name_to_idx):
-    """The collision primitives of the biped proper (same for robot.urdf and robot_w_arm.urdf): see the module docstring."""
+def leg_and_base_contacts(name_to_idx, fixed_arms=False):
+    """Collision point sets of the biped proper (same for robot.urdf and robot_w_arm.urdf): see the module docstring.
+    fixed_arms: robot.urdf, whose arm links are fixed to the trunk -- their meshes become shapes of the base."""
     contacts = [{"body": name_to_idx["base"], "points": box_corners((0, 0, 0), (0.125, 0.19, 0.248)),
                  "source": "const.xacro:17-19 trunk box (body.stl absent)"}]
+    if fixed_arms:
+        contacts += fixed_arm_contacts(name_to_idx["base"])
     for side, sgn in (("L", 1.0), ("R", -1.0)):
+        for link, mesh in ((f"{side}_hip", "hip.STL"), (f"{side}_hip2", f"hip2_{side}.STL")):
+            pts = stl_points(os.path.join(MESH_DIR, mesh))
+            if link.endswith("_hip") and side == "R":
+                pts = pts * np.array([1.0, -1.0, 1.0])        # one hip.STL for both sides: mirror it for the right leg
+            contacts.append({"body": name_to_idx[link], "points": hull_support(pts, DIAG8),
+                             "source": f"{mesh} convex-hull support points (stand-in for the absent {side}_hip{'1' if link.endswith('_hip') else '2'}.STL)"})
         contacts.append({"body": name_to_idx[f"{side}_thigh"],
                          "points": box_corners((0, sgn * 0.0175, -0.09), (0.06, 0.035, 0.18)),
                          "source": "const.xacro:128-133 thigh box (thigh_combined_*2.stl absent)"})
-        lo, hi = stl_bbox(os.path.join(MESH_DIR, f"foot_{side}2.stl"))
-        ctr, size = (lo + hi) / 2, hi - lo
-        contacts.append({"body": name_to_idx[f"{side}_toe"], "points": box_corners(ctr, size),
-                         "source": f"foot_{side}2.stl axis-aligned bounding box", "bbox": [lo.tolist(), hi.tolist()]})
+        path = os.path.join(MESH_DIR, f"foot_{side}2.stl")
+        lo, hi = stl_bbox(path)
+        contacts.append({"body": name_to_idx[f"{side}_toe"], "points": foot_points(path),
+                         "source": f"foot_{side}2.stl convex-hull support points", "bbox": [lo.tolist(), hi.tolist()]})
     return contacts
+
+
+def fixed_arm_contacts(base_idx):
+    """robot.urdf:594-890: eight arm links hang off the trunk through FIXED joints.  Their collision meshes, placed by the
+    chain of joint origins, as 8 hull support points each in the base frame."""
+    root = ET.parse(URDF).getroot()
+    joints = {j.find("child").get("link"): j for j in root.findall("joint")}
+    out = []
+    for link in root.findall("link"):
+        nm = link.get("name")
+        if nm.split("_")[-1] not in ("twist", "shoulder", "roll", "elbow"):
+            continue
+        col = link.find("collision")
+        mesh = col.find("geometry").find("mesh") if col is not None and col.find("geometry") is not None else None
+        if mesh is None:
+            continue
+        path = os.path.normpath(os.path.join(os.path.dirname(URDF), mesh.get("filename")))
+        if not os.path.exists(path):
+            continue
+        chain, l = [], nm
+        while l in joints:
+            assert joints[l].get("type") == "fixed" or joints[l].find("parent").get("link") == "base", nm
+            chain.append(joints[l]); l = joints[l].find("parent").get("link")
+        p, R = np.zeros(3), np.eye(3)
+        for j in reversed(chain):
+            jp, jR = parse_origin(j.find("origin"))
+            p, R = p + R @ jp, R @ jR
+        co, cR = parse_origin(col.find("origin"))
+        pts = (stl_points(path) @ (R @ cR).T) + (p + R @ co)
+        out.append({"body": base_idx, "points": hull_support(pts, DIAG8),
+                    "source": f"{nm}: {os.path.basename(path)} convex-hull support points, fixed to the trunk"})
+    assert len(out) == 6, [o["source"] for o in out]
+    return out
+
+
+def emit_model_header(prefix, struct, title, bodies, contacts, nl, chains, path):
+    """C tables of one robot for the kernels and the host build (isaac_amd/csrc/hx_dyn.h reads them through a model
+    descriptor).  Per body side (left, then right) one table of `SIDE_STRIDE` floats:
+        joints  [nl][JSTRIDE]: 0-2 joint offset in the parent frame, 3-5 h = m * com, 6-11 inertia about the body-frame
+                origin (xx yy zz xy xz yz), 12 mass, 13 q_lo, 14 q_hi, 15 v_max, and for robots with rotated joint frames
+                16-24 the constant child -> parent rotation (row-major)
+        shapes  per body with collision points, in body order: bounding sphere (centre xyz, radius), then the points
+    and one base table: bounding sphere, base points (an even count: the two lanes of a robot take half each), then
+    inertia (6), h (3), mass."""
+    by_body = {}
+    for c in contacts:
+        by_body.setdefault(c["body"], []).extend(c["points"])
+    has_rot = any("rot" in b for b in bodies)
+    jstride = 28 if has_rot else 16
+
+    def Io(bd):
+        c = np.array(bd["com"]); m = bd["mass"]
+        I = np.array(bd["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
+        return [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+
+    def sphere(pts):
+        pts = np.array(pts)
+        ctr = (pts.min(0) + pts.max(0)) / 2
+        return list(ctr) + [float(np.sqrt(((pts - ctr) ** 2).sum(1)).max())]
+
+    def flit(v):
+        t = "%.9g" % v
+        if "." not in t and "e" not in t and "n" not in t:
+            t += ".0"
+        return t + "f"
+
+    npts = [len(by_body.get(1 + k, [])) for k in range(nl)]
+    assert npts == [len(by_body.get(1 + nl + k, [])) for k in range(nl)], "both sides must carry the same point counts"
+    pts_off, off = [], nl * jstride
+    for k in range(nl):
+        pts_off.append(off if npts[k] else -1)
+        off += (4 + 3 * npts[k]) if npts[k] else 0
+    side_stride = (off + 3) // 4 * 4
+    side = []
+    for sd in range(2):
+        row = []
+        for k in range(nl):
+            bd = bodies[1 + sd * nl + k]
+            j = list(bd["offset"]) + list(bd["mass"] * np.array(bd["com"])) + Io(bd) + [bd["mass"], bd["lower"], bd["upper"], bd["velocity"]]
+            if has_rot:
+                j += list(np.array(bd.get("rot", np.eye(3))).reshape(-1)) + [0.0, 0.0, 0.0]
+            assert len(j) == jstride
+            row += j
+        for k in range(nl):
+            pts = by_body.get(1 + sd * nl + k, [])
+            if pts:
+                row += sphere(pts) + [x for pt in pts for x in pt]
+        row += [0.0] * (side_stride - len(row))
+        side += row
+    base_pts = by_body.get(0, [])
+    if len(base_pts) % 2:
+        base_pts = base_pts + [base_pts[-1]]
+    base = sphere(base_pts) + [x for pt in base_pts for x in pt] + Io(bodies[0]) + list(bodies[0]["mass"] * np.array(bodies[0]["com"])) + [bodies[0]["mass"]]
+    axis = [bodies[1 + k]["axis"] for k in range(nl)]
+    assert axis == [bodies[1 + nl + k]["axis"] for k in range(nl)]
+    ints = lambda v: ", ".join(str(x) for x in v)
+    L = [f"// GENERATED by tools/compile_urdf.py from the reference's {title} -- do not edit.",
+         "#pragma once",
+         f"struct {struct} {{",
+         f"  static constexpr int NL = {nl};                 // joints per body side",
+         f"  static constexpr int NCH = {len(chains)};                // kinematic chains per side, each hanging off the base",
+         f"  static constexpr int CH_START[{len(chains)}] = {{{ints(c[0] for c in chains)}}};",
+         f"  static constexpr int CH_LEN[{len(chains)}] = {{{ints(c[1] for c in chains)}}};",
+         f"  static constexpr int AXIS[{nl}] = {{{ints(axis)}}};",
+         f"  static constexpr bool HAS_ROT = {'true' if has_rot else 'false'};",
+         f"  static constexpr int JSTRIDE = {jstride};",
+         f"  static constexpr int NPTS[{nl}] = {{{ints(npts)}}};        // collision points per side-local body",
+         f"  static constexpr int PTS_OFF[{nl}] = {{{ints(pts_off)}}};   // float offset of the body's [sphere 4][points 3 * n] block",
+         f"  static constexpr int SIDE_STRIDE = {side_stride};",
+         f"  static constexpr int NBASE = {len(base_pts)};",
+         f"  static constexpr int BASE_FLOATS = {len(base)};",
+         "};",
+         f"HX_TABLE float {prefix}_SIDE[{len(side)}] = {{{', '.join(flit(v) for v in side)}}};",
+         f"HX_TABLE float {prefix}_BASE[{len(base)}] = {{{', '.join(flit(v) for v in base)}}};",
+         f"static constexpr float {prefix}_MASS0 = {flit(bodies[0]['mass'])};",
+         f"static constexpr float {prefix}_EFFORT[{2 * nl}] = {{{', '.join(flit(b['effort']) for b in bodies[1:])}}};"]
+    with open(path, "w") as f:
+        f.write("\n".join(L) + "\n")
 
 
 def main_full():
@@ -213,49 +382,14 @@ def main_full():
         o, R = parse_origin(col.find("origin"))
         assert np.allclose(R, np.eye(3))
         lo, hi = stl_bbox(path)
-        contacts.append({"body": name_to_idx[nm], "points": box_corners(o + (lo + hi) / 2, hi - lo),
-                         "source": os.path.basename(path) + " axis-aligned bounding box", "bbox": [lo.tolist(), hi.tolist()]})
+        contacts.append({"body": name_to_idx[nm], "points": hull_support(stl_points(path) + o, DIAG8),
+                         "source": os.path.basename(path) + " convex-hull support points", "bbox": [lo.tolist(), hi.tolist()]})
     model = {"source": "resources/robots/hector_v2/xacro/robot_w_arm.urdf (collapse_fixed_joints, children in alphabetical order)",
              "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": contacts}
     with open(os.path.join(ROOT, "isaac_amd/assets/hector_full_model.json"), "w") as f:
         json.dump(model, f, indent=1)
-    # ---- C header for the kernels: per-side table (leg 5 + arm 4 bodies of 16 floats, then 5 corner blocks of 24
-    #      floats: thigh, toe, twist, shoulder, elbow) and the base constants
-    def flit(v):
-        t = "%.9g" % v
-        if "." not in t and "e" not in t and "n" not in t:
-            t += ".0"
-        return t + "f"
-
-    def Io(bd):
-        c = np.array(bd["com"]); m = bd["mass"]
-        I = np.array(bd["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
-        return [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
-
-    by_body = {c["body"]: c for c in contacts}
-    sidec = []
-    for side in range(2):
-        row = []
-        for k in range(9):
-            bd = bodies[1 + side * 9 + k]
-            row += list(bd["offset"]) + list(bd["mass"] * np.array(bd["com"])) + Io(bd) + [bd["mass"], bd["lower"], bd["upper"], bd["velocity"]]
-        for nm in ("thigh", "toe", "twist", "shoulder", "elbow"):
-            c = by_body.get(name_to_idx[("L_" if side == 0 else "R_") + nm])
-            assert c is not None, nm
-            row += [x for pt in c["points"] for x in pt]
-        assert len(row) == 9 * 16 + 5 * 24
-        sidec += row
-    L = ["// GENERATED by tools/compile_urdf.py --full from the reference's robot_w_arm.urdf -- do not edit.",
-         "// 19 collapsed bodies / 18 revolute joints in Isaac Gym order: L leg, L arm, R leg, R arm.",
-         "#pragma once", "#define HXF_SIDE_STRIDE 264",
-         "__device__ static const float HXF_SIDEC[528] = {%s};" % ", ".join(flit(v) for v in sidec),
-         "__device__ static const float HXF_BASE_PTS[24] = {%s};" % ", ".join(flit(x) for pt in contacts[0]["points"] for x in pt),
-         "static constexpr float HXF_IO[6] = {%s};" % ", ".join(flit(v) for v in Io(bodies[0])),
-         "static constexpr float HXF_H[3] = {%s};" % ", ".join(flit(bodies[0]["mass"] * x) for x in bodies[0]["com"]),
-         "static constexpr float HXF_MASS0 = %s;" % flit(bodies[0]["mass"]),
-         "static constexpr float HXF_EFFORT[18] = {%s};" % ", ".join(flit(b["effort"]) for b in bodies[1:])]
-    with open(os.path.join(ROOT, "isaac_amd/csrc/hx_model_data_full.h"), "w") as f:
-        f.write("\n".join(L) + "\n")
+    emit_model_header("HXF", "HXM_Full", "robot_w_arm.urdf (19 bodies / 18 revolute joints in Isaac Gym order: L leg, L arm, R leg, R arm)",
+                      bodies, contacts, 9, [(0, 5), (5, 4)], os.path.join(ROOT, "isaac_amd/csrc/hx_model_data_full.h"))
     for i, b in enumerate(bodies):
         print(i, b["name"], "parent", b["parent"], "m=%.5f" % b["mass"], b.get("joint"), b.get("axis"))
     print("total mass %.5f" % model["total_mass"])
@@ -284,6 +418,8 @@ def main_xbot():
              "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": contacts}
     with open(os.path.join(ROOT, "isaac_amd/assets/xbot_model.json"), "w") as f:
         json.dump(model, f, indent=1)
+    emit_model_header("HXX", "HXM_XBot", "XBot-L.urdf (13 bodies / 12 revolute joints about the z axes of rotated joint frames)",
+                      bodies, contacts, 6, [(0, 6)], os.path.join(ROOT, "isaac_amd/csrc/hx_model_data_xbot.h"))
     for i, b in enumerate(bodies):
         print(i, b["name"], "parent", b["parent"], "m=%.5f" % b["mass"], b.get("joint"), b.get("axis"), "rot" in b)
     print("total mass %.5f" % model["total_mass"])
@@ -296,7 +432,7 @@ def main():
 
     # collision primitives: list of (body index, [points in body frame])
     name_to_idx = {b["name"]: i for i, b in enumerate(bodies)}
-    contacts = leg_and_base_contacts(name_to_idx)
+    contacts = leg_and_base_contacts(name_to_idx, fixed_arms=True)
 
     model = {"source": "resources/robots/hector_v2/xacro/robot.urdf (collapse_fixed_joints)",
              "total_mass": total, "bodies": bodies, "contacts": contacts}
@@ -304,70 +440,8 @@ def main():
     with open(os.path.join(ROOT, "isaac_amd/assets/hector_model.json"), "w") as f:
         json.dump(model, f, indent=1)
 
-    # ---- C header ----
-    L = []
-    L.append("// GENERATED by tools/compile_urdf.py from the reference's robot.urdf -- do not edit.")
-    L.append("// 11 collapsed bodies / 10 revolute joints; body i>0 is driven by joint i-1.")
-    L.append("#pragma once")
-    L.append("#define HX_NB 11")
-    L.append("#define HX_NJ 10")
-
-    def flit(v):
-        t = "%.9g" % v
-        if "." not in t and "e" not in t and "n" not in t:
-            t += ".0"
-        return t + "f"
-
-    def arr(name, vals):
-        L.append("static constexpr float %s[%d] = {%s};" % (name, len(vals), ", ".join(flit(v) for v in vals)))
-
-    def iarr(name, vals):
-        L.append("static constexpr int %s[%d] = {%s};" % (name, len(vals), ", ".join(str(v) for v in vals)))
-
-    iarr("HXM_PARENT", [b["parent"] for b in bodies])
-    iarr("HXM_AXIS", [b.get("axis", -1) for b in bodies])
-    arr("HXM_MASS", [b["mass"] for b in bodies])
-    arr("HXM_COM", [x for b in bodies for x in b["com"]])
-    arr("HXM_ICOM", [np.array(b["inertia_com"])[i, j] for b in bodies
-                     for (i, j) in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
-    # spatial inertia about the body-frame origin: I = [[Io, hx],[hx^T, m 1]], h = m*com,
-    # Io = Ic + m (c.c 1 - c c^T)   (6 values: xx yy zz xy xz yz)
-    io = []
-    for b in bodies:
-        c = np.array(b["com"]); m = b["mass"]
-        Io = np.array(b["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
-        io += [Io[0, 0], Io[1, 1], Io[2, 2], Io[0, 1], Io[0, 2], Io[1, 2]]
-    arr("HXM_IO", io)
-    arr("HXM_H", [b["mass"] * x for b in bodies for x in b["com"]])
-    arr("HXM_OFFSET", [x for b in bodies for x in b.get("offset", [0, 0, 0])])
-    arr("HXM_QLO", [b["lower"] for b in bodies[1:]])
-    arr("HXM_QHI", [b["upper"] for b in bodies[1:]])
-    arr("HXM_VMAX", [b["velocity"] for b in bodies[1:]])
-    arr("HXM_EFFORT", [b["effort"] for b in bodies[1:]])
-    iarr("HXM_CONTACT_BODY", [c["body"] for c in contacts])
-    arr("HXM_CONTACT_PTS", [x for c in contacts for p in c["points"] for x in p])
-    L.append("#define HX_NCSHAPE %d" % len(contacts))
-    # per-leg constant table staged in LDS by the two-lanes-per-robot kernel:
-    # leg l, local body b (0 hip, 1 hip2, 2 thigh, 3 calf, 4 toe) at [l*128 + b*16 + ...]:
-    #   0-2 joint offset, 3-5 h = m*com, 6-11 Io (xx yy zz xy xz yz), 12 mass, 13 q_lo, 14 q_hi, 15 v_max
-    # then 24 floats thigh box corners at [l*128 + 80], 24 floats toe box corners at [l*128 + 104]
-    legc = []
-    for leg in range(2):
-        row = []
-        for b in range(5):
-            bd = bodies[1 + leg * 5 + b]
-            c = np.array(bd["com"]); m = bd["mass"]
-            Io = np.array(bd["inertia_com"]) + m * (c @ c * np.eye(3) - np.outer(c, c))
-            row += list(bd["offset"]) + list(m * c) + [Io[0, 0], Io[1, 1], Io[2, 2], Io[0, 1], Io[0, 2], Io[1, 2]]
-            row += [m, bd["lower"], bd["upper"], bd["velocity"]]
-        row += [x for pt in contacts[1 + 2 * leg]["points"] for x in pt]
-        row += [x for pt in contacts[2 + 2 * leg]["points"] for x in pt]
-        assert len(row) == 128
-        legc += row
-    L.append("#define HX_LEGC_STRIDE 128")
-    L.append("__device__ static const float HXM_LEGC[256] = {%s};" % ", ".join(flit(v) for v in legc))
-    with open(os.path.join(ROOT, "isaac_amd/csrc/hx_model_data.h"), "w") as f:
-        f.write("\n".join(L) + "\n")
+    emit_model_header("HXM", "HXM_Hector", "robot.urdf (11 collapsed bodies / 10 revolute joints; body i > 0 is driven by joint i - 1)",
+                      bodies, contacts, 5, [(0, 5)], os.path.join(ROOT, "isaac_amd/csrc/hx_model_data.h"))
 
     print("bodies:")
     for i, b in enumerate(bodies):
