@@ -196,6 +196,9 @@ int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h);
  * count_h: episodes finished since the last call.  The call starts a new iteration's accumulation. */
 int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS + 2]*/, int32_t* count_h);
 void* hx_sim_stream(hx_sim* s);
+/* measurement hook: per-phase shader-clock cycles of the env-step kernel, summed over waves and launches; meaningful only in a
+ * library built with -DHX_STEP_PROF (tools/step_prof.py), all zeros otherwise.  which = 1 start / clear, 0 read. */
+int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[9]*/);
 int hx_sync(void* hip_stream);
 
 #ifdef __cplusplus

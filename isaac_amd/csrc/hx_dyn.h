@@ -48,38 +48,78 @@ template <class M> struct ModelInfo {
   static constexpr int slot(int B) { int n = 0; for (int k = 0; k < B; ++k) n += M::NPTS[k] > 0 ? 1 : 0; return M::NPTS[B] > 0 ? n : -1; }
   static constexpr int chain_start_of(int B) { int s = 0; for (int c = 0; c < M::NCH; ++c) if (B >= M::CH_START[c] && B < M::CH_START[c] + M::CH_LEN[c]) s = M::CH_START[c]; return s; }
   static constexpr int NSHAPE = nshape();
-  static constexpr int LDS_FLOATS = 2 * M::SIDE_STRIDE + M::BASE_FLOATS + 2 * M::NL * 4;
+  static constexpr int NSLOT = NSHAPE + 1;                 // contact-buffer slots of a lane: its shape bodies, then the base
+  static constexpr int NENT = NSHAPE + M::BASE_NSUB;       // entries of the lane's contact loop: shape bodies, then its base sub-shapes
+  static constexpr int PD_OFF = 2 * M::SIDE_STRIDE + M::BASE_FLOATS;
+  static constexpr int ENT_OFF = PD_OFF + 2 * M::NL * 4;   // [side][NENT][3] ints: float offset of the shape block, points, buffer slot
+  static constexpr int LDS_FLOATS = ENT_OFF + 2 * NENT * 3;
 };
 
 // Terrain: each robot keeps a HX_PATCH x HX_PATCH window of the height grid (metres, fp32) in LDS, centred on its
 // base at the start of the env step; `patch == nullptr` selects the ground plane z = 0.
 #define HX_PATCH 16
+#define HX_POOL 8
+#define HX_PATCH_LD (HX_PATCH * HX_PATCH + 1)      /* per-robot LDS strides: odd, so that the 32 robots of a wave reading the */
+#define HX_POOL_LD (HX_POOL * HX_POOL + 1)          /* same cell of their own windows hit 32 different banks */
 struct DynParams {
   float dt, gz, kn, dn, veps, lim_k, lim_d, mu;
   const float* patch;     // LDS, [HX_PATCH][HX_PATCH] row-major (row = x index), or nullptr
   float px0, py0;         // world x / y of patch node (0, 0)
   float inv_hs;           // 1 / horizontal_scale
-  float zmax;             // highest node of the patch: points above it cannot touch
-  float zmax_near;        // highest node of the central (HX_PATCH/2 + 1)^2 nodes: the bound for points over that part
+  const float* pool;      // LDS, [HX_POOL][HX_POOL]: pool[I][J] = highest node among nodes 2I-2 .. 2I+4 x 2J-2 .. 2J+4 of the
+                          // patch -- an upper bound of the surface under any point whose cell (i, j) has (i/2, j/2) = (I, J),
+                          // and under a whole shape of bounding radius <= 0.2 m centred over such a cell
+  const float* poolw;     // LDS, same shape: 1 if two neighbouring nodes of that region differ by more than `wall` (only then
+                          // can a point over cell (I, J) meet a wall or a cliff cell), else 0
   float wall;             // height difference between grid neighbours beyond which the trimesh has a vertical wall
                           // (slope_treshold * horizontal_scale, reference utils/terrain.py:70-73); 0 = no walls (heightfield)
+  long long* prof;        // measurement builds (-DHX_STEP_PROF): per-wave cycle counters in LDS, else unused
 };
+// Phase timers of the env-step kernel (tools/step_prof.py): lane 0 of a wave adds the shader-clock cycles since the
+// previous mark to counter `id`.  Compiled out unless -DHX_STEP_PROF.
+#if defined(HX_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define HX_T(prof, id) do { if ((prof) != nullptr && threadIdx.x == 0) { const long long t_ = clock64(); (prof)[id] += t_ - (prof)[15]; (prof)[15] = t_; } } while (0)
+#else
+#define HX_T(prof, id) do { } while (0)
+#endif
 
-// stage the per-side tables, the base table and the PD constants of both sides (pd_src: kp[ND], kd[ND], tau_lim[ND],
-// default_pos[ND] in DoF order = left side then right side) into LDS; call with all threads, then synchronise
+// stage the per-side tables, the base table, the PD constants of both sides (kp[ND], kd[ND], tau_lim[ND], default_pos[ND]
+// in DoF order = left side then right side) and the contact-loop entry tables into LDS; call with all threads, then
+// synchronise
 template <class M> HXD void dyn_stage_constants(float* lds, int tid, int nthreads, const float* kp, const float* kd, const float* tl, const float* q0) {
+  using MI = ModelInfo<M>;
   for (int i = tid; i < 2 * M::SIDE_STRIDE; i += nthreads) lds[i] = M::side_table()[i];
   for (int i = tid; i < M::BASE_FLOATS; i += nthreads) lds[2 * M::SIDE_STRIDE + i] = M::base_table()[i];
-  float* pd = lds + 2 * M::SIDE_STRIDE + M::BASE_FLOATS;
+  float* pd = lds + MI::PD_OFF;
   for (int i = tid; i < 2 * M::NL; i += nthreads) { pd[4 * i] = kp[i]; pd[4 * i + 1] = kd[i]; pd[4 * i + 2] = tl[i]; pd[4 * i + 3] = q0[i]; }
+  int* ent = reinterpret_cast<int*>(lds + MI::ENT_OFF);
+  for (int i = tid; i < 2 * MI::NENT; i += nthreads) {
+    const int side = i / MI::NENT, e = i % MI::NENT;
+    int off = 0, np = 0, slot = 0;
+    if (e < MI::NSHAPE) {
+      int b = 0;
+      for (int k = 0; k < M::NL; ++k) if (MI::slot(k) == e) b = k;
+      off = side * M::SIDE_STRIDE + M::PTS_OFF[b]; np = M::NPTS[b]; slot = e;
+    } else {
+      off = 2 * M::SIDE_STRIDE + (side * M::BASE_NSUB + (e - MI::NSHAPE)) * (4 + 3 * M::BASE_NP); np = M::BASE_NP; slot = MI::NSHAPE;
+    }
+    ent[3 * i] = off; ent[3 * i + 1] = np; ent[3 * i + 2] = slot;
+  }
 }
 
 // one side's view of the constants
 template <class M> struct SideConst {
+  const float* lds;    // all staged constants
   const float* t;      // side table
-  const float* bt;     // base table: sphere 4, points 3 * NBASE, inertia 6, h 3, mass
+  const float* bt;     // base table: 2 x BASE_NSUB sub-shapes [sphere 4][points 3 * BASE_NP], then inertia 6, h 3, mass
   const float* pd;     // [NL][4] kp, kd, tau_lim, default position of this side's joints
-  HXD void bind(const float* lds, int side) { t = lds + side * M::SIDE_STRIDE; bt = lds + 2 * M::SIDE_STRIDE; pd = bt + M::BASE_FLOATS + side * M::NL * 4; }
+  const int* ent;      // [NENT][3] contact-loop entries of this side
+  const float* bsub;   // this lane's BASE_NSUB base sub-shapes
+  HXD void bind(const float* l, int side) {
+    lds = l; t = l + side * M::SIDE_STRIDE; bt = l + 2 * M::SIDE_STRIDE; pd = l + ModelInfo<M>::PD_OFF + side * M::NL * 4;
+    ent = reinterpret_cast<const int*>(l + ModelInfo<M>::ENT_OFF) + side * ModelInfo<M>::NENT * 3;
+    bsub = bt + side * M::BASE_NSUB * (4 + 3 * M::BASE_NP);
+  }
   HXD V3 off(int b) const { return ld3(t + b * M::JSTRIDE); }
   HXD V3 h(int b) const { return ld3(t + b * M::JSTRIDE + 3); }
   HXD float mass(int b) const { return t[b * M::JSTRIDE + 12]; }
@@ -102,10 +142,10 @@ template <class M> struct SideConst {
   }
   HXD SI inertia(int b) const { return spatial(t + b * M::JSTRIDE + 6, h(b), mass(b), 1.0f); }
   HXD const float* shape(int b) const { return t + M::PTS_OFF[b]; }        // sphere (centre xyz, radius), then the points
-  HXD const float* base_shape() const { return bt; }
-  HXD V3 base_h() const { return ld3(bt + 4 + 3 * M::NBASE + 6); }
-  HXD float base_mass() const { return bt[4 + 3 * M::NBASE + 9]; }
-  HXD SI base_inertia(float s) const { return spatial(bt + 4 + 3 * M::NBASE, base_h(), base_mass(), s); }
+  static constexpr int BASE_IO = 2 * M::BASE_NSUB * (4 + 3 * M::BASE_NP);
+  HXD V3 base_h() const { return ld3(bt + BASE_IO + 6); }
+  HXD float base_mass() const { return bt[BASE_IO + 9]; }
+  HXD SI base_inertia(float s) const { return spatial(bt + BASE_IO, base_h(), base_mass(), s); }
 };
 
 // v x* (I v) for a rigid body with spatial inertia `in` (H = skew(h), M = m 1)
@@ -122,12 +162,12 @@ HXD SV rb_bias(const SI& in, V3 hh, float m, SV v) {
 // vertices the reference moved under the high ones (slope_treshold, utils/terrain.py:70-73): the low ground continues
 // flat through the cell and a vertical wall stands on the high vertices' grid line.  Such a cell returns its low level
 // here; the wall itself is handled by wall_push() for points that have crossed it.
-HXD float terrain_query(const DynParams& P, float u, float w, V3& nw) {
+HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls) {
   const int i = hx_imin(hx_imax((int)floorf(u), 0), HX_PATCH - 2), j = hx_imin(hx_imax((int)floorf(w), 0), HX_PATCH - 2);
   const float fu = fminf(fmaxf(u - (float)i, 0.f), 1.f), fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
   const float* c = P.patch + i * HX_PATCH + j;
   float h00 = c[0], h01 = c[1], h10 = c[HX_PATCH], h11 = c[HX_PATCH + 1];
-  if (P.wall > 0.f) {
+  if (hx_any(walls)) {
     const float lo = fminf(fminf(h00, h01), fminf(h10, h11));
     if (fmaxf(fmaxf(h00, h01), fmaxf(h10, h11)) - lo > P.wall) {
       // vertices standing more than a wall height above the cell's lowest one are "high": the mesh has no surface of
@@ -171,45 +211,113 @@ HXD bool wall_push(const DynParams& P, float u, float w, float z, float& pen, V3
   return true;
 }
 
-// Accumulate the contact terms of points [p0, p0 + npts) of a shape (`shp`: bounding sphere, then xyz triples; LDS) on a
-// body with spatial velocity v (body coords), body->world rotation Rb and world position pb of the body origin.
-// a_true == nullptr: f0 += explicit spatial force, B += implicit 6x6.
-// a_true != nullptr: returns the implicit-consistent net force (body coords)  sum_c [f0_c - K_c Xc a].
-// Plane: normal = world z, penetration = -z.  Terrain: normal of the triangle under the point, penetration = distance to
-// that triangle's plane; or the wall the point went through (wall_push).
-HXD V3 contact_points(const DynParams& P, const float* shp, int p0, int npts, SV v, const M3& Rb, V3 pb, SV& f0, SI& B, const SV* a_true) {
-  V3 net = mk(0.f, 0.f, 0.f);
-  const V3 zb = row(Rb, 2);          // world z in body coords
-  {
-    // bounding sphere of the whole shape: nothing of it can touch while its lowest possible point is above the ground's
-    // highest one (0 on the plane, the patch maximum on terrain)
-    const float zc = pb.z + dot(zb, ld3(shp)) - shp[3];
-    if (!hx_any(zc < ((P.patch != nullptr) ? P.zmax : 0.f))) return net;
+// index of the pool entry over patch coordinates (u, w): see DynParams::pool
+HXD int terrain_pool_index(float u, float w) {
+  const int i = hx_imin(hx_imax((int)floorf(u), 0), HX_PATCH - 2), j = hx_imin(hx_imax((int)floorf(w), 0), HX_PATCH - 2);
+  return (i >> 1) * HX_POOL + (j >> 1);
+}
+// Per-lane contact buffer.  The contact phase of a substep is ONE runtime loop over the lane's collision shapes (a single
+// instance of the point loop in the instruction stream instead of one inlined copy per shape); it takes each shape's body
+// state from this buffer and leaves the accumulated explicit force f0 and implicit 6x6 term B there for the articulated-
+// inertia pass, and for the net contact forces read after the accelerations are known.  Device: LDS, [slot][field][lane];
+// host: a local array (stride 1).
+#define HX_CB_V 0        /* in : spatial velocity of the body, body coords (w, v)            6 */
+#define HX_CB_R 6        /* in : body -> world rotation, row-major                            9 */
+#define HX_CB_P 15       /* in : world position of the body origin                            3 */
+#define HX_CB_F 18       /* out: f0 (w, v)                                                     6 */
+#define HX_CB_A 24       /* out: B.A symmetric (xx xy xz yy yz zz)                             6 */
+#define HX_CB_H 30       /* out: B.H row-major                                                 9 */
+#define HX_CB_M 39       /* out: B.M symmetric                                                 6 */
+#define HX_CB_FIELDS 45
+struct ContactBuf {
+  float* base; int stride;
+  HXD float& at(int slot, int field) const { return base[(slot * HX_CB_FIELDS + field) * stride]; }
+  HXD void put_body(int slot, const SV& v, const M3& Rb, V3 pb) const {
+    at(slot, HX_CB_V) = v.w.x; at(slot, HX_CB_V + 1) = v.w.y; at(slot, HX_CB_V + 2) = v.w.z;
+    at(slot, HX_CB_V + 3) = v.v.x; at(slot, HX_CB_V + 4) = v.v.y; at(slot, HX_CB_V + 5) = v.v.z;
+    for (int i = 0; i < 9; ++i) at(slot, HX_CB_R + i) = Rb.m[i];
+    at(slot, HX_CB_P) = pb.x; at(slot, HX_CB_P + 1) = pb.y; at(slot, HX_CB_P + 2) = pb.z;
   }
+  HXD M3 rot_of(int slot) const { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = at(slot, HX_CB_R + i); return r; }
+  // f0 and B of a slot added to (IA, pA):  IA += B ;  pA += -f0 + B g   (g = gravity field in body coords, linear part only)
+  HXD void add_to(int slot, SI& IA, SV& pA, V3 g) const {
+    SV f0; f0.w = mk(at(slot, HX_CB_F), at(slot, HX_CB_F + 1), at(slot, HX_CB_F + 2)); f0.v = mk(at(slot, HX_CB_F + 3), at(slot, HX_CB_F + 4), at(slot, HX_CB_F + 5));
+    SI B;
+    const float axx = at(slot, HX_CB_A), axy = at(slot, HX_CB_A + 1), axz = at(slot, HX_CB_A + 2), ayy = at(slot, HX_CB_A + 3), ayz = at(slot, HX_CB_A + 4), azz = at(slot, HX_CB_A + 5);
+    B.A.m[0] = axx; B.A.m[1] = axy; B.A.m[2] = axz; B.A.m[3] = axy; B.A.m[4] = ayy; B.A.m[5] = ayz; B.A.m[6] = axz; B.A.m[7] = ayz; B.A.m[8] = azz;
+    for (int i = 0; i < 9; ++i) B.H.m[i] = at(slot, HX_CB_H + i);
+    const float mxx = at(slot, HX_CB_M), mxy = at(slot, HX_CB_M + 1), mxz = at(slot, HX_CB_M + 2), myy = at(slot, HX_CB_M + 3), myz = at(slot, HX_CB_M + 4), mzz = at(slot, HX_CB_M + 5);
+    B.M.m[0] = mxx; B.M.m[1] = mxy; B.M.m[2] = mxz; B.M.m[3] = mxy; B.M.m[4] = myy; B.M.m[5] = myz; B.M.m[6] = mxz; B.M.m[7] = myz; B.M.m[8] = mzz;
+    siadd(IA, B);
+    SV gg; gg.w = mk(0.f, 0.f, 0.f); gg.v = g;
+    pA = pA - f0 + mulSI(B, gg);
+  }
+  // implicit-consistent net force of a slot (body coords):  sum_c [f_c - K_c Xc a] = f0.v - (B a).v = f0.v - (H^T a.w + M a.v)
+  HXD V3 net_force(int slot, const SV& a) const {
+    M3 H; for (int i = 0; i < 9; ++i) H.m[i] = at(slot, HX_CB_H + i);
+    const float mxx = at(slot, HX_CB_M), mxy = at(slot, HX_CB_M + 1), mxz = at(slot, HX_CB_M + 2), myy = at(slot, HX_CB_M + 3), myz = at(slot, HX_CB_M + 4), mzz = at(slot, HX_CB_M + 5);
+    const V3 ma = mk(mxx * a.v.x + mxy * a.v.y + mxz * a.v.z, mxy * a.v.x + myy * a.v.y + myz * a.v.z, mxz * a.v.x + myz * a.v.y + mzz * a.v.z);
+    return mk(at(slot, HX_CB_F + 3), at(slot, HX_CB_F + 4), at(slot, HX_CB_F + 5)) - (mulT(H, a.w) + ma);
+  }
+};
+
+// Bounding-sphere test of a shape (`shp`: centre xyz + radius, then the points) on a body with world pose (Rb, pb): can any
+// lane's shape touch at all?  Nothing of it can while its lowest possible point is above the highest ground in reach: 0 on
+// the plane; on terrain the pooled maximum around the sphere's centre (radius <= 0.2 m: one pool entry; wider shapes: the
+// 3 x 3 entries around, reach 0.4 m).  Wave-uniform result.  Runs in the kinematics pass, where the pose is in registers,
+// so that the contact loop only ever visits shapes that may touch.
+HXD bool shape_maybe(const DynParams& P, const float* shp, const M3& Rb, V3 pb) {
+  const V3 c = ld3(shp);
+  const float zlow = pb.z + dot(row(Rb, 2), c) - shp[3];
+  float bound = 0.f;
+  if (P.patch != nullptr) {
+    const float u = (pb.x + dot(row(Rb, 0), c) - P.px0) * P.inv_hs, w = (pb.y + dot(row(Rb, 1), c) - P.py0) * P.inv_hs;
+    const int pi = terrain_pool_index(u, w);
+    bound = P.pool[pi];
+    if (shp[3] > 0.2f) {            // uniform branch
+      const int i = pi / HX_POOL, j = pi % HX_POOL;
+      for (int a = hx_imax(i - 1, 0); a <= hx_imin(i + 1, HX_POOL - 1); ++a)
+        for (int b = hx_imax(j - 1, 0); b <= hx_imin(j + 1, HX_POOL - 1); ++b) bound = fmaxf(bound, P.pool[a * HX_POOL + b]);
+    }
+  }
+  return hx_any(zlow < bound);
+}
+
+// Contact terms of one shape (`shp`: bounding sphere centre xyz + radius, then npts xyz triples; LDS): the body state
+// comes from slot `in` of the buffer, explicit force and implicit 6x6 are ACCUMULATED into slot `out` (several base
+// sub-shapes share one output).  Plane: normal = world z, penetration = -z.  Terrain: normal of the triangle under the
+// point, penetration = distance to that triangle's plane; or the wall the point went through (wall_push).
+HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const ContactBuf& cb, int in, int out, bool accumulate) {
+  const V3 pb = mk(cb.at(in, HX_CB_P), cb.at(in, HX_CB_P + 1), cb.at(in, HX_CB_P + 2));
+  const M3 Rb = cb.rot_of(in);
+  const V3 zb = row(Rb, 2);          // world z in body coords
+  SV v; v.w = mk(cb.at(in, HX_CB_V), cb.at(in, HX_CB_V + 1), cb.at(in, HX_CB_V + 2)); v.v = mk(cb.at(in, HX_CB_V + 3), cb.at(in, HX_CB_V + 4), cb.at(in, HX_CB_V + 5));
   const float c_n = P.dn + P.kn * P.dt;
   const float* pts = shp + 4;
+  SV f0 = sv0();
+  float Axx = 0.f, Axy = 0.f, Axz = 0.f, Ayy = 0.f, Ayz = 0.f, Azz = 0.f, Mxx = 0.f, Mxy = 0.f, Mxz = 0.f, Myy = 0.f, Myz = 0.f, Mzz = 0.f;
+  M3 H = m3zero();
+  float any_on = 0.f;
 #pragma unroll 1
-  for (int k = p0; k < p0 + npts; ++k) {
+  for (int k = 0; k < npts; ++k) {
     const V3 r = ld3(pts + 3 * k);
     const float z = pb.z + dot(zb, r);
     V3 nb = zb;
     float pen = -z;
     if (P.patch != nullptr) {
-      if (!hx_any(z < P.zmax)) continue;
-      // patch coordinates of the point; over the central part of the window the tighter bound applies
       const float u = (pb.x + dot(row(Rb, 0), r) - P.px0) * P.inv_hs, w = (pb.y + dot(row(Rb, 1), r) - P.py0) * P.inv_hs;
-      const float lo = (float)(HX_PATCH / 4), hi = (float)(HX_PATCH - HX_PATCH / 4);
-      const bool near = (u >= lo) && (u <= hi) && (w >= lo) && (w <= hi);
-      if (!hx_any(z < (near ? P.zmax_near : P.zmax))) continue;
+      const int pi = terrain_pool_index(u, w);
+      if (!hx_any(z < P.pool[pi])) continue;
+      const bool walls = P.poolw[pi] != 0.f;         // never set without walls (P.wall = 0)
       V3 nw;
-      const float h = terrain_query(P, u, w, nw);
+      const float h = terrain_query(P, u, w, nw, walls);
       pen = (h - z) * nw.z;
-      if (P.wall > 0.f && hx_any(pen > 0.f)) {
+      if (hx_any(walls && pen > 0.f)) {
         float wp = pen; V3 wn = nw;
-        if (pen > 0.f && wall_push(P, u, w, z, wp, wn)) { pen = wp; nw = wn; }
+        if (walls && pen > 0.f && wall_push(P, u, w, z, wp, wn)) { pen = wp; nw = wn; }
       }
       nb = mulT(Rb, nw);
-    }
+    } else if (!hx_any(z < 0.f)) continue;
     const V3 vp = v.v + cross(v.w, r);
     const float vn = dot(vp, nb);
     const float fn0 = P.kn * pen - c_n * vn;
@@ -219,30 +327,34 @@ HXD V3 contact_points(const DynParams& P, const float* shp, int p0, int npts, SV
     const float vtn = sqrtf(dot(vt, vt));
     const float c_t = P.mu * fn0 / fmaxf(vtn, P.veps);
     const float on = act ? 1.f : 0.f;
+    any_on = fmaxf(any_on, on);
     const V3 f = on * (fn0 * nb - c_t * vt);
     const float alpha = on * P.dt * c_t, beta = on * P.dt * (c_n - c_t);
-    if (a_true == nullptr) {
-      f0.v = f0.v + f;
-      f0.w = f0.w + cross(r, f);
-      const V3 m = cross(r, nb);
-      const float rr = dot(r, r);
-      // A += alpha (|r|^2 1 - r r^T) + beta m m^T ; H += alpha rx + beta m n^T ; M += alpha 1 + beta n n^T
-      B.A.m[0] += alpha * rr; B.A.m[4] += alpha * rr; B.A.m[8] += alpha * rr;
-      addouter(B.A, -alpha, r, r);
-      addouter(B.A, beta, m, m);
-      B.H.m[1] += -alpha * r.z; B.H.m[2] += alpha * r.y;
-      B.H.m[3] += alpha * r.z;  B.H.m[5] += -alpha * r.x;
-      B.H.m[6] += -alpha * r.y; B.H.m[7] += alpha * r.x;
-      addouter(B.H, beta, m, nb);
-      B.M.m[0] += alpha; B.M.m[4] += alpha; B.M.m[8] += alpha;
-      addouter(B.M, beta, nb, nb);
-    } else {
-      const V3 ap = a_true->v + cross(a_true->w, r);          // Xc a
-      const V3 ka = alpha * ap + (beta * dot(nb, ap)) * nb;    // K Xc a
-      net = net + (f - ka);
-    }
+    f0.v = f0.v + f;
+    f0.w = f0.w + cross(r, f);
+    const V3 m = cross(r, nb);
+    const float rr = dot(r, r);
+    // A += alpha (|r|^2 1 - r r^T) + beta m m^T ; H += alpha rx + beta m n^T ; M += alpha 1 + beta n n^T
+    Axx += alpha * (rr - r.x * r.x) + beta * m.x * m.x; Axy += -alpha * r.x * r.y + beta * m.x * m.y; Axz += -alpha * r.x * r.z + beta * m.x * m.z;
+    Ayy += alpha * (rr - r.y * r.y) + beta * m.y * m.y; Ayz += -alpha * r.y * r.z + beta * m.y * m.z; Azz += alpha * (rr - r.z * r.z) + beta * m.z * m.z;
+    H.m[1] += -alpha * r.z; H.m[2] += alpha * r.y;
+    H.m[3] += alpha * r.z;  H.m[5] += -alpha * r.x;
+    H.m[6] += -alpha * r.y; H.m[7] += alpha * r.x;
+    addouter(H, beta, m, nb);
+    Mxx += alpha + beta * nb.x * nb.x; Mxy += beta * nb.x * nb.y; Mxz += beta * nb.x * nb.z;
+    Myy += alpha + beta * nb.y * nb.y; Myz += beta * nb.y * nb.z; Mzz += alpha + beta * nb.z * nb.z;
   }
-  return net;
+  if (!hx_any(any_on != 0.f)) return false;
+  // the first shape to touch a slot in this substep assigns, later ones (base sub-shapes share a slot) accumulate; both
+  // decisions are wave-uniform, lanes without an active point write zeros
+  const float keep = accumulate ? 1.f : 0.f;
+  auto acc = [&](int field, float val) { float& d = cb.at(out, field); d = accumulate ? d + val : val; };
+  (void)keep;
+  acc(HX_CB_F, f0.w.x); acc(HX_CB_F + 1, f0.w.y); acc(HX_CB_F + 2, f0.w.z); acc(HX_CB_F + 3, f0.v.x); acc(HX_CB_F + 4, f0.v.y); acc(HX_CB_F + 5, f0.v.z);
+  acc(HX_CB_A, Axx); acc(HX_CB_A + 1, Axy); acc(HX_CB_A + 2, Axz); acc(HX_CB_A + 3, Ayy); acc(HX_CB_A + 4, Ayz); acc(HX_CB_A + 5, Azz);
+  for (int i = 0; i < 9; ++i) acc(HX_CB_H + i, H.m[i]);
+  acc(HX_CB_M, Mxx); acc(HX_CB_M + 1, Mxy); acc(HX_CB_M + 2, Mxz); acc(HX_CB_M + 3, Myy); acc(HX_CB_M + 4, Myz); acc(HX_CB_M + 5, Mzz);
+  return true;
 }
 
 // 6x6 SPD solve (Cholesky, fully unrolled, static indices): x = A^-1 b
@@ -282,7 +394,7 @@ template <class M> struct DynStateT {
   float q[M::NL], qd[M::NL];
 };
 
-// world-frame net contact forces: base = this side's HALF of the base points (the driver sums the two halves),
+// world-frame net contact forces: base = this side's share of the base sub-shapes (the driver sums the two shares),
 // shape[slot] = the side's bodies that carry collision points, in body order
 template <class M> struct SideForcesT { V3 base; V3 shape[ModelInfo<M>::NSHAPE]; };
 
@@ -293,46 +405,67 @@ template <class M> struct SideWork {
   SV v[NL];                                      // body velocities, body coords
   float cs_c[NL], cs_s[NL];
   SV U[NL]; float Dinv[NL], uu[NL];
-  M3 Rs[NS]; V3 ps[NS];                          // body -> world rotation / origin of the bodies that carry collision points
   SV a[NL];                                      // accelerations relative to the gravity field
   float tau[NL];
+  uint32_t touched;                              // contact-buffer slots that hold contact terms this substep (wave-uniform)
 };
 
-// ---- upward half of a substep for one side: kinematics, articulated inertias leaf -> root, this side's half of the base
-// points; hands (accI, accP) = the side's contribution to the base system.  target = PD position target per joint.
+// ---- upward half of a substep for one side: kinematics, the contact phase, articulated inertias leaf -> root;
+// hands (accI, accP) = the side's contribution to the base system.  target = PD position target per joint.
 template <class M>
-HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, int side, const float* target, SI& accI, SV& accP) {
+HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb, const float* target, SI& accI, SV& accP) {
   using MI = ModelInfo<M>;
   W.R0 = quat_to_mat(S.quat);
   W.v0.w = mulT(W.R0, S.angvel); W.v0.v = mulT(W.R0, S.linvel);
   W.g0.w = mk(0.f, 0.f, 0.f); W.g0.v = P.gz * row(W.R0, 2);
+  // ---- pass 1: kinematics down every chain; a body whose collision shape may touch (bounding-sphere test) leaves its
+  //      state in the contact buffer and sets its entry's bit
+  uint32_t maybe = 0u;
+  static_for<M::NCH>([&](auto cc) {
+    constexpr int CH = decltype(cc)::value, S0 = M::CH_START[CH], LEN = M::CH_LEN[CH];
+    M3 Rc = W.R0; V3 pc = S.pos;
+    static_for<LEN>([&](auto ic) {
+      constexpr int B = S0 + decltype(ic)::value;
+      constexpr int K = M::AXIS[B];
+      float s, c;
+      joint_sincos(S.q[B], &s, &c);
+      W.cs_c[B] = c; W.cs_s[B] = s;
+      const V3 r = C.off(B);
+      const SV vp = (B == S0) ? W.v0 : W.v[B == S0 ? B : B - 1];
+      V3 w = vp.w, t = vp.v + cross(vp.w, r);
+      pc = pc + mul(Rc, r);
+      if constexpr (M::HAS_ROT) { const M3 E = C.rotc(B); w = mulT(E, w); t = mulT(E, t); Rc = matmul(Rc, E); }
+      W.v[B].w = rotT<K>(c, s, w);
+      W.v[B].v = rotT<K>(c, s, t);
+      if (K == 0) W.v[B].w.x += S.qd[B];
+      if (K == 1) W.v[B].w.y += S.qd[B];
+      if (K == 2) W.v[B].w.z += S.qd[B];
+      for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
+      if constexpr (MI::slot(B) >= 0) {
+        if (shape_maybe(P, C.shape(B), Rc, pc)) { maybe |= (1u << MI::slot(B)); cb.put_body(MI::slot(B), W.v[B], Rc, pc); }
+      }
+    });
+  });
+  for (int k = 0; k < M::BASE_NSUB; ++k)
+    if (shape_maybe(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos)) maybe |= (1u << (MI::NSHAPE + k));
+  if (maybe >> MI::NSHAPE) cb.put_body(MI::NSHAPE, W.v0, W.R0, S.pos);
+  HX_T(P.prof, 2);
+  // ---- contact phase: one runtime loop over this lane's shapes (its shape bodies, then its share of the base)
+  {
+    uint32_t touched = 0u;
+#pragma unroll 1
+    for (int e = 0; e < MI::NENT; ++e) {
+      if (!((maybe >> e) & 1u)) continue;
+      const int off = C.ent[3 * e], np = C.ent[3 * e + 1], slot = C.ent[3 * e + 2];
+      if (contact_shape(P, C.lds + off, np, cb, slot, slot, (touched >> slot) & 1u)) touched |= (1u << slot);
+    }
+    W.touched = touched;
+  }
+  HX_T(P.prof, 3);
+  // ---- pass 2: articulated inertias, leaf -> root of every chain
   accI = si0(); accP = sv0();
   static_for<M::NCH>([&](auto cc) {
     constexpr int CH = decltype(cc)::value, S0 = M::CH_START[CH], LEN = M::CH_LEN[CH];
-    // ---- pass 1: kinematics down the chain
-    {
-      M3 Rc = W.R0; V3 pc = S.pos;
-      static_for<LEN>([&](auto ic) {
-        constexpr int B = S0 + decltype(ic)::value;
-        constexpr int K = M::AXIS[B];
-        float s, c;
-        joint_sincos(S.q[B], &s, &c);
-        W.cs_c[B] = c; W.cs_s[B] = s;
-        const V3 r = C.off(B);
-        const SV vp = (B == S0) ? W.v0 : W.v[B == S0 ? B : B - 1];
-        V3 w = vp.w, t = vp.v + cross(vp.w, r);
-        pc = pc + mul(Rc, r);
-        if constexpr (M::HAS_ROT) { const M3 E = C.rotc(B); w = mulT(E, w); t = mulT(E, t); Rc = matmul(Rc, E); }
-        W.v[B].w = rotT<K>(c, s, w);
-        W.v[B].v = rotT<K>(c, s, t);
-        if (K == 0) W.v[B].w.x += S.qd[B];
-        if (K == 1) W.v[B].w.y += S.qd[B];
-        if (K == 2) W.v[B].w.z += S.qd[B];
-        for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
-        if constexpr (MI::slot(B) >= 0) { W.Rs[MI::slot(B)] = Rc; W.ps[MI::slot(B)] = pc; }
-      });
-    }
-    // ---- pass 2: articulated inertias, leaf -> root of the chain
     SI chI = si0(); SV chP = sv0();
     static_for<LEN>([&](auto ic) {
       constexpr int B = S0 + LEN - 1 - decltype(ic)::value;     // last .. first
@@ -342,12 +475,7 @@ HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, cons
       if (B < S0 + LEN - 1) { siadd(IA, chI); pA = pA + chP; }
       if constexpr (MI::slot(B) >= 0) {
         constexpr int SL = MI::slot(B);
-        const M3& Rb = W.Rs[SL];
-        SV f0 = sv0(); SI Bc = si0();
-        contact_points(P, C.shape(B), 0, M::NPTS[B], W.v[B], Rb, W.ps[SL], f0, Bc, nullptr);
-        siadd(IA, Bc);
-        SV g; g.w = mk(0.f, 0.f, 0.f); g.v = P.gz * row(Rb, 2);
-        pA = pA - f0 + mulSI(Bc, g);
+        if ((W.touched >> SL) & 1u) cb.add_to(SL, IA, pA, P.gz * mk(cb.at(SL, HX_CB_R + 6), cb.at(SL, HX_CB_R + 7), cb.at(SL, HX_CB_R + 8)));
       }
       // joint-space terms: PD torque (reference legged_robot.py:339-355) + soft limits, linearly implicit
       const float q = S.q[B], qd = S.qd[B];
@@ -402,13 +530,9 @@ HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, cons
     });
     siadd(accI, chI); accP = accP + chP;
   });
-  // ---- this side's half of the base points
-  {
-    SV f0 = sv0(); SI Bc = si0();
-    contact_points(P, C.base_shape(), side * (M::NBASE / 2), M::NBASE / 2, W.v0, W.R0, S.pos, f0, Bc, nullptr);
-    siadd(accI, Bc);
-    accP = accP - f0 + mulSI(Bc, W.g0);
-  }
+  // ---- this side's share of the base shapes
+  if ((W.touched >> MI::NSHAPE) & 1u) cb.add_to(MI::NSHAPE, accI, accP, W.g0.v);
+  HX_T(P.prof, 4);
 }
 
 // base system: (I_base + sum of both sides) a0 = -(p_base + sum of both sides)
@@ -436,7 +560,7 @@ HXD SV base_solve(const SideConst<M>& C, const SV& v0, float mass_scale, const S
 // ---- downward half for one side: accelerations root -> leaf, (last substep) implicit-consistent contact forces,
 // integration of the side's joints.  F.base receives this side's half of the base points.
 template <class M>
-HXD void side_down(SideWork<M>& W, DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, int side, SV a0, bool want_forces, SideForcesT<M>& F) {
+HXD void side_down(SideWork<M>& W, DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb, SV a0, bool want_forces, SideForcesT<M>& F) {
   using MI = ModelInfo<M>;
   float qdd[M::NL];
   static_for<M::NCH>([&](auto cc) {
@@ -465,18 +589,19 @@ HXD void side_down(SideWork<M>& W, DynStateT<M>& S, const DynParams& P, const Si
     });
   });
   if (want_forces) {
-    SV dmy; SI dmyB;
-    {
-      SV at = a0; at.v = at.v + W.g0.v;          // true spatial acceleration of the base
-      F.base = mul(W.R0, contact_points(P, C.base_shape(), side * (M::NBASE / 2), M::NBASE / 2, W.v0, W.R0, S.pos, dmy, dmyB, &at));
-    }
+    // implicit-consistent net contact forces, world frame: f0 - B a_true with the terms the contact phase left in the buffer
+    F.base = mk(0.f, 0.f, 0.f);
+    if ((W.touched >> MI::NSHAPE) & 1u) { SV at = a0; at.v = at.v + W.g0.v; F.base = mul(W.R0, cb.net_force(MI::NSHAPE, at)); }
     static_for<M::NL>([&](auto ic) {
       constexpr int B = decltype(ic)::value;
       if constexpr (MI::slot(B) >= 0) {
         constexpr int SL = MI::slot(B);
-        const M3& Rb = W.Rs[SL];
-        SV at = W.a[B]; at.v = at.v + P.gz * row(Rb, 2);
-        F.shape[SL] = mul(Rb, contact_points(P, C.shape(B), 0, M::NPTS[B], W.v[B], Rb, W.ps[SL], dmy, dmyB, &at));
+        F.shape[SL] = mk(0.f, 0.f, 0.f);
+        if ((W.touched >> SL) & 1u) {
+          const M3 Rb = cb.rot_of(SL);
+          SV at = W.a[B]; at.v = at.v + P.gz * row(Rb, 2);
+          F.shape[SL] = mul(Rb, cb.net_force(SL, at));
+        }
       }
     });
   }
@@ -512,11 +637,11 @@ __device__ __forceinline__ V3 hx_xchg(V3 a) { return mk(hx_xchg(a.x), hx_xchg(a.
 // One 1 ms substep on the device: this lane's side, the partner lane's contribution through the DPP exchange
 // (a + b == b + a bitwise, so both lanes hold the identical base system and solve it redundantly).
 template <class M>
-__device__ __forceinline__ void dyn_substep(DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, int side, const float* target, float mass_scale,
+__device__ __forceinline__ void dyn_substep(DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb, const float* target, float mass_scale,
                      float* tau_out, bool want_forces, SideForcesT<M>& F) {
   SideWork<M> W;
   SI accI; SV accP;
-  side_up<M>(W, S, P, C, side, target, accI, accP);
+  side_up<M>(W, S, P, C, cb, target, accI, accP);
   for (int i = 0; i < 9; ++i) {
     accI.A.m[i] += hx_xchg(accI.A.m[i]);
     accI.H.m[i] += hx_xchg(accI.H.m[i]);
@@ -525,10 +650,12 @@ __device__ __forceinline__ void dyn_substep(DynStateT<M>& S, const DynParams& P,
   accP.w = accP.w + hx_xchg(accP.w);
   accP.v = accP.v + hx_xchg(accP.v);
   const SV a0 = base_solve<M>(C, W.v0, mass_scale, accI, accP);
-  side_down<M>(W, S, P, C, side, a0, want_forces, F);
+  HX_T(P.prof, 5);
+  side_down<M>(W, S, P, C, cb, a0, want_forces, F);
   if (want_forces) F.base = F.base + hx_xchg(F.base);
   for (int j = 0; j < M::NL; ++j) tau_out[j] = W.tau[j];
   base_integrate<M>(S, P, W.R0, W.v0, W.g0, a0);
+  HX_T(P.prof, 6);
 }
 #endif
 
@@ -539,12 +666,14 @@ HXD void dyn_substep_pair(DynStateT<M>& SL, DynStateT<M>& SR, const DynParams& P
                           SideForcesT<M>& FL, SideForcesT<M>& FR) {
   SideWork<M> WL, WR;
   SI aI, bI; SV aP, bP;
-  side_up<M>(WL, SL, P, CL, 0, targetL, aI, aP);
-  side_up<M>(WR, SR, P, CR, 1, targetR, bI, bP);
+  float bufL[ModelInfo<M>::NSLOT * HX_CB_FIELDS], bufR[ModelInfo<M>::NSLOT * HX_CB_FIELDS];
+  ContactBuf cbL, cbR; cbL.base = bufL; cbL.stride = 1; cbR.base = bufR; cbR.stride = 1;
+  side_up<M>(WL, SL, P, CL, cbL, targetL, aI, aP);
+  side_up<M>(WR, SR, P, CR, cbR, targetR, bI, bP);
   siadd(aI, bI); aP = aP + bP;
   const SV a0 = base_solve<M>(CL, WL.v0, mass_scale, aI, aP);
-  side_down<M>(WL, SL, P, CL, 0, a0, want_forces, FL);
-  side_down<M>(WR, SR, P, CR, 1, a0, want_forces, FR);
+  side_down<M>(WL, SL, P, CL, cbL, a0, want_forces, FL);
+  side_down<M>(WR, SR, P, CR, cbR, a0, want_forces, FR);
   if (want_forces) { const V3 b = FL.base + FR.base; FL.base = b; FR.base = b; }
   for (int j = 0; j < M::NL; ++j) { tauL[j] = WL.tau[j]; tauR[j] = WR.tau[j]; }
   base_integrate<M>(SL, P, WL.R0, WL.v0, WL.g0, a0);

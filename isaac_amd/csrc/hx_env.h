@@ -50,6 +50,10 @@ struct SimPtrs {
   int t_rows, t_cols;
   float t_inv_hs, t_hs, t_x0, t_y0;
   float t_wall;               // slope_treshold * horizontal_scale for mesh_type 'trimesh', 0 for 'heightfield' (no walls)
+  // pooled bounds of the grid (terrain_pool_build), [t_prows][t_pcols] each: highest node / cliff flag of the 7 x 7 nodes
+  // around every second node -- what DynParams::pool / poolw window into
+  const float* t_pool; const float* t_poolw;
+  int t_prows, t_pcols;
   // terrain curriculum (legged_robot.py:399-419): level per env, tile column per env, platform origin per tile;
   // cur_levels == nullptr = off
   int* cur_levels;            // [N]
@@ -58,6 +62,7 @@ struct SimPtrs {
   int cur_rows, cur_cols;
   float cur_up_dist;          // terrain.env_length / 2
   float cur_down_scale;       // max_episode_length_s * 0.5
+  long long* prof;            // [16] measurement builds only (-DHX_STEP_PROF): cycle counters summed over waves; else nullptr
 };
 
 struct StepArgs {
@@ -95,13 +100,22 @@ struct Rng {
     philox4(k0, k1, gid, step, (uint32_t)field, 0u, o);
     return (float)(o[0] >> 8) * (1.0f / 16777216.0f);
   }
-  HXD float nrm(int field) const {
-    if (pack) return pack[(size_t)field * n + env];
-    uint32_t o[4];
-    philox4(k0, k1, gid, step, (uint32_t)field, 1u, o);
-    const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);   // (0,1]
-    const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+  // N(0,1) draws of `count` consecutive fields.  One Philox call yields the four normals of fields 4b .. 4b+3 (two
+  // Box-Muller pairs), so a run costs count / 4 calls.
+  HXD void nrm_run(int field0, int count, float* out) const {
+    if (pack) { for (int k = 0; k < count; ++k) out[k] = pack[(size_t)(field0 + k) * n + env]; return; }
+    for (int b = field0 >> 2; b <= (field0 + count - 1) >> 2; ++b) {
+      uint32_t o[4];
+      philox4(k0, k1, gid, step, (uint32_t)b, 1u, o);
+      float z[4];
+      for (int h = 0; h < 2; ++h) {
+        const float u1 = 1.0f - (float)(o[2 * h] >> 8) * (1.0f / 16777216.0f);   // (0,1]
+        const float u2 = (float)(o[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1)), a = 6.283185307179586f * u2;
+        z[2 * h] = r * cosf(a); z[2 * h + 1] = r * sinf(a);
+      }
+      for (int c = 0; c < 4; ++c) { const int k = 4 * b + c - field0; if (k >= 0 && k < count) out[k] = z[c]; }
+    }
   }
 };
 
@@ -148,10 +162,12 @@ template <class M>
 HXD void env_actions(const hx_sim_cfg& cfg, const Rng& rng, const float* actions_row, float* act) {
   using D = TaskDims<M>;
   const float delay = rng.uni(D::RP_DELAY) * cfg.action_delay;
+  float eps[D::ND];
+  rng.nrm_run(D::RP_ACT_NOISE, D::ND, eps);
   for (int j = 0; j < D::ND; ++j) {
     float x = clampf(actions_row[j], -cfg.clip_actions, cfg.clip_actions);
     x = (1.0f - delay) * x + delay * act[j];
-    x = x + cfg.action_noise * rng.nrm(D::RP_ACT_NOISE + j) * x;
+    x = x + cfg.action_noise * eps[j] * x;
     act[j] = clampf(x, -cfg.clip_actions, cfg.clip_actions);
   }
 }
@@ -511,11 +527,14 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
     for (int k = 0; k < PB; ++k) o[k] = f[k];
     o[PB] = base_ang_vel.x * cfg.obs_scale_ang_vel; o[PB + 1] = base_ang_vel.y * cfg.obs_scale_ang_vel; o[PB + 2] = base_ang_vel.z * cfg.obs_scale_ang_vel;
     o[PB + 3] = euler.x * cfg.obs_scale_quat; o[PB + 4] = euler.y * cfg.obs_scale_quat; o[PB + 5] = euler.z * cfg.obs_scale_quat;
-    if (cfg.add_noise)
+    if (cfg.add_noise) {
+      float eps[OBSF];
+      rng.nrm_run(D::RP_OBS_NOISE, OBSF, eps);
       for (int k = 0; k < OBSF; ++k) {
         const float sv = cfg.noise_scale_vec[k];
-        if (sv != 0.f) o[k] = o[k] + rng.nrm(D::RP_OBS_NOISE + k) * sv * cfg.noise_level;
+        if (sv != 0.f) o[k] = o[k] + eps[k] * sv * cfg.noise_level;
       }
+    }
     if (writer) for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
     f[PB + 0] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[PB + 1] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[PB + 2] = base_lin_vel.z * cfg.obs_scale_lin_vel;
     f[PB + 3] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[PB + 4] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[PB + 5] = base_ang_vel.z * cfg.obs_scale_ang_vel;
@@ -583,28 +602,56 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
 #undef ST
 }
 
-// highest node of a window part [k0, k1) of the HX_PATCH^2 nodes, and of the central nodes among them
-HXD void patch_bounds(const float* patch, int k0, int k1, float& zm, float& zn) {
-  zm = -3.0e38f; zn = -3.0e38f;
-  for (int idx = k0; idx < k1; ++idx) {
-    const int i = idx / HX_PATCH, j = idx % HX_PATCH;
-    const float hv = patch[idx];
-    zm = fmaxf(zm, hv);
-    // nodes HX_PATCH/4 .. HX_PATCH - HX_PATCH/4 bound every point with patch coordinates in that closed range
-    if (i >= HX_PATCH / 4 && i <= HX_PATCH - HX_PATCH / 4 && j >= HX_PATCH / 4 && j <= HX_PATCH - HX_PATCH / 4) zn = fmaxf(zn, hv);
-  }
-}
 // grid index of the window's node (0, 0) for a robot whose base is at (bx, by)
+// (even indices: the window's pool entries are then entries of the grid's pooled maps)
 HXD void patch_origin(const SimPtrs& p, float bx, float by, int& oi, int& oj) {
   const int ci = (int)floorf((bx - p.t_x0) * p.t_inv_hs + 0.5f) - HX_PATCH / 2;
   const int cj = (int)floorf((by - p.t_y0) * p.t_inv_hs + 0.5f) - HX_PATCH / 2;
-  oi = hx_imin(hx_imax(ci, 0), p.t_rows - HX_PATCH);
-  oj = hx_imin(hx_imax(cj, 0), p.t_cols - HX_PATCH);
+  oi = hx_imin(hx_imax(ci, 0), p.t_rows - HX_PATCH) & ~1;
+  oj = hx_imin(hx_imax(cj, 0), p.t_cols - HX_PATCH) & ~1;
+}
+// Pooled maps of a height grid h[rows][cols] (metres), built once per terrain on the host: entry (I, J) covers nodes
+// 2I-2 .. 2I+4 x 2J-2 .. 2J+4 (clamped to the grid): pool = the highest of them; poolw = 1 if one of the cells whose
+// lowest-index corner lies in that range is a cliff cell (its four corners span more than `wall`), else 0.  Two separable
+// passes.  prows = rows / 2, pcols = cols / 2.
+inline void terrain_pool_build(const float* h, int rows, int cols, float wall, float* pool, float* poolw) {
+  const int prows = rows / 2, pcols = cols / 2;
+  float* rmax = new float[(size_t)rows * pcols];
+  float* rflag = new float[(size_t)rows * pcols];
+#pragma omp parallel for schedule(static)
+  for (int a = 0; a < rows; ++a) {
+    const int a1 = hx_imin(a + 1, rows - 1);
+    for (int J = 0; J < pcols; ++J) {
+      float m = -3.0e38f, f = 0.f;
+      for (int t = -2; t <= 4; ++t) {
+        const int b = hx_imin(hx_imax(2 * J + t, 0), cols - 1), b1 = hx_imin(b + 1, cols - 1);
+        const float h00 = h[(size_t)a * cols + b];
+        m = fmaxf(m, h00);
+        if (wall > 0.f) {
+          const float h10 = h[(size_t)a1 * cols + b], h01 = h[(size_t)a * cols + b1], h11 = h[(size_t)a1 * cols + b1];
+          if (fmaxf(fmaxf(h00, h01), fmaxf(h10, h11)) - fminf(fminf(h00, h01), fminf(h10, h11)) > wall) f = 1.f;
+        }
+      }
+      rmax[(size_t)a * pcols + J] = m; rflag[(size_t)a * pcols + J] = f;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int I = 0; I < prows; ++I)
+    for (int J = 0; J < pcols; ++J) {
+      float m = -3.0e38f, f = 0.f;
+      for (int t = -2; t <= 4; ++t) {
+        const int a = hx_imin(hx_imax(2 * I + t, 0), rows - 1);
+        m = fmaxf(m, rmax[(size_t)a * pcols + J]);
+        f = fmaxf(f, rflag[(size_t)a * pcols + J]);
+      }
+      pool[(size_t)I * pcols + J] = m; poolw[(size_t)I * pcols + J] = f;
+    }
+  delete[] rmax; delete[] rflag;
 }
 HXD DynParams dyn_params(const hx_sim_cfg& cfg, float friction) {
   DynParams P;
   P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
   P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
-  P.patch = nullptr; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.zmax = 0.f; P.zmax_near = 0.f; P.wall = 0.f;
+  P.patch = nullptr; P.pool = nullptr; P.poolw = nullptr; P.prof = nullptr; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.wall = 0.f;
   return P;
 }

@@ -28,9 +28,23 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   using MI = ModelInfo<M>;
   constexpr int NL = D::NL, ND = D::ND;
   constexpr SLay SL(ND);
-  __shared__ float lds_const[MI::LDS_FLOATS];
-  __shared__ float lds_patch[32 * HX_PATCH * HX_PATCH];
-  __shared__ int lds_patch_org[32][2];
+  // dynamic LDS: staged constants | 32 height windows | 32 pooled bounds | window origins | per-lane contact buffer
+  extern __shared__ float lds_all[];
+  float* lds_const = lds_all;
+  float* lds_patch = lds_const + (MI::LDS_FLOATS + 3) / 4 * 4;
+  float* lds_pool = lds_patch + 32 * HX_PATCH_LD;
+  float* lds_poolw = lds_pool + 32 * HX_POOL_LD;
+  int (*lds_patch_org)[2] = reinterpret_cast<int (*)[2]>(lds_poolw + 32 * HX_POOL_LD);
+  float* lds_cb = lds_poolw + 32 * HX_POOL_LD + 64;
+#if defined(HX_STEP_PROF)
+  __shared__ long long lds_prof[16];
+  if (threadIdx.x < 16) lds_prof[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) lds_prof[15] = clock64();
+  long long* const prof = (p.prof != nullptr) ? lds_prof : nullptr;
+#else
+  long long* const prof = nullptr;
+#endif
   const hx_sim_cfg& cfg = *cfgp;
   dyn_stage_constants<M>(lds_const, threadIdx.x, 64, cfg.p_gains, cfg.d_gains, cfg.torque_limits, cfg.default_dof_pos);
   const int n = cfg.num_envs;
@@ -38,26 +52,35 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   const int side = threadIdx.x & 1;
   const bool use_terrain = (p.terrain != nullptr) && (A.mode == 0);
   if (use_terrain) {
-    // window of the height grid around each robot's base, fetched cooperatively: one wave instruction covers
-    // four 64-byte rows of one robot's window
-    if (side == 0) {
-      const int ec = min(e, n - 1);
-      int oi, oj;
-      patch_origin(p, p.st[(size_t)SL.ROOT_POS * n + ec], p.st[(size_t)(SL.ROOT_POS + 1) * n + ec], oi, oj);
-      lds_patch_org[threadIdx.x >> 1][0] = oi;
-      lds_patch_org[threadIdx.x >> 1][1] = oj;
-    }
-    __syncthreads();
-    for (int r = 0; r < 32; ++r) {
-      const int oi = lds_patch_org[r][0], oj = lds_patch_org[r][1];
+    // Every lane fetches half of its own robot's windows: 8 of the 16 rows of the height window, 4 of the 8 rows of the
+    // two pooled maps.  All addresses follow from the robot's own base position, so the loads of a lane are independent
+    // and stay in flight together (a cooperative robot-by-robot copy waited for each robot's loads in turn).
+    const int ec = min(e, n - 1), r = threadIdx.x >> 1;
+    int oi, oj;
+    patch_origin(p, p.st[(size_t)SL.ROOT_POS * n + ec], p.st[(size_t)(SL.ROOT_POS + 1) * n + ec], oi, oj);
+    if (side == 0) { lds_patch_org[r][0] = oi; lds_patch_org[r][1] = oj; }
+    const float* src = p.terrain + (size_t)(oi + side * (HX_PATCH / 2)) * p.t_cols + oj;
+    float* dst = lds_patch + r * HX_PATCH_LD + side * (HX_PATCH / 2) * HX_PATCH;
 #pragma unroll
-      for (int k = 0; k < HX_PATCH * HX_PATCH / 64; ++k) {
-        const int idx = k * 64 + threadIdx.x;
-        lds_patch[r * HX_PATCH * HX_PATCH + idx] = p.terrain[(size_t)(oi + idx / HX_PATCH) * p.t_cols + (oj + idx % HX_PATCH)];
+    for (int a = 0; a < HX_PATCH / 2; ++a) {
+      float v[HX_PATCH];
+#pragma unroll
+      for (int b = 0; b < HX_PATCH; ++b) v[b] = src[(size_t)a * p.t_cols + b];
+#pragma unroll
+      for (int b = 0; b < HX_PATCH; ++b) dst[a * HX_PATCH + b] = v[b];
+    }
+    const size_t po = (size_t)(oi / 2 + side * (HX_POOL / 2)) * p.t_pcols + oj / 2;
+#pragma unroll
+    for (int a = 0; a < HX_POOL / 2; ++a) {
+#pragma unroll
+      for (int b = 0; b < HX_POOL; ++b) {
+        lds_pool[r * HX_POOL_LD + (side * (HX_POOL / 2) + a) * HX_POOL + b] = p.t_pool[po + (size_t)a * p.t_pcols + b];
+        lds_poolw[r * HX_POOL_LD + (side * (HX_POOL / 2) + a) * HX_POOL + b] = p.t_poolw[po + (size_t)a * p.t_pcols + b];
       }
     }
   }
   __syncthreads();
+  HX_T(prof, 0);
   if (e >= n) return;                      // both lanes of a pair leave together
   const bool writer = (side == 0);         // env-level results are computed by both lanes, stored by one
   SideConst<M> C; C.bind(lds_const, side);
@@ -85,17 +108,17 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     env_actions<M>(cfg, rng, actions + (size_t)e * ND, R.act);
     // ---- legged_robot.py:93-100 : decimation x {PD torque, simulate}
     DynParams P = dyn_params(cfg, R.friction);
+    P.prof = prof;
+    HX_T(prof, 1);
     if (use_terrain) {
       const int r = threadIdx.x >> 1;
-      P.patch = lds_patch + r * HX_PATCH * HX_PATCH;
+      P.patch = lds_patch + r * HX_PATCH_LD;
       P.px0 = p.t_x0 + (float)lds_patch_org[r][0] * p.t_hs;
       P.py0 = p.t_y0 + (float)lds_patch_org[r][1] * p.t_hs;
       P.inv_hs = p.t_inv_hs; P.wall = p.t_wall;
-      float zm, zn;
-      patch_bounds(P.patch, side * (HX_PATCH * HX_PATCH / 2), (side + 1) * (HX_PATCH * HX_PATCH / 2), zm, zn);
-      P.zmax = fmaxf(zm, hx_xchg(zm));
-      P.zmax_near = fmaxf(zn, hx_xchg(zn));
+      P.pool = lds_pool + r * HX_POOL_LD; P.poolw = lds_poolw + r * HX_POOL_LD;
     }
+    ContactBuf cb; cb.base = lds_cb + threadIdx.x; cb.stride = 64;
     float target[NL];
     for (int j = 0; j < NL; ++j) {
       const float aj = side ? R.act[NL + j] : R.act[j];
@@ -105,7 +128,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     const int decimation = cfg.decimation;
 #pragma unroll 1
     for (int sub = 0; sub < decimation; ++sub)
-      dyn_substep<M>(S, P, C, side, target, mass_scale, tau_side, sub == decimation - 1, F);
+      dyn_substep<M>(S, P, C, cb, target, mass_scale, tau_side, sub == decimation - 1, F);
     // Blow-up guard (no reference counterpart; PhysX clamps internally).  A non-finite or runaway state would put NaNs
     // into the observations and from there into every weight.  Such a robot is put back on its start pose with zero
     // forces right here, so nothing downstream sees the bad numbers, and the step ends its episode as a fall.
@@ -151,7 +174,16 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   R.f_base = F.base;
   R.pos = S.pos; for (int k = 0; k < 4; ++k) R.quat[k] = S.quat[k];
   R.linvel = S.linvel; R.angvel = S.angvel;
+  HX_T(prof, 7);
   env_glue<M>(p, cfg, A, n, e, writer, rng, R);
+  HX_T(prof, 8);
+#if defined(HX_STEP_PROF)
+  if (prof != nullptr && threadIdx.x == 0) for (int k = 0; k < 9; ++k) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
+#endif
+}
+
+template <class M> static constexpr size_t env_step_lds_bytes() {
+  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + 32 * HX_PATCH_LD + 2 * 32 * HX_POOL_LD + 64 + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * 64);
 }
 
 // Frame stacking for BOTH observation streams (hector_env.py:246-254 + clip of legged_robot.py:104-107), one
@@ -328,6 +360,9 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
     st[(size_t)SL_.BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : (s->nd == HX_NUM_DOF ? HXM_MASS0 : HXF_MASS0);
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  // the env-step kernel keeps the height windows and the per-lane contact buffer in LDS: more than the 64 KB default
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelHector>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelHector>()));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelFull>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelFull>()));
   if (dalloc(s, &s->cfg_d, 1)) return -3;
   HX_CHECK(hipMemcpy(s->cfg_d, &s->cfg, sizeof(hx_sim_cfg), hipMemcpyHostToDevice));
   return 0;
@@ -337,7 +372,7 @@ extern "C" int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t r
                                   float vertical_scale, float x0, float y0, float wall_height) {
   if (!s) { hx_set_error("hx_sim_set_terrain: null sim"); return -2; }
   if (!heights_h) { s->p.terrain = nullptr; return 0; }
-  if (rows < HX_PATCH || cols < HX_PATCH || !(horizontal_scale > 0.f)) { hx_set_error("hx_sim_set_terrain: grid smaller than the contact window or bad scale"); return -2; }
+  if (rows < HX_PATCH + 2 || cols < HX_PATCH + 2 || !(horizontal_scale > 0.f)) { hx_set_error("hx_sim_set_terrain: grid smaller than the contact window or bad scale"); return -2; }
   // metres in fp32, rounded from the double product exactly like the float32 mesh vertices of the reference
   std::vector<float> h((size_t)rows * cols);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((double)heights_h[i] * (double)vertical_scale);
@@ -345,6 +380,17 @@ extern "C" int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t r
   HX_CHECK(hipMalloc((void**)&d, h.size() * sizeof(float)));
   s->allocs.push_back(d);
   HX_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  {
+    const int prows = rows / 2, pcols = cols / 2;
+    std::vector<float> pool((size_t)prows * pcols), poolw((size_t)prows * pcols);
+    terrain_pool_build(h.data(), rows, cols, wall_height > 0.f ? wall_height : 0.f, pool.data(), poolw.data());
+    float *dp = nullptr, *dw = nullptr;
+    HX_CHECK(hipMalloc((void**)&dp, pool.size() * sizeof(float))); s->allocs.push_back(dp);
+    HX_CHECK(hipMalloc((void**)&dw, poolw.size() * sizeof(float))); s->allocs.push_back(dw);
+    HX_CHECK(hipMemcpy(dp, pool.data(), pool.size() * sizeof(float), hipMemcpyHostToDevice));
+    HX_CHECK(hipMemcpy(dw, poolw.data(), poolw.size() * sizeof(float), hipMemcpyHostToDevice));
+    s->p.t_pool = dp; s->p.t_poolw = dw; s->p.t_prows = prows; s->p.t_pcols = pcols;
+  }
   s->p.terrain = d; s->p.t_rows = rows; s->p.t_cols = cols;
   s->p.t_hs = horizontal_scale; s->p.t_inv_hs = 1.0f / horizontal_scale; s->p.t_x0 = x0; s->p.t_y0 = y0;
   s->p.t_wall = wall_height > 0.f ? wall_height : 0.f;
@@ -399,8 +445,8 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   A.rng_step = s->rng_step++;
   // reset counter: ping-pong pair; the stack kernel of step t zeroes the counter step t+1 will use
   s->p.num_reset = s->num_reset2[s->parity];
-  if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
-  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((2 * n + 63) / 64), dim3(64), 0, s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((2 * n + 63) / 64), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((2 * n + 63) / 64), dim3(64), env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
   if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }
@@ -538,3 +584,19 @@ extern "C" int hx_sim_episode_stats(hx_sim* s, float* mean_h, int32_t* count_h) 
   return 0;
 }
 extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }
+// measurement hook (tools/step_prof.py; library built with -DHX_STEP_PROF): which = 1 starts / clears, 0 reads the cycle
+// counters summed over all waves and launches since: {window fetch + pooling, action processing, kinematics, contact
+// phase, articulated inertias, exchange + base solve, accelerations + forces + integration, guard + gather, glue}
+extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[9]*/) {
+  if (!s) { hx_set_error("hx_sim_prof: null sim"); return -2; }
+  if (which == 1) {
+    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 16)) return -3; s->p.prof = d; }
+    HX_CHECK(hipStreamSynchronize(s->stream));
+    HX_CHECK(hipMemset(s->p.prof, 0, 16 * sizeof(long long)));
+    return 0;
+  }
+  if (!s->p.prof || !out_h) { hx_set_error("hx_sim_prof: not started"); return -2; }
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(out_h, s->p.prof, 9 * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+}

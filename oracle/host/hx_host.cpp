@@ -27,7 +27,7 @@ struct hxh_env {
   uint32_t rng_step;
   uint64_t seed;
   std::vector<std::vector<char>> bufs;
-  std::vector<float> terrain;
+  std::vector<float> terrain, tpool, tpoolw;
 };
 
 template <typename T> static T* halloc(hxh_env* s, size_t count) {
@@ -89,9 +89,12 @@ extern "C" void hxh_destroy(hxh_env* s) { delete s; }
 
 extern "C" int hxh_set_terrain(hxh_env* s, const int16_t* heights, int rows, int cols, float hs, float vs, float x0, float y0, float wall) {
   if (!heights) { s->p.terrain = nullptr; return 0; }
-  if (rows < HX_PATCH || cols < HX_PATCH) return -2;
+  if (rows < HX_PATCH + 2 || cols < HX_PATCH + 2) return -2;
   s->terrain.resize((size_t)rows * cols);
   for (size_t i = 0; i < s->terrain.size(); ++i) s->terrain[i] = (float)((double)heights[i] * (double)vs);
+  s->tpool.assign((size_t)(rows / 2) * (cols / 2), 0.f); s->tpoolw.assign((size_t)(rows / 2) * (cols / 2), 0.f);
+  terrain_pool_build(s->terrain.data(), rows, cols, wall > 0.f ? wall : 0.f, s->tpool.data(), s->tpoolw.data());
+  s->p.t_pool = s->tpool.data(); s->p.t_poolw = s->tpoolw.data(); s->p.t_prows = rows / 2; s->p.t_pcols = cols / 2;
   s->p.terrain = s->terrain.data(); s->p.t_rows = rows; s->p.t_cols = cols;
   s->p.t_hs = hs; s->p.t_inv_hs = 1.0f / hs; s->p.t_x0 = x0; s->p.t_y0 = y0; s->p.t_wall = wall;
   return 0;
@@ -129,13 +132,17 @@ template <class M> static void step_robot(hxh_env* s, const float* actions, cons
   if (A.mode == 0) {
     env_actions<M>(cfg, rng, actions + (size_t)e * ND, R.act);
     DynParams P = dyn_params(cfg, R.friction);
-    float patch[HX_PATCH * HX_PATCH];
+    float patch[HX_PATCH * HX_PATCH], pool[HX_POOL * HX_POOL], poolw[HX_POOL * HX_POOL];
     if (p.terrain != nullptr) {
       int oi, oj;
       patch_origin(p, S[0].pos.x, S[0].pos.y, oi, oj);
       for (int idx = 0; idx < HX_PATCH * HX_PATCH; ++idx) patch[idx] = p.terrain[(size_t)(oi + idx / HX_PATCH) * p.t_cols + (oj + idx % HX_PATCH)];
       P.patch = patch; P.px0 = p.t_x0 + (float)oi * p.t_hs; P.py0 = p.t_y0 + (float)oj * p.t_hs; P.inv_hs = p.t_inv_hs; P.wall = p.t_wall;
-      patch_bounds(patch, 0, HX_PATCH * HX_PATCH, P.zmax, P.zmax_near);
+      for (int c = 0; c < HX_POOL * HX_POOL; ++c) {
+        const size_t g = (size_t)(oi / 2 + c / HX_POOL) * p.t_pcols + (oj / 2 + c % HX_POOL);
+        pool[c] = p.t_pool[g]; poolw[c] = p.t_poolw[g];
+      }
+      P.pool = pool; P.poolw = poolw;
     }
     float target[2][NL];
     for (int sd = 0; sd < 2; ++sd)

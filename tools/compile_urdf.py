@@ -274,11 +274,14 @@ def emit_model_header(prefix, struct, title, bodies, contacts, nl, chains, path)
                 origin (xx yy zz xy xz yz), 12 mass, 13 q_lo, 14 q_hi, 15 v_max, and for robots with rotated joint frames
                 16-24 the constant child -> parent rotation (row-major)
         shapes  per body with collision points, in body order: bounding sphere (centre xyz, radius), then the points
-    and one base table: bounding sphere, base points (an even count: the two lanes of a robot take half each), then
-    inertia (6), h (3), mass."""
-    by_body = {}
+    and one base table: 2 x BASE_NSUB sub-shapes (the two lanes of a robot take BASE_NSUB each), [sphere 4][BASE_NP points]
+    each, then inertia (6), h (3), mass."""
+    by_body, base_subs = {}, []
     for c in contacts:
-        by_body.setdefault(c["body"], []).extend(c["points"])
+        if c["body"] == 0:
+            base_subs.append(c["points"])          # the base keeps its shapes apart: each gets its own bounding sphere
+        else:
+            by_body.setdefault(c["body"], []).extend(c["points"])
     has_rot = any("rot" in b for b in bodies)
     jstride = 28 if has_rot else 16
 
@@ -321,10 +324,18 @@ def emit_model_header(prefix, struct, title, bodies, contacts, nl, chains, path)
                 row += sphere(pts) + [x for pt in pts for x in pt]
         row += [0.0] * (side_stride - len(row))
         side += row
-    base_pts = by_body.get(0, [])
-    if len(base_pts) % 2:
-        base_pts = base_pts + [base_pts[-1]]
-    base = sphere(base_pts) + [x for pt in base_pts for x in pt] + Io(bodies[0]) + list(bodies[0]["mass"] * np.array(bodies[0]["com"])) + [bodies[0]["mass"]]
+    # base sub-shapes: BASE_NP points each, BASE_NSUB per lane (lane 0 takes the first half of the list, lane 1 the rest;
+    # an odd count is padded with an empty sub-shape: radius -1e9 never passes the bounding-sphere test)
+    base_np = max(len(x) for x in base_subs)
+    assert all(len(x) == base_np for x in base_subs), "base sub-shapes must carry the same number of points"
+    nsub = (len(base_subs) + 1) // 2
+    blocks = [sphere(x) + [v for pt in x for v in pt] for x in base_subs]
+    while len(blocks) < 2 * nsub:
+        blocks.insert(nsub if len(base_subs) > 1 else len(blocks), [0.0, 0.0, 0.0, -1.0e9] + [0.0] * (3 * base_np))
+    for k in range(nl):
+        if npts[k]:
+            assert sphere(by_body[1 + k])[3] <= 0.2, "side shapes must fit the 0.2 m reach of one terrain pool entry"
+    base = [v for blk in blocks for v in blk] + Io(bodies[0]) + list(bodies[0]["mass"] * np.array(bodies[0]["com"])) + [bodies[0]["mass"]]
     axis = [bodies[1 + k]["axis"] for k in range(nl)]
     assert axis == [bodies[1 + nl + k]["axis"] for k in range(nl)]
     ints = lambda v: ", ".join(str(x) for x in v)
@@ -341,7 +352,8 @@ def emit_model_header(prefix, struct, title, bodies, contacts, nl, chains, path)
          f"  static constexpr int NPTS[{nl}] = {{{ints(npts)}}};        // collision points per side-local body",
          f"  static constexpr int PTS_OFF[{nl}] = {{{ints(pts_off)}}};   // float offset of the body's [sphere 4][points 3 * n] block",
          f"  static constexpr int SIDE_STRIDE = {side_stride};",
-         f"  static constexpr int NBASE = {len(base_pts)};",
+         f"  static constexpr int BASE_NSUB = {nsub};             // base sub-shapes per lane, [sphere 4][points 3 * BASE_NP] each",
+         f"  static constexpr int BASE_NP = {base_np};",
          f"  static constexpr int BASE_FLOATS = {len(base)};",
          "};",
          f"HX_TABLE float {prefix}_SIDE[{len(side)}] = {{{', '.join(flit(v) for v in side)}}};",

@@ -8,10 +8,10 @@ from isaac_amd.envs.configs import HectorCfg, HectorFullCfg
 from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-mesh = sys.argv[3] if len(sys.argv) > 3 else "trimesh"      # trimesh | plane | flatgrid (terrain path over an all-zero grid)
+mesh = sys.argv[3] if len(sys.argv) > 3 else "trimesh"      # trimesh | heightfield (no walls) | plane | flatgrid (terrain path over an all-zero grid)
 task = sys.argv[4] if len(sys.argv) > 4 else "hector"          # hector | hector_full
 cfg = (HectorFullCfg if task == "hector_full" else HectorCfg)(); cfg.env.num_envs = n; cfg.seed = 5
-cfg.terrain.mesh_type = "plane" if mesh == "plane" else "trimesh"
+cfg.terrain.mesh_type = "plane" if mesh == "plane" else ("heightfield" if mesh == "heightfield" else "trimesh")
 if mesh == "flatgrid":
     cfg.terrain.terrain_proportions = [1.0, 0, 0, 0, 0, 0, 0]
 np.random.seed(5)
