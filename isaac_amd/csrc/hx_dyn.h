@@ -1,12 +1,12 @@
 // hx_dyn.h -- articulated-body dynamics of the hector family of bipeds (fp32), single source for the gfx950 kernels
 // and the host build (hx_math.h explains the split).
 //
-// Device layout: TWO lanes per robot.  Lane 2e owns the left body side of robot e, lane 2e+1 the right side; both carry
-// the floating base redundantly.  Every robot of the family is a base with kinematic chains hanging off it (hector: one
+// Device layout: EIGHT lanes per robot, four per body side (hx_math.h).  A side's four lanes run the side's recursion
+// redundantly and share its contact points; both sides carry the floating base redundantly.  Every robot of the family is a base with kinematic chains hanging off it (hector: one
 // 5-joint leg per side; hector_full: a leg and a 4-joint arm per side; XBot-L: one 6-joint leg per side), so
 // Featherstone's articulated-body algorithm splits cleanly per side: a lane runs the leaf-to-root recursion of its own
 // chains and the two sides' contributions to the base (6x6 articulated inertia + bias force, 33 floats) are summed with
-// one lane-pair exchange (DPP quad permutation, hx_xchg).  Per-side constants (joint offsets, inertias, limits, PD gains,
+// one cross-side exchange (DPP half-row mirror, hx_xchg).  Per-side constants (joint offsets, inertias, limits, PD gains,
 // collision points) are staged once per workgroup in LDS and read with the lane's side offset, which keeps the code
 // identical for both lanes -- half the instruction footprint of a one-lane-per-robot unrolling, which did not fit the
 // instruction cache (DESIGN.md "Env-step kernel").  Nothing inside the substep loop reads global memory.
@@ -74,6 +74,7 @@ struct DynParams {
   float wall;             // height difference between grid neighbours beyond which the trimesh has a vertical wall
                           // (slope_treshold * horizontal_scale, reference utils/terrain.py:70-73); 0 = no walls (heightfield)
   long long* prof;        // measurement builds (-DHX_STEP_PROF): per-wave cycle counters in LDS, else unused
+  int pt0, ptstep;        // this lane's share of a shape's points: pt0, pt0 + ptstep, ... (device: lane & 3, 4; host: 0, 1)
 };
 // Phase timers of the env-step kernel (tools/step_prof.py): lane 0 of a wave adds the shader-clock cycles since the
 // previous mark to counter `id`.  Compiled out unless -DHX_STEP_PROF.
@@ -299,7 +300,7 @@ HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const Con
   M3 H = m3zero();
   float any_on = 0.f;
 #pragma unroll 1
-  for (int k = 0; k < npts; ++k) {
+  for (int k = P.pt0; k < npts; k += P.ptstep) {
     const V3 r = ld3(pts + 3 * k);
     const float z = pb.z + dot(zb, r);
     V3 nb = zb;
@@ -345,11 +346,10 @@ HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const Con
     Myy += alpha + beta * nb.y * nb.y; Myz += beta * nb.y * nb.z; Mzz += alpha + beta * nb.z * nb.z;
   }
   if (!hx_any(any_on != 0.f)) return false;
-  // the first shape to touch a slot in this substep assigns, later ones (base sub-shapes share a slot) accumulate; both
-  // decisions are wave-uniform, lanes without an active point write zeros
-  const float keep = accumulate ? 1.f : 0.f;
-  auto acc = [&](int field, float val) { float& d = cb.at(out, field); d = accumulate ? d + val : val; };
-  (void)keep;
+  // the four lanes of the side add their partial sums (afterwards they agree bitwise).  The first shape to touch a slot in
+  // this substep assigns, later ones (base sub-shapes share a slot) accumulate; both decisions are wave-uniform, lanes
+  // without an active point write zeros
+  auto acc = [&](int field, float val) { float& d = cb.at(out, field); val = hx_qsum(val); d = accumulate ? d + val : val; };
   acc(HX_CB_F, f0.w.x); acc(HX_CB_F + 1, f0.w.y); acc(HX_CB_F + 2, f0.w.z); acc(HX_CB_F + 3, f0.v.x); acc(HX_CB_F + 4, f0.v.y); acc(HX_CB_F + 5, f0.v.z);
   acc(HX_CB_A, Axx); acc(HX_CB_A + 1, Axy); acc(HX_CB_A + 2, Axz); acc(HX_CB_A + 3, Ayy); acc(HX_CB_A + 4, Ayz); acc(HX_CB_A + 5, Azz);
   for (int i = 0; i < 9; ++i) acc(HX_CB_H + i, H.m[i]);

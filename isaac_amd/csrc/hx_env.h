@@ -226,6 +226,10 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   V3 base_lin_vel = mk(LD(SL.BLV), LD(SL.BLV + 1), LD(SL.BLV + 2));
   V3 base_ang_vel = mk(LD(SL.BAV), LD(SL.BAV + 1), LD(SL.BAV + 2));
   float ep_ret = LD(SL.EP_RET);
+  // per-term episode sums: loaded with the rest of the glue state (one batch of independent loads), updated in registers
+  // and stored once -- a read-modify-write per reward term made every term wait for its own global load
+  float ep_sum[HX_NUM_REWARDS];
+  for (int r = 0; r < HX_NUM_REWARDS; ++r) ep_sum[r] = p.ep_sums[(size_t)r * n + e];
 
   const float TWO_PI = 6.283185307179586f;
   V3 euler, pgrav;
@@ -299,7 +303,7 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
     auto add = [&](int id, float r) {
       const float x = r * sc[id];
       rsum += x;
-      if (writer) p.ep_sums[(size_t)id * n + e] += x;
+      ep_sum[id] += x;
     };
     if (sc[HX_R_ACTION_SMOOTHNESS] != 0.f) {
       float t1 = 0, t2 = 0, t3 = 0;
@@ -488,11 +492,8 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
     const int finished_len = ep_len;
     ep_len = 0;
     for (int r = 0; r < HX_NUM_REWARDS; ++r) {
-      if (writer) {
-        const float s = p.ep_sums[(size_t)r * n + e];
-        if (A.mode == 0 && s != 0.f) hx_atomic_add(&p.stat_sum[r], s);
-        p.ep_sums[(size_t)r * n + e] = 0.f;
-      }
+      if (writer && A.mode == 0 && ep_sum[r] != 0.f) hx_atomic_add(&p.stat_sum[r], ep_sum[r]);
+      ep_sum[r] = 0.f;
     }
     if (A.mode == 0 && writer) {
       // Train/mean_reward and Train/mean_episode_length of the runner (on_policy_runner.py:140-154)
@@ -572,6 +573,7 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   ST(SL.BLV, base_lin_vel.x); ST(SL.BLV + 1, base_lin_vel.y); ST(SL.BLV + 2, base_lin_vel.z);
   ST(SL.BAV, base_ang_vel.x); ST(SL.BAV + 1, base_ang_vel.y); ST(SL.BAV + 2, base_ang_vel.z);
   p.ep_len[e] = ep_len;
+  for (int r = 0; r < HX_NUM_REWARDS; ++r) p.ep_sums[(size_t)r * n + e] = ep_sum[r];
   ST(SL.EP_RET, ep_ret);
   p.rew[e] = rew_total;
   p.reset[e] = reset ? 1 : 0;
@@ -652,6 +654,6 @@ HXD DynParams dyn_params(const hx_sim_cfg& cfg, float friction) {
   DynParams P;
   P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
   P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
-  P.patch = nullptr; P.pool = nullptr; P.poolw = nullptr; P.prof = nullptr; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.wall = 0.f;
+  P.patch = nullptr; P.pool = nullptr; P.poolw = nullptr; P.prof = nullptr; P.pt0 = 0; P.ptstep = 1; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.wall = 0.f;
   return P;
 }

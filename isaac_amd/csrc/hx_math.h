@@ -20,12 +20,38 @@ using std::memcpy;
 #endif
 #include <utility>
 
-// ---- lane primitives.  Device: the two lanes 2e / 2e+1 of a wave are the two body sides of robot e; the partner's value
-// comes through a DPP quad permutation (one VALU instruction, no LDS round trip).  Host: one robot at a time, both
-// sides in sequence -- the drivers in hx_dyn.h / hx_env.h never call hx_xchg there.
+// ---- lane primitives.  Device: EIGHT lanes per robot -- lanes 8e .. 8e+3 are the left body side of robot e, lanes
+// 8e+4 .. 8e+7 the right side.  The four lanes of a side (a DPP quad) run the same articulated-body recursion redundantly
+// and SHARE the side's contact points (lane k takes points k, k+4, ...; hx_qsum adds the four partial sums, after which
+// the quad's lanes agree bitwise).  The other side's value comes through a DPP half-row mirror (lane i <-> 7 - i of each
+// group of eight: a left lane reads a right lane, all of which hold the same number).  Both are single VALU instructions,
+// no LDS round trip.  Host: one robot at a time, both sides in sequence -- the drivers never call hx_xchg there and the
+// quad operations are the identity.
+#define HX_LANES_PER_ROBOT 8
+#define HX_LANES_PER_SIDE 4
 #if defined(__HIPCC__)
-__device__ __forceinline__ float hx_xchg(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float hx_dpp_quad_xor1(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float hx_dpp_quad_xor2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ float hx_xchg(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x141, 0xF, 0xF, true)); }           // row_half_mirror
 #endif
+// sum / maximum over the four lanes of a body side; every lane of the quad receives the same result (the additions are
+// arranged so: (a + b) + (c + d) with both operand orders commuting bitwise)
+HXD float hx_qsum(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = x + hx_dpp_quad_xor1(x);
+  return x + hx_dpp_quad_xor2(x);
+#else
+  return x;
+#endif
+}
+HXD float hx_qmax(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = fmaxf(x, hx_dpp_quad_xor1(x));
+  return fmaxf(x, hx_dpp_quad_xor2(x));
+#else
+  return x;
+#endif
+}
 HXD bool hx_any(bool p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __any((int)p) != 0;

@@ -19,8 +19,9 @@
 #include "hx_common.h"
 
 // One launch per env step; the ten 1 ms substeps run inside with the robot's state in registers.  The arithmetic lives
-// in hx_dyn.h (dynamics) and hx_env.h (task glue), both shared with the host build; this kernel is the lane-pair driver:
-// lanes (2e, 2e+1) = (left side, right side) of robot e, 32 robots per 64-lane workgroup.
+// in hx_dyn.h (dynamics) and hx_env.h (task glue), both shared with the host build; this kernel is the lane-group driver:
+// eight lanes per robot (four per body side, hx_math.h), HX_RPW = 8 robots per 64-lane workgroup.
+#define HX_RPW (64 / HX_LANES_PER_ROBOT)      /* robots per wave = per workgroup */
 template <class M>
 __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim_cfg* __restrict__ cfgp, const float* __restrict__ actions,
                                                          const float* __restrict__ pack, StepArgs A) {
@@ -28,14 +29,14 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   using MI = ModelInfo<M>;
   constexpr int NL = D::NL, ND = D::ND;
   constexpr SLay SL(ND);
-  // dynamic LDS: staged constants | 32 height windows | 32 pooled bounds | window origins | per-lane contact buffer
+  // dynamic LDS: staged constants | HX_RPW height windows | pooled bounds | cliff flags | window origins | per-lane contact buffer
   extern __shared__ float lds_all[];
   float* lds_const = lds_all;
   float* lds_patch = lds_const + (MI::LDS_FLOATS + 3) / 4 * 4;
-  float* lds_pool = lds_patch + 32 * HX_PATCH_LD;
-  float* lds_poolw = lds_pool + 32 * HX_POOL_LD;
-  int (*lds_patch_org)[2] = reinterpret_cast<int (*)[2]>(lds_poolw + 32 * HX_POOL_LD);
-  float* lds_cb = lds_poolw + 32 * HX_POOL_LD + 64;
+  float* lds_pool = lds_patch + HX_RPW * HX_PATCH_LD;
+  float* lds_poolw = lds_pool + HX_RPW * HX_POOL_LD;
+  int (*lds_patch_org)[2] = reinterpret_cast<int (*)[2]>(lds_poolw + HX_RPW * HX_POOL_LD);
+  float* lds_cb = lds_poolw + HX_RPW * HX_POOL_LD + 2 * HX_RPW;
 #if defined(HX_STEP_PROF)
   __shared__ long long lds_prof[16];
   if (threadIdx.x < 16) lds_prof[threadIdx.x] = 0;
@@ -48,41 +49,39 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   const hx_sim_cfg& cfg = *cfgp;
   dyn_stage_constants<M>(lds_const, threadIdx.x, 64, cfg.p_gains, cfg.d_gains, cfg.torque_limits, cfg.default_dof_pos);
   const int n = cfg.num_envs;
-  const int e = (blockIdx.x * 64 + threadIdx.x) >> 1;
-  const int side = threadIdx.x & 1;
+  const int e = blockIdx.x * HX_RPW + (threadIdx.x >> 3);
+  const int side = (threadIdx.x >> 2) & 1, sub = threadIdx.x & 3, r = threadIdx.x >> 3;      // body side, lane of the side, robot of the wave
   const bool use_terrain = (p.terrain != nullptr) && (A.mode == 0);
   if (use_terrain) {
-    // Every lane fetches half of its own robot's windows: 8 of the 16 rows of the height window, 4 of the 8 rows of the
-    // two pooled maps.  All addresses follow from the robot's own base position, so the loads of a lane are independent
-    // and stay in flight together (a cooperative robot-by-robot copy waited for each robot's loads in turn).
-    const int ec = min(e, n - 1), r = threadIdx.x >> 1;
+    // Every lane fetches an eighth of its own robot's windows: 2 of the 16 rows of the height window, 1 of the 8 rows of
+    // the two pooled maps.  All addresses follow from the robot's own base position, so the loads of a lane are
+    // independent and stay in flight together.
+    const int ec = min(e, n - 1), part = threadIdx.x & 7;
     int oi, oj;
     patch_origin(p, p.st[(size_t)SL.ROOT_POS * n + ec], p.st[(size_t)(SL.ROOT_POS + 1) * n + ec], oi, oj);
-    if (side == 0) { lds_patch_org[r][0] = oi; lds_patch_org[r][1] = oj; }
-    const float* src = p.terrain + (size_t)(oi + side * (HX_PATCH / 2)) * p.t_cols + oj;
-    float* dst = lds_patch + r * HX_PATCH_LD + side * (HX_PATCH / 2) * HX_PATCH;
+    if (part == 0) { lds_patch_org[r][0] = oi; lds_patch_org[r][1] = oj; }
+    const float* src = p.terrain + (size_t)(oi + 2 * part) * p.t_cols + oj;
+    float* dst = lds_patch + r * HX_PATCH_LD + 2 * part * HX_PATCH;
+    {
+      float v[2 * HX_PATCH];
 #pragma unroll
-    for (int a = 0; a < HX_PATCH / 2; ++a) {
-      float v[HX_PATCH];
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < HX_PATCH; ++b) v[b] = src[(size_t)a * p.t_cols + b];
+        for (int b = 0; b < HX_PATCH; ++b) v[a * HX_PATCH + b] = src[(size_t)a * p.t_cols + b];
 #pragma unroll
-      for (int b = 0; b < HX_PATCH; ++b) dst[a * HX_PATCH + b] = v[b];
+      for (int k = 0; k < 2 * HX_PATCH; ++k) dst[k] = v[k];
     }
-    const size_t po = (size_t)(oi / 2 + side * (HX_POOL / 2)) * p.t_pcols + oj / 2;
+    const size_t po = (size_t)(oi / 2 + part) * p.t_pcols + oj / 2;
 #pragma unroll
-    for (int a = 0; a < HX_POOL / 2; ++a) {
-#pragma unroll
-      for (int b = 0; b < HX_POOL; ++b) {
-        lds_pool[r * HX_POOL_LD + (side * (HX_POOL / 2) + a) * HX_POOL + b] = p.t_pool[po + (size_t)a * p.t_pcols + b];
-        lds_poolw[r * HX_POOL_LD + (side * (HX_POOL / 2) + a) * HX_POOL + b] = p.t_poolw[po + (size_t)a * p.t_pcols + b];
-      }
+    for (int b = 0; b < HX_POOL; ++b) {
+      lds_pool[r * HX_POOL_LD + part * HX_POOL + b] = p.t_pool[po + b];
+      lds_poolw[r * HX_POOL_LD + part * HX_POOL + b] = p.t_poolw[po + b];
     }
   }
   __syncthreads();
   HX_T(prof, 0);
   if (e >= n) return;                      // both lanes of a pair leave together
-  const bool writer = (side == 0);         // env-level results are computed by both lanes, stored by one
+  const bool writer = (side == 0) && (sub == 0);         // env-level results are computed by all eight lanes, stored by one
   SideConst<M> C; C.bind(lds_const, side);
   Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
 #define LD(f) (p.st[(size_t)(f) * n + e])
@@ -110,8 +109,8 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     DynParams P = dyn_params(cfg, R.friction);
     P.prof = prof;
     HX_T(prof, 1);
+    P.pt0 = sub; P.ptstep = HX_LANES_PER_SIDE;
     if (use_terrain) {
-      const int r = threadIdx.x >> 1;
       P.patch = lds_patch + r * HX_PATCH_LD;
       P.px0 = p.t_x0 + (float)lds_patch_org[r][0] * p.t_hs;
       P.py0 = p.t_y0 + (float)lds_patch_org[r][1] * p.t_hs;
@@ -183,7 +182,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
 }
 
 template <class M> static constexpr size_t env_step_lds_bytes() {
-  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + 32 * HX_PATCH_LD + 2 * 32 * HX_POOL_LD + 64 + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * 64);
+  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + HX_RPW * HX_PATCH_LD + 2 * HX_RPW * HX_POOL_LD + 2 * HX_RPW + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * 64);
 }
 
 // Frame stacking for BOTH observation streams (hector_env.py:246-254 + clip of legged_robot.py:104-107), one
@@ -445,8 +444,8 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   A.rng_step = s->rng_step++;
   // reset counter: ping-pong pair; the stack kernel of step t zeroes the counter step t+1 will use
   s->p.num_reset = s->num_reset2[s->parity];
-  if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((2 * n + 63) / 64), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
-  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((2 * n + 63) / 64), dim3(64), env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
   if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }

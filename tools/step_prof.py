@@ -34,7 +34,7 @@ for _ in range(steps):
     L.hx_sim_step(env._h, act.ptr, None)
 out = np.zeros(9, np.int64)
 capi.check(L.hx_sim_prof(env._h, 0, out.ctypes.data), "prof")
-waves = (2 * n + 63) // 64
+waves = (n + 7) // 8
 names = ["window fetch + pooling", "action processing", "kinematics (x10)", "contact phase (x10)", "articulated inertias (x10)",
          "exchange + base solve (x10)", "accelerations, forces, integration (x10)", "guard + gather", "glue"]
 per = out / (waves * steps)
