@@ -50,46 +50,87 @@ def pmc_traffic(kernel_name):
         return None, None
 
 
-def cpu_baseline(sample_envs=4096, sample_steps=6, terrain="trimesh"):
-    """The numpy oracle (oracle/env.py + oracle/physics.py + oracle/ppo.py: the CPU restatement, kind="port")
-    timed on this box's host cores for a bounded sample of the same iteration: `sample_steps` rollout steps of
-    `sample_envs` robots (policy forward, env step with 10 substeps, store), GAE and the 2x4-minibatch update."""
-    from oracle.env import HectorEnvOracle, RP_SIZE
+def pmc_env_step():
+    """Wave-level VALU instructions per launch of the env-step kernel from the committed PMC pass (profiles/*_env_step_pmc.json,
+    `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` on this command); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_env_step_pmc.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        d["source"] = "profiles/" + os.path.basename(files[-1])
+        return d
+    except Exception:
+        return None
+
+
+def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_rows=16384):
+    """CPU baseline on this box's host cores, kind = "port": the env step is the HOST build of the product's own single-source
+    kernel text (oracle/host: isaac_amd/csrc/hx_math.h + hx_dyn.h + hx_env.h compiled with g++ -O3 -march=native -fopenmp,
+    OpenMP over robots) -- what SURVEY.md 8(d) specifies -- and the learner is the numpy oracle (oracle/ppo.py, BLAS threads).
+    Timed: `sample_steps` env steps of `sample_envs` robots on the same terrain (all host threads, then OMP_NUM_THREADS = 10,
+    the reference's physx.num_threads, hector_config.py:109) and one PPO minibatch step on `update_rows` rows scaled to the
+    8 x 61 440 rows of an iteration; combined into env-steps/s of a whole iteration."""
+    import subprocess
+    from isaac_amd.envs.configs import HectorCfg
+    code = (
+        "import sys, time, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from isaac_amd.envs.configs import HectorCfg\n"
+        "from oracle.host import HostEnv, lib\n"
+        f"cfg = HectorCfg(); cfg.env.num_envs = {sample_envs}; cfg.terrain.mesh_type = {terrain!r}; cfg.seed = 5\n"
+        "np.random.seed(5)\n"
+        "env = HostEnv(cfg)\n"
+        f"a = (0.3 * np.random.default_rng(0).standard_normal(({sample_envs}, 10))).astype(np.float32)\n"
+        "for _ in range(10): env.L.hxh_step(env.h, a.ctypes.data, None)\n"
+        "best = 1e30\n"
+        "for rep in range(3):\n"
+        "    t0 = time.perf_counter()\n"
+        f"    for _ in range({max(1, sample_steps // 3)}): env.L.hxh_step(env.h, a.ctypes.data, None)\n"
+        f"    best = min(best, (time.perf_counter() - t0) / {max(1, sample_steps // 3)})\n"
+        "print(json.dumps(dict(s_per_step=best, threads=int(lib().hxh_num_threads()))))\n")
+
+    def run(threads):
+        env = dict(os.environ)
+        if threads:
+            env["OMP_NUM_THREADS"] = str(threads)
+        else:
+            env.pop("OMP_NUM_THREADS", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    full, ten = run(None), run(10)
+    # learner: one minibatch step (forward, loss, backward, clip, Adam) of the numpy oracle on a bounded number of rows
     from oracle.ppo import ActorCriticOracle, PPOOracle
     rng = np.random.default_rng(0)
-    n, T = sample_envs, sample_steps
-    pack = lambda: np.concatenate([rng.uniform(size=(34, n)), rng.standard_normal((41, n))]).astype(np.float32)
-    hf, origins = None, np.zeros((n, 3))
-    if terrain != "plane":                # the same 20 x 20 tile map layout as the product's default config (untimed set-up)
-        import types
-        from oracle.terrain import HeightField, HumanoidTerrainOracle
-        tc = types.SimpleNamespace(mesh_type=terrain, horizontal_scale=0.1, vertical_scale=0.005, border_size=25, curriculum=False,
-                                   selected=False, terrain_length=8.0, terrain_width=8.0, num_rows=20, num_cols=20,
-                                   terrain_proportions=[0.1, 0.1, 0.2, 0.1, 0.1, 0.2, 0.2])
-        np.random.seed(5)
-        ter = HumanoidTerrainOracle(tc, n)
-        hf = HeightField(ter.heightsamples, 0.1, 0.005, 25)
-        origins = ter.env_origins[rng.integers(0, 20, n), np.floor(np.arange(n) / (n / 20)).astype(int)]
-    env = HectorEnvOracle(n, rng.uniform(0.1, 1.0, n), 8.15528 + rng.uniform(-2, 4, n), origins, pack(),
-                          start_xy=origins, terrain=hf, custom_origins=hf is not None)
-    alg = PPOOracle(ActorCriticOracle.default_init(rng), n, T)
+    N, T = update_rows // 16, 16
+    alg = PPOOracle(ActorCriticOracle.default_init(rng), N, T, num_learning_epochs=1, num_mini_batches=1)
     t0 = time.perf_counter()
-    obs, priv = env.obs_buf, env.priv_buf
-    for _ in range(T):
-        a = alg.act(obs, priv, rng.standard_normal((n, 10)).astype(np.float32))
-        obs, priv, rew, done = env.step(a, pack())
-        alg.process_env_step(rew, done, env.time_outs_visible)
-    alg.compute_returns(priv)
-    alg.update(rng.permutation(n * T))
-    dt = time.perf_counter() - t0
+    for t in range(T):
+        o, pv = rng.standard_normal((N, 615)).astype(np.float32), rng.standard_normal((N, 1050)).astype(np.float32)
+        alg.act(o, pv, rng.standard_normal((N, 10)).astype(np.float32))
+        alg.process_env_step(rng.uniform(0, 0.05, N).astype(np.float32), rng.uniform(size=N) < 0.01)
+    t_act = (time.perf_counter() - t0) / (N * T)                  # policy forward + store, seconds per env-step
+    alg.compute_returns(pv)
+    t0 = time.perf_counter()
+    alg.update(rng.permutation(N * T))
+    t_upd_row = (time.perf_counter() - t0) / (N * T)              # seconds per minibatch row
     try:
         import threadpoolctl
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+        blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count()
-    return {"value": n * T / dt, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
-            "sample": f"{T} rollout steps x {n} envs (terrain {terrain}) + GAE + full 2x4-minibatch update, numpy float32/64 oracle, "
-                      f"{dt:.1f} s wall; host has {os.cpu_count()} logical cores"}
+        blas_threads = os.cpu_count()
+    n = sample_envs
+    per_env_step = lambda env_s: env_s / n + t_act + 2 * t_upd_row          # 2 epochs over every stored row
+    v_full, v_ten = 1.0 / per_env_step(full["s_per_step"]), 1.0 / per_env_step(ten["s_per_step"])
+    return {"value": v_full, "unit": "env-steps/s", "cores": int(full["threads"]), "kind": "port",
+            "sample": f"{sample_steps} env steps x {n} robots (terrain {terrain}) on the host build of the kernel source: "
+                      f"{1e3 * full['s_per_step']:.1f} ms per step with {full['threads']} OpenMP threads, {1e3 * ten['s_per_step']:.1f} ms with 10; "
+                      f"learner = numpy oracle, {T} policy steps + one minibatch step on {N * T} rows ({blas_threads} BLAS threads), scaled to 2 epochs; "
+                      f"host has {os.cpu_count()} logical cores",
+            "env_only_env_steps_per_s": n / full["s_per_step"], "omp10": {"value": v_ten, "env_only_env_steps_per_s": n / ten["s_per_step"], "cores": 10}}
 
 
 def main():
@@ -176,12 +217,19 @@ def main():
     if not args.no_prof:
         dominant = max(prof_all["kernels"], key=lambda r: r["ms"])["name"] if prof_all and prof_all["kernels"] else None
         runner.alg.prof_begin(only=dominant)
+        if args.shards == 1:
+            capi.check(capi.lib().hx_sim_time(env._h, 1, None), "hx_sim_time")
     t0 = time.perf_counter()
     runner.learn(args.steps, init_at_random_ep_len=False)
     env.sync()
     comm.barrier()
     elapsed = time.perf_counter() - t0
     prof = None if args.no_prof else runner.alg.prof_end()
+    env_step_ms = None
+    if not args.no_prof and args.shards == 1:
+        tt = np.zeros(2, np.float64)
+        capi.check(capi.lib().hx_sim_time(env._h, 0, tt.ctypes.data), "hx_sim_time")
+        env_step_ms = tt
     elapsed = comm.max_over_ranks(elapsed)
 
     if comm.rank == 0:
@@ -213,6 +261,20 @@ def main():
                                "all_gemm_kernels": (prof_all or prof)["kernels"],
                                "all_gemm_kernels_from": "warm-up iterations (all launches bracketed)" if prof_all else "timed region",
                                "whole_iteration_mfma_frac": None if full else value / world * FLOP_PER_ENV_STEP / (peak * 1e12)}
+        if env_step_ms is not None and env_step_ms[1] > 0 and "roofline" in out:
+            # the env-step kernel: top kernel of the rollout, bound by VALU issue (it reads and writes ~1.3 KB per robot).
+            # peak = one wave64 VALU instruction per SIMD every 4 cycles at 2.4 GHz on 1024 SIMDs
+            us = 1e3 * env_step_ms[0] / env_step_ms[1]
+            pmc = None if full else pmc_env_step()
+            peak = 1024 * 2.4e9 / 4
+            es = {"kernel": "hx_env_step_kernel", "bound": "valu-issue", "launches": int(env_step_ms[1]), "avg_launch_us": us,
+                  "waves": (args.envs + 7) // 8, "peak_wave_insts_per_s": peak, "valu_insts_per_launch": None, "achieved_wave_insts_per_s": None, "frac": None}
+            if pmc and args.envs == 4096 and args.terrain == pmc.get("terrain", "trimesh"):
+                es["valu_insts_per_launch"] = pmc["valu_insts_per_launch"]
+                es["achieved_wave_insts_per_s"] = pmc["valu_insts_per_launch"] / (us * 1e-6)
+                es["frac"] = es["achieved_wave_insts_per_s"] / peak
+                es["pmc_source"] = pmc.get("source")
+            out["roofline"]["env_step"] = es
         if not args.no_cpu_baseline and world == 1 and not full:            # rank 0 at N = 1 only; other ranks wait at the barrier below
             try:
                 out["cpu_baseline"] = cpu_baseline(terrain=args.terrain)

@@ -99,6 +99,7 @@ def lib():
     L.hx_sim_episode_stats.argtypes = [vp, vp, vp]
     L.hx_sim_stream.argtypes = [vp]
     L.hx_sim_prof.argtypes = [vp, C.c_int, vp]
+    L.hx_sim_time.argtypes = [vp, C.c_int, vp]
     L.hx_sim_stream.restype = vp
     # generic device memory helpers
     L.hx_malloc.argtypes = [C.c_size_t, C.POINTER(vp)]

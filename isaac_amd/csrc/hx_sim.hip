@@ -273,6 +273,8 @@ struct hx_sim {
   uint32_t rng_step;
   uint64_t seed;
   std::vector<void*> allocs;
+  // HIP-event timing of the env-step kernel (hx_sim_time)
+  bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0;
 };
 
 template <typename T> static int dalloc(hx_sim* s, T** ptr, size_t count) {
@@ -427,6 +429,7 @@ extern "C" void hx_sim_destroy(hx_sim* s) {
   if (!s) return;
   (void)hipDeviceSynchronize();
   for (void* a : s->allocs) hipFree(a);
+  for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
   if (s->own_stream) hipStreamDestroy(s->stream);
   delete s;
 }
@@ -444,8 +447,15 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   A.rng_step = s->rng_step++;
   // reset counter: ping-pong pair; the stack kernel of step t zeroes the counter step t+1 will use
   s->p.num_reset = s->num_reset2[s->parity];
+  bool timed = s->timing && mode == 0;
+  if (timed) {
+    while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); }
+    timed = s->ev_used + 2 <= s->ev.size();
+  }
+  if (timed) (void)hipEventRecord(s->ev[s->ev_used], s->stream);
   if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], s->stream); s->ev_used += 2; }
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
   if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }
@@ -580,6 +590,19 @@ extern "C" int hx_sim_episode_stats(hx_sim* s, float* mean_h, int32_t* count_h) 
   HX_CHECK(hipMemset(s->p.stat_acc, 0, sizeof(acc)));
   HX_CHECK(hipMemset(s->p.stat_steps, 0, sizeof(int)));
   HX_CHECK(hipMemset(s->p.stat_cnt, 0, sizeof(int)));
+  return 0;
+}
+// HIP-event timing of the env-step kernel on the simulator's stream: which = 1 start / clear, 0 stop and read
+// {total milliseconds, launches} (bench.py: the live duration behind roofline.env_step)
+extern "C" int hx_sim_time(hx_sim* s, int which, double* out_h /*[2]*/) {
+  if (!s) { hx_set_error("hx_sim_time: null sim"); return -2; }
+  if (which == 1) { s->timing = true; s->ev_used = 0; return 0; }
+  s->timing = false;
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  double ms = 0;
+  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); ms += t; }
+  if (out_h) { out_h[0] = ms; out_h[1] = (double)(s->ev_used / 2); }
+  s->ev_used = 0;
   return 0;
 }
 extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }
