@@ -177,9 +177,8 @@ def main():
         if args.gpus != 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     if args.force_collectives and world == 1:
-        from isaac_amd.parallel import TorchComm
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
-        comm = TorchComm("nccl")
+        from isaac_amd.parallel import HxComm
+        comm = HxComm(rank=0, world_size=1, local_rank=0)      # one rank, real RCCL: every collective of the N > 1 path runs
         comm.force_collectives = True
     else:
         comm = init_comm()

@@ -94,6 +94,32 @@ int hx_ppo_last_values_range(hx_ppo* p, const float* last_priv, int env0, int co
 int hx_ppo_adv_moments(hx_ppo* p, void** moments /* double[3] on device: sum, sum of squares, count */);
 int hx_ppo_adv_normalize(hx_ppo* p);
 
+/* ---- data parallelism (absent in the reference): one process per GPU, environments sharded, parameters
+ * replicated.  hx_comm is an RCCL communicator over xGMI owned by this library (bound at run time, no link dependency):
+ *   rank 0:      hx_comm_get_unique_id(id)    -- 128 opaque bytes (ncclUniqueId), handed to the other ranks by the host
+ *   every rank:  hx_comm_init(id, rank, world, &c) ; hx_ppo_set_comm(learner, c)
+ * From then on hx_ppo_update / hx_ppo_minibatch_step enqueue ONE ncclAllReduce(sum) of the flat
+ * [gradient | kl_sum | value_loss_sum | surrogate_sum | rows] buffer per optimiser step on the learner's stream, between the
+ * backward kernels and the Adam kernel (which scales by 1 / world), and hx_ppo_adv_normalize all-reduces the three
+ * advantage moments on the same stream first, so that the normalisation (rollout_storage.py:135-136) is the one a single
+ * process would compute over all ranks' rows.  Nothing synchronises with the host.  Every rank sees the same global KL, so
+ * the learning-rate decision (ppo.py:136-148) and with it the parameters stay bit-identical without a broadcast;
+ * hx_ppo_broadcast_params makes them identical once at start-up. */
+#define HX_COMM_ID_BYTES 128
+enum { HX_COMM_F32 = 0, HX_COMM_F64 = 1 };
+enum { HX_COMM_SUM = 0, HX_COMM_MAX = 1 };
+typedef struct hx_comm hx_comm;
+int hx_comm_get_unique_id(uint8_t* id_h /*[HX_COMM_ID_BYTES]*/);
+int hx_comm_init(const uint8_t* id_h, int rank, int world, hx_comm** out);
+void hx_comm_destroy(hx_comm* c);
+int hx_comm_rank(hx_comm* c);
+int hx_comm_world(hx_comm* c);
+/* in-place collectives on device buffers for the host's bookkeeping (barrier, max-over-ranks timing, episode statistics) */
+int hx_comm_all_reduce(hx_comm* c, void* buf, size_t count, int dtype, int op, void* hip_stream);
+int hx_comm_broadcast(hx_comm* c, void* buf, size_t count_f32, int root, void* hip_stream);
+int hx_ppo_set_comm(hx_ppo* p, hx_comm* c /*NULL: back to single process*/);
+int hx_ppo_broadcast_params(hx_ppo* p, int root);
+
 int hx_ppo_update_begin(hx_ppo* p, const int32_t* perm /*[T*N], nullable: drawn on device*/);
 int hx_ppo_minibatch_backward(hx_ppo* p, int mb_index, void** grad_buffer, int64_t* count);
 int hx_ppo_minibatch_step(hx_ppo* p, float inv_world_size);

@@ -40,8 +40,8 @@ class OnPolicyRunner:
         self.comm = comm
         num_critic_obs = env.num_privileged_obs if env.num_privileged_obs is not None else env.num_obs
         actor_critic = _CLASSES[self.cfg["policy_class_name"]](env.num_obs, num_critic_obs, env.num_actions, **self.policy_cfg)
-        if comm is not None and comm.world_size > 1:
-            actor_critic.load_state_dict(comm.broadcast_state(actor_critic.state_dict()))
+        if comm is not None and comm.world_size > 1 and not getattr(comm, "in_library", False):
+            actor_critic.load_state_dict(comm.broadcast_state(actor_critic.state_dict()))      # HxComm broadcasts on the device instead
         alg_kw = dict(self.alg_cfg)
         if "seed" in train_cfg and "seed" not in alg_kw:      # exploration noise keyed by seed + rank, permutation by seed
             alg_kw["seed"] = train_cfg["seed"]

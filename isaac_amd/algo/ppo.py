@@ -181,7 +181,7 @@ class PPO:
             raise ValueError("num_envs * num_steps_per_env must be divisible by num_mini_batches")
         self._cfg = c
         ext = None
-        if self._distributed():
+        if self._distributed() and not getattr(self.comm, "in_library", False):
             ext = self.comm.alloc_grad_buffer(self._padded_count(c) + 4)
         h = capi.C.c_void_p()
         capi.check(self._L.hx_ppo_create(capi.C.byref(c), self._stream, ext, capi.C.byref(h)), "hx_ppo_create")
@@ -193,6 +193,8 @@ class PPO:
         if self.mlp_dtype == "bf16":
             capi.check(self._L.hx_ppo_set_compute_dtype(h, 1), "hx_ppo_set_compute_dtype")
         ac.load_state_dict(ac._pending_state)
+        if self._distributed() and getattr(self.comm, "in_library", False):
+            self.comm.attach(self)        # RCCL inside the library: hx_ppo_set_comm + parameter broadcast from rank 0
         if self.seed is not None:         # exploration noise keyed per rank, permutation keyed by the run's seed
             rank = self.comm.rank if self.comm is not None else 0
             capi.check(self._L.hx_ppo_set_seed(h, int(self.seed) + rank, int(self.seed)), "hx_ppo_set_seed")
@@ -268,7 +270,7 @@ class PPO:
             capi.check(self._L.hx_ppo_last_values_range(self._h, device_pointer(priv)[0], env0, count, stream), "last_values_range")
             capi.check(self._L.hx_sync(stream), "sync")
         capi.check(self._L.hx_ppo_compute_returns(self._h, None), "hx_ppo_compute_returns")
-        if self._distributed():
+        if self._distributed() and not getattr(self.comm, "in_library", False):
             m = capi.C.c_void_p()
             capi.check(self._L.hx_ppo_adv_moments(self._h, capi.C.byref(m)), "adv_moments")
             self.comm.all_reduce_moments(m.value, self.stream)
@@ -288,7 +290,7 @@ class PPO:
     def compute_returns(self, last_critic_obs):
         pp, k = self._padded_ptr(last_critic_obs, self._cfg.num_priv, self.priv_ld)
         capi.check(self._L.hx_ppo_compute_returns(self._h, pp), "hx_ppo_compute_returns")
-        if self._distributed():
+        if self._distributed() and not getattr(self.comm, "in_library", False):
             m = capi.C.c_void_p()
             capi.check(self._L.hx_ppo_adv_moments(self._h, capi.C.byref(m)), "adv_moments")
             self.comm.all_reduce_moments(m.value, self.stream)
@@ -300,7 +302,8 @@ class PPO:
         pp, k = (None, None) if perm is None else device_pointer(np.ascontiguousarray(perm, np.int32))
         stats = np.zeros(4, np.float32)
         world = 1 if self.comm is None else self.comm.world_size
-        if not self._distributed():
+        if not self._distributed() or getattr(self.comm, "in_library", False):
+            # one C call; with a library-owned communicator it enqueues the RCCL all-reduce of every optimiser step itself
             capi.check(self._L.hx_ppo_update(self._h, pp, capi.ptr(stats)), "hx_ppo_update")
         else:
             capi.check(self._L.hx_ppo_update_begin(self._h, pp), "update_begin")

@@ -133,6 +133,16 @@ def lib():
     L.hx_ppo_last_values_range.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     L.hx_ppo_adv_moments.argtypes = [vp, C.POINTER(vp)]
     L.hx_ppo_adv_normalize.argtypes = [vp]
+    L.hx_comm_get_unique_id.argtypes = [vp]
+    L.hx_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.hx_comm_destroy.argtypes = [vp]
+    L.hx_comm_destroy.restype = None
+    L.hx_comm_rank.argtypes = [vp]
+    L.hx_comm_world.argtypes = [vp]
+    L.hx_comm_all_reduce.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    L.hx_comm_broadcast.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    L.hx_ppo_set_comm.argtypes = [vp, vp]
+    L.hx_ppo_broadcast_params.argtypes = [vp, C.c_int]
     L.hx_ppo_update_begin.argtypes = [vp, vp]
     L.hx_ppo_minibatch_backward.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.hx_ppo_minibatch_step.argtypes = [vp, C.c_float]

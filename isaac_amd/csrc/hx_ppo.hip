@@ -818,6 +818,7 @@ struct hx_ppo {
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
   uint32_t seed_lo, seed_hi, act_counter, perm_counter, perm_key;
+  hx_comm* comm = nullptr;       // RCCL communicator (hx_comm.hip) when data parallel: all-reduce inside hx_ppo_minibatch_step
   // profiling
   bool prof; std::vector<hipEvent_t> ev; std::vector<int> ev_kid; size_t ev_used; double prof_flops[5]; long prof_launches[5];
   std::vector<void*> allocs;
@@ -1347,6 +1348,18 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
   delete s;
 }
 
+extern "C" int hx_ppo_set_comm(hx_ppo* s, hx_comm* c) {
+  if (!s) { hx_set_error("hx_ppo_set_comm: null learner"); return -2; }
+  s->comm = c;
+  return 0;
+}
+extern "C" int hx_ppo_broadcast_params(hx_ppo* s, int root) {
+  if (!s || !s->comm) { hx_set_error("hx_ppo_broadcast_params: no communicator set"); return -2; }
+  int rc = hx_comm_broadcast(s->comm, s->params, s->padded, root, s->stream); if (rc) return rc;
+  refresh_transposes(s, s->stream);
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
 extern "C" int64_t hx_ppo_num_params(hx_ppo* s) { return s->torch_count; }
 // Keys of the learner's two random streams.  sample_seed keys the action noise of PPO.act (Philox counter = env row,
 // act call, action index): data-parallel ranks pass seed + rank so that their exploration noise is independent.
@@ -1592,6 +1605,7 @@ extern "C" int hx_ppo_compute_returns(hx_ppo* s, const float* last_priv) {
 extern "C" int hx_ppo_adv_moments(hx_ppo* s, void** m) { *m = s->moments; return 0; }
 extern "C" int hx_ppo_adv_normalize(hx_ppo* s) {
   const size_t TN = (size_t)s->cfg.num_steps * s->cfg.num_envs;
+  if (s->comm) { const int rc = hx_comm_all_reduce(s->comm, s->moments, 3, HX_COMM_F64, HX_COMM_SUM, s->stream); if (rc) return rc; }
   hipLaunchKernelGGL(hx_adv_normalize_kernel, dim3((unsigned)((TN + 255) / 256)), dim3(256), 0, s->stream, s->s_adv_raw, s->moments, TN, s->s_adv);
   HX_CHECK(hipGetLastError());
   return 0;
@@ -1687,6 +1701,11 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
 extern "C" int hx_ppo_minibatch_step(hx_ppo* s, float inv_world) {
   const hx_ppo_cfg& c = s->cfg;
   hipStream_t st = s->stream;
+  if (s->comm) {
+    // the one collective of an optimiser step: gradients and loss statistics of all ranks, in place, on this stream
+    const int rc = hx_comm_all_reduce(s->comm, s->grads, s->padded + 4, HX_COMM_F32, HX_COMM_SUM, st); if (rc) return rc;
+    inv_world = 1.0f / (float)hx_comm_world(s->comm);
+  }
   // after an all-reduce(sum) the statistics are global sums, so kl_mean = kl_sum / rows is already world-wide
   hipLaunchKernelGGL(hx_schedule_kernel, dim3(1), dim3(1), 0, st, s->grads + s->stats_off, c.adaptive_schedule, c.desired_kl, s->sched);
   HX_CHECK(hipMemsetAsync(s->sumsq, 0, sizeof(double), st));

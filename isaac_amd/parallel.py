@@ -9,10 +9,12 @@ so that after it every rank holds the global gradient sum AND the global KL stat
 Adam kernel, and parameters stay bit-identical across ranks without a broadcast.  Once per iteration a 3-double
 all-reduce makes the advantage normalisation (rollout_storage.py:135-136) global.
 
-Transport: torch.distributed -- backend "nccl" (= RCCL over xGMI on ROCm) on GPUs; backend "gloo" for the
-world_size-2 CPU tests of this orchestration (tests/test_parallel_cpu.py).  The gradient buffer is allocated
-by torch when world_size > 1 and handed to the library as an external buffer (hx_ppo_create ext_grad_buffer),
-so the collective runs on the tensor in place with no staging copy.  xGMI sizing: 6.07 MB per step, ring
+Transport on GPUs: RCCL over xGMI INSIDE libhx.so (HxComm below; isaac_amd/csrc/hx_comm.hip, include/hx_ppo.h): the
+learner enqueues the all-reduce on its own HIP stream between the backward kernels and the Adam kernel, the advantage
+moments are all-reduced on the same stream, nothing synchronises with the host and torch.distributed is not involved
+(its TCPStore carries the 128-byte RCCL unique id from rank 0 to the others, once).  TorchComm (torch.distributed,
+backend "gloo") remains for the world_size-2 CPU tests of the orchestration (tests/test_parallel_cpu.py) and as
+"gloo-staged" rehearsal of the real kernels with several ranks on one GPU.  xGMI sizing: 6.07 MB per step, ring
 all-reduce moves 2*(7/8)*6.07 MB = 10.6 MB per link direction ~ 70 us at ~153 GB/s/link, < 1 % of a 61 440-row
 minibatch step, so a single un-bucketed collective is the right granularity.
 """
@@ -59,7 +61,9 @@ class TorchComm(Comm):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if backend is None:
-            backend = os.environ.get("HX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = os.environ.get("HX_DIST_BACKEND") or "gloo"
+        if backend == "nccl":
+            raise ValueError("the RCCL transport lives in libhx.so now: use isaac_amd.parallel.HxComm (HX_DIST_BACKEND=rccl)")
         # "gloo-staged": gloo collectives on host copies of the library's DEVICE buffers.  A functional rehearsal of the
         # N > 1 path where RCCL cannot run (several ranks sharing one GPU); never the measured configuration.
         self.staged = (backend == "gloo-staged")
@@ -156,10 +160,77 @@ class TorchComm(Comm):
             self.dist.destroy_process_group()
 
 
+class HxComm(Comm):
+    """RCCL communicator owned by libhx.so.  in_library = True tells PPO that the library issues the collectives itself
+    (hx_ppo_set_comm): PPO.update is then the same single C call as on one GPU."""
+    in_library = True
+
+    def __init__(self, rank=None, world_size=None, local_rank=None):
+        import ctypes as C
+        from . import capi
+        self.capi, self.C = capi, C
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
+        L = capi.lib()
+        ndev = max(1, L.hx_device_count())
+        capi.check(L.hx_set_device(self.local_rank % ndev), "hx_set_device")
+        uid = (C.c_uint8 * 128)()
+        if self.world_size > 1:
+            # host-side rendezvous: rank 0's unique id through a TCPStore on MASTER_ADDR:MASTER_PORT (plumbing only)
+            from datetime import timedelta
+            from torch.distributed import TCPStore
+            store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29511")), self.world_size,
+                             self.rank == 0, timeout=timedelta(seconds=300))
+            if self.rank == 0:
+                capi.check(L.hx_comm_get_unique_id(uid), "hx_comm_get_unique_id")
+                store.set("hx_rccl_unique_id", bytes(uid))
+            else:
+                raw = store.get("hx_rccl_unique_id")
+                C.memmove(uid, raw, 128)
+            self._store = store
+        else:
+            capi.check(L.hx_comm_get_unique_id(uid), "hx_comm_get_unique_id")
+        h = C.c_void_p()
+        capi.check(L.hx_comm_init(uid, self.rank, self.world_size, C.byref(h)), "hx_comm_init")
+        self._h = h
+        self._scratch = capi.DeviceBuffer(64)
+
+    def attach(self, alg):
+        """Bind the learner: gradients / moments are all-reduced inside the library from now on; rank 0's parameters win."""
+        self.capi.check(self.capi.lib().hx_ppo_set_comm(alg._h, self._h), "hx_ppo_set_comm")
+        self.capi.check(self.capi.lib().hx_ppo_broadcast_params(alg._h, 0), "hx_ppo_broadcast_params")
+
+    def _reduce_scalar(self, x, op):
+        a = np.array([float(x)], np.float64)
+        self._scratch.upload(a)
+        self.capi.check(self.capi.lib().hx_comm_all_reduce(self._h, self._scratch.ptr, 1, 1, op, None), "hx_comm_all_reduce")
+        return float(self._scratch.download(np.float64, (1,))[0])
+
+    def barrier(self):
+        self._reduce_scalar(0.0, 0)
+
+    def max_over_ranks(self, x):
+        return self._reduce_scalar(x, 1)
+
+    def sum_over_ranks(self, x):
+        return self._reduce_scalar(x, 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.capi.lib().hx_comm_destroy(self._h)
+            self._h = None
+
+
 def init_comm(backend=None):
-    """Comm for this process: TorchComm under torch.distributed.run (WORLD_SIZE > 1), identity otherwise."""
+    """Comm for this process: under torch.distributed.run (WORLD_SIZE > 1) the in-library RCCL communicator on GPUs
+    (HX_DIST_BACKEND=rccl, the default there), TorchComm for "gloo" / "gloo-staged"; the identity otherwise."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        return TorchComm(backend)
+        backend = backend or os.environ.get("HX_DIST_BACKEND")
+        if backend is None:
+            from . import capi
+            backend = "rccl" if capi.lib().hx_device_count() > 0 else "gloo"
+        return HxComm() if backend in ("rccl", "nccl") else TorchComm(backend)
     return Comm()
 
 

@@ -20,8 +20,8 @@ def main(out_path, iters):
     from isaac_amd.parallel import init_comm
     from isaac_amd.utils.helpers import set_seed
     if os.environ.get("HX_DP_FORCE_RCCL") == "1":      # one rank, real RCCL: every collective of the N > 1 path runs (as identity)
-        from isaac_amd.parallel import TorchComm
-        comm = TorchComm("nccl")
+        from isaac_amd.parallel import HxComm
+        comm = HxComm(rank=0, world_size=1, local_rank=0)
         comm.force_collectives = True
     else:
         comm = init_comm()

@@ -32,10 +32,10 @@ def test_two_ranks_stay_bit_identical(hxlib, tmp_path):
 
 
 def test_one_rank_rccl_path_equals_single_process(hxlib, tmp_path):
-    """The measured N > 1 transport is torch.distributed's "nccl" backend (= RCCL), which cannot run with two ranks on the
-    one GPU of the test box.  With ONE rank it can: the whole distributed path (torch-owned gradient buffer handed to
-    hx_ppo_create, backward / all-reduce in place through RCCL / step with 1/world scaling, advantage-moment all-reduce,
-    stream hand-offs between the library's stream and torch's) must then train bitwise like the single-process path."""
+    """The measured N > 1 transport is RCCL inside libhx.so (hx_comm_init / hx_ppo_set_comm), which cannot run with two ranks
+    on the one GPU of the test box.  With ONE rank it can: the whole distributed path (unique id, communicator, parameter
+    broadcast, ncclAllReduce of the flat gradient + statistics buffer on the learner's stream in every optimiser step with
+    1/world scaling, advantage-moment all-reduce) must then train bitwise like the single-process path."""
     outs = []
     for tag, extra in (("plain", {}), ("rccl", {"HX_DP_FORCE_RCCL": "1", "MASTER_ADDR": "127.0.0.1",
                                                 "MASTER_PORT": str(29900 + os.getpid() % 90)})):

@@ -137,17 +137,13 @@ def test_rollout_overflow_raises(hxlib):
 
 
 def test_collective_code_path_single_rank(hxlib):
-    """Walk the multi-GPU path with one rank: torch-owned external gradient buffer, RCCL all-reduce through
-    torch.distributed (backend nccl), 1/world scaling in the Adam kernel.  With world_size 1 the result must be
-    bit-identical to the fused single-process path."""
-    import os
-    import torch
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    from isaac_amd.parallel import TorchComm
-    comm = TorchComm("nccl")
+    """Walk the multi-GPU path with one rank: RCCL communicator inside libhx.so (hx_comm_init), parameter broadcast,
+    ncclAllReduce of the gradient buffer and of the advantage moments on the learner's stream, 1/world scaling in the Adam
+    kernel.  With world_size 1 the result must be bit-identical to the plain single-process path."""
+    from isaac_amd.parallel import HxComm
+    comm = HxComm(rank=0, world_size=1, local_rank=0)
     comm.force_collectives = True
+    assert comm.max_over_ranks(3.25) == 3.25 and comm.sum_over_ranks(-1.5) == -1.5
     seed, T, N = 31, 4, 64
     inp = rollout_inputs(seed, T, N)
     perm = np.random.default_rng(1).permutation(T * N).astype(np.int32)
@@ -170,7 +166,40 @@ def test_collective_code_path_single_rank(hxlib):
     assert l0 == l1 and lr0 == lr1
     for k in sd0:
         np.testing.assert_array_equal(sd0[k], sd1[k], err_msg=k)
-    torch.distributed.destroy_process_group()
+    comm.close()
+
+
+def test_ranks_draw_different_exploration_noise(hxlib):
+    """hx_ppo_set_seed(seed + rank, seed): two learners standing for two data-parallel ranks, identical weights and identical
+    observations, must sample DIFFERENT actions (independent exploration), and a learner re-created with the same rank's seed
+    the same ones; hx_ppo_set_rng_state restores a position in the stream (what a resumed checkpoint does)."""
+    class FakeComm:
+        in_library, world_size, local_rank = False, 1, 0
+
+        def __init__(self, rank):
+            self.rank = rank
+    rng = np.random.default_rng(0)
+    o, p = rng.standard_normal((32, 615)).astype(np.float32), rng.standard_normal((32, 1050)).astype(np.float32)
+    init = ActorCriticOracle.default_init(np.random.default_rng(5))
+    acts = []
+    for rank in (0, 1, 0):
+        ac = ActorCritic(615, 1050, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[768, 256, 128])
+        ac.load_state_dict(init.state_dict())
+        alg = PPO(ac, comm=FakeComm(rank), seed=5)
+        alg.init_storage(32, 4, [615], [1050], [10])
+        a0 = alg.act(o, p).numpy().copy()
+        alg.process_env_step(np.zeros(32, np.float32), np.zeros(32, np.uint8), {})
+        a1 = alg.act(o, p).numpy().copy()
+        if rank == 1:
+            alg.process_env_step(np.zeros(32, np.float32), np.zeros(32, np.uint8), {})
+            alg.load_rng_state(0, 0)                     # rewind: the first draw comes back
+            np.testing.assert_array_equal(alg.act(o, p).numpy(), a0)
+        acts.append((a0, a1))
+        alg.close()
+    assert np.abs(acts[0][0] - acts[1][0]).max() > 0.1                   # rank 0 vs rank 1: different noise
+    assert np.abs(acts[0][0] - acts[0][1]).max() > 0.1                   # successive calls: different noise
+    np.testing.assert_array_equal(acts[0][0], acts[2][0])                # same rank, same seed: same stream
+    np.testing.assert_array_equal(acts[0][1], acts[2][1])
 
 
 def test_non_finite_gradient_skips_the_step(hxlib):
