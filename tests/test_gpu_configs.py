@@ -71,7 +71,7 @@ def test_config1_64_envs_full_iteration_against_oracle(hxlib):
         alg.process_env_step(rew, done, infos)
         ref.process_env_step(r2, d2, orc.time_outs_visible)
     assert stale_fired > 0, "the stale extras['time_outs'] quirk never fired: the test lost its point"
-    assert worst["act"] < 2e-3 and worst["obs"] < 5e-2 and worst["rew"] < 2e-3, worst
+    assert worst["act"] < 1e-4 and worst["obs"] < 5e-3 and worst["rew"] < 1e-4, worst       # measured 8e-6 / 6e-4 / 4e-6
     alg.compute_returns(priv)
     ref.compute_returns(p2)
     np.testing.assert_allclose(alg.buffer(4, (T, n)).numpy(), ref.rewards, rtol=0, atol=3e-3)        # incl. the (stale) time-out bootstrap
