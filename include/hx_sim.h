@@ -201,7 +201,7 @@ int hx_sim_time(hx_sim* s, int which, double* out_h /*[2]*/);
 void* hx_sim_stream(hx_sim* s);
 /* measurement hook: per-phase shader-clock cycles of the env-step kernel, summed over waves and launches; meaningful only in a
  * library built with -DHX_STEP_PROF (tools/step_prof.py), all zeros otherwise.  which = 1 start / clear, 0 read. */
-int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[9]*/);
+int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[15]: 9 phase timers, then shape-visit counts*/);
 int hx_sync(void* hip_stream);
 
 #ifdef __cplusplus

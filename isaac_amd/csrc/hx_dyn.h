@@ -265,9 +265,10 @@ struct ContactBuf {
 // Bounding-sphere test of a shape (`shp`: centre xyz + radius, then the points) on a body with world pose (Rb, pb): can any
 // lane's shape touch at all?  Nothing of it can while its lowest possible point is above the highest ground in reach: 0 on
 // the plane; on terrain the pooled maximum around the sphere's centre (radius <= 0.2 m: one pool entry; wider shapes: the
-// 3 x 3 entries around, reach 0.4 m).  Wave-uniform result.  Runs in the kinematics pass, where the pose is in registers,
-// so that the contact loop only ever visits shapes that may touch.
-HXD bool shape_maybe(const DynParams& P, const float* shp, const M3& Rb, V3 pb) {
+// 3 x 3 entries around, reach 0.4 m).  Returns lowest point minus bound, per lane: negative = may touch.  Runs in the
+// kinematics pass, where the pose is in registers, so that the contact loop only ever visits shapes that may touch; the
+// tests of a pass are evaluated without branches in between, so their LDS latencies overlap with the recursion.
+HXD float shape_gap(const DynParams& P, const float* shp, const M3& Rb, V3 pb) {
   const V3 c = ld3(shp);
   const float zlow = pb.z + dot(row(Rb, 2), c) - shp[3];
   float bound = 0.f;
@@ -281,7 +282,7 @@ HXD bool shape_maybe(const DynParams& P, const float* shp, const M3& Rb, V3 pb) 
         for (int b = hx_imax(j - 1, 0); b <= hx_imin(j + 1, HX_POOL - 1); ++b) bound = fmaxf(bound, P.pool[a * HX_POOL + b]);
     }
   }
-  return hx_any(zlow < bound);
+  return zlow - bound;
 }
 
 // Contact terms of one shape (`shp`: bounding sphere centre xyz + radius, then npts xyz triples; LDS): the body state
@@ -420,7 +421,7 @@ HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, cons
   W.g0.w = mk(0.f, 0.f, 0.f); W.g0.v = P.gz * row(W.R0, 2);
   // ---- pass 1: kinematics down every chain; a body whose collision shape may touch (bounding-sphere test) leaves its
   //      state in the contact buffer and sets its entry's bit
-  uint32_t maybe = 0u;
+  float gap[MI::NENT];
   static_for<M::NCH>([&](auto cc) {
     constexpr int CH = decltype(cc)::value, S0 = M::CH_START[CH], LEN = M::CH_LEN[CH];
     M3 Rc = W.R0; V3 pc = S.pos;
@@ -441,14 +442,16 @@ HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, cons
       if (K == 1) W.v[B].w.y += S.qd[B];
       if (K == 2) W.v[B].w.z += S.qd[B];
       for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
-      if constexpr (MI::slot(B) >= 0) {
-        if (shape_maybe(P, C.shape(B), Rc, pc)) { maybe |= (1u << MI::slot(B)); cb.put_body(MI::slot(B), W.v[B], Rc, pc); }
-      }
+      if constexpr (MI::slot(B) >= 0) { gap[MI::slot(B)] = shape_gap(P, C.shape(B), Rc, pc); cb.put_body(MI::slot(B), W.v[B], Rc, pc); }
     });
   });
-  for (int k = 0; k < M::BASE_NSUB; ++k)
-    if (shape_maybe(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos)) maybe |= (1u << (MI::NSHAPE + k));
-  if (maybe >> MI::NSHAPE) cb.put_body(MI::NSHAPE, W.v0, W.R0, S.pos);
+  for (int k = 0; k < M::BASE_NSUB; ++k) gap[MI::NSHAPE + k] = shape_gap(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos);
+  cb.put_body(MI::NSHAPE, W.v0, W.R0, S.pos);
+  uint32_t maybe = 0u;
+  for (int k = 0; k < MI::NENT; ++k) maybe |= hx_any(gap[k] < 0.f) ? (1u << k) : 0u;
+#if defined(HX_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+  if (P.prof != nullptr && threadIdx.x == 0) { P.prof[9] += __popc(maybe); for (int k = 0; k < MI::NENT && k < 5; ++k) P.prof[10 + k] += (maybe >> k) & 1u; }
+#endif
   HX_T(P.prof, 2);
   // ---- contact phase: one runtime loop over this lane's shapes (its shape bodies, then its share of the base)
   {

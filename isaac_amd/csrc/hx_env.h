@@ -91,6 +91,10 @@ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, ui
 
 struct Rng {
   const float* pack;   // injected [HX_RP_SIZE][N] or nullptr
+  // Device: the eight lanes of a robot share the Philox work of a run of normals -- lane l generates blocks l, l + 8, ... and
+  // parks the values in `share` (LDS, >= 4 * ceil(count / 4) + 4 floats of this robot), every lane reads all of them back.
+  // Host / packs: share == nullptr, nlanes == 1.
+  float* share; int lane, nlanes;
   int n, env;
   uint32_t gid;        // global env id: keys the counter-based generator
   uint32_t k0, k1, step;
@@ -104,16 +108,32 @@ struct Rng {
   // Box-Muller pairs), so a run costs count / 4 calls.
   HXD void nrm_run(int field0, int count, float* out) const {
     if (pack) { for (int k = 0; k < count; ++k) out[k] = pack[(size_t)(field0 + k) * n + env]; return; }
-    for (int b = field0 >> 2; b <= (field0 + count - 1) >> 2; ++b) {
+    const int b0 = field0 >> 2, b1 = (field0 + count - 1) >> 2;
+    auto block = [&](int b, float* z) {
       uint32_t o[4];
       philox4(k0, k1, gid, step, (uint32_t)b, 1u, o);
-      float z[4];
       for (int h = 0; h < 2; ++h) {
         const float u1 = 1.0f - (float)(o[2 * h] >> 8) * (1.0f / 16777216.0f);   // (0,1]
         const float u2 = (float)(o[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
         const float r = sqrtf(-2.0f * logf(u1)), a = 6.283185307179586f * u2;
         z[2 * h] = r * cosf(a); z[2 * h + 1] = r * sinf(a);
       }
+    };
+    if (share != nullptr) {
+      // every lane runs the same few iterations on its own blocks (no divergence), then the values meet in LDS
+      for (int b = b0 + lane; b <= b1; b += nlanes) {
+        float z[4];
+        block(b, z);
+        for (int c = 0; c < 4; ++c) share[4 * (b - b0) + c] = z[c];
+      }
+      hx_lds_fence();
+      for (int k = 0; k < count; ++k) out[k] = share[field0 - 4 * b0 + k];
+      hx_lds_fence();
+      return;
+    }
+    for (int b = b0; b <= b1; ++b) {
+      float z[4];
+      block(b, z);
       for (int c = 0; c < 4; ++c) { const int k = 4 * b + c - field0; if (k >= 0 && k < count) out[k] = z[c]; }
     }
   }

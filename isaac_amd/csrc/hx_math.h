@@ -94,6 +94,15 @@ HXD int hx_atomic_add(int* p, int v) {
   return old;
 #endif
 }
+// order LDS traffic between the lanes of one wave (values written by one lane, read by its neighbours): the wave runs in
+// lockstep, so waiting for the outstanding LDS operations is all it takes -- no workgroup barrier
+HXD void hx_lds_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
 HXD int hx_imin(int a, int b) { return a < b ? a : b; }
 HXD int hx_imax(int a, int b) { return a > b ? a : b; }
 

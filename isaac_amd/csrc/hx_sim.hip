@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   if (e >= n) return;                      // both lanes of a pair leave together
   const bool writer = (side == 0) && (sub == 0);         // env-level results are computed by all eight lanes, stored by one
   SideConst<M> C; C.bind(lds_const, side);
-  Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
+  Rng rng; rng.pack = pack; rng.share = lds_cb + (size_t)MI::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + r * 80; rng.lane = threadIdx.x & 7; rng.nlanes = HX_LANES_PER_ROBOT; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
 #define LD(f) (p.st[(size_t)(f) * n + e])
   // ---- load state: base (both lanes) + this lane's side; only what the physics needs (the glue loads its own state)
   DynStateT<M> S;
@@ -117,7 +117,10 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
       P.inv_hs = p.t_inv_hs; P.wall = p.t_wall;
       P.pool = lds_pool + r * HX_POOL_LD; P.poolw = lds_poolw + r * HX_POOL_LD;
     }
-    ContactBuf cb; cb.base = lds_cb + threadIdx.x; cb.stride = 64;
+    // one buffer column per body side: the four lanes of a side hold the same body states and (after the quad sums) write the
+    // same contact terms, so they share it -- 16 columns per wave instead of 64 keeps the kernel's LDS footprint small enough
+    // for the deferred critic's GEMM workgroups to stay resident beside it
+    ContactBuf cb; cb.base = lds_cb + (threadIdx.x >> 2); cb.stride = 64 / HX_LANES_PER_SIDE;
     float target[NL];
     for (int j = 0; j < NL; ++j) {
       const float aj = side ? R.act[NL + j] : R.act[j];
@@ -177,12 +180,12 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   env_glue<M>(p, cfg, A, n, e, writer, rng, R);
   HX_T(prof, 8);
 #if defined(HX_STEP_PROF)
-  if (prof != nullptr && threadIdx.x == 0) for (int k = 0; k < 9; ++k) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
+  if (prof != nullptr && threadIdx.x == 0) for (int k = 0; k < 15; ++k) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
 #endif
 }
 
 template <class M> static constexpr size_t env_step_lds_bytes() {
-  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + HX_RPW * HX_PATCH_LD + 2 * HX_RPW * HX_POOL_LD + 2 * HX_RPW + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * 64);
+  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + HX_RPW * HX_PATCH_LD + 2 * HX_RPW * HX_POOL_LD + 2 * HX_RPW + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + HX_RPW * 80);
 }
 
 // Frame stacking for BOTH observation streams (hector_env.py:246-254 + clip of legged_robot.py:104-107), one
@@ -609,7 +612,7 @@ extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }
 // measurement hook (tools/step_prof.py; library built with -DHX_STEP_PROF): which = 1 starts / clears, 0 reads the cycle
 // counters summed over all waves and launches since: {window fetch + pooling, action processing, kinematics, contact
 // phase, articulated inertias, exchange + base solve, accelerations + forces + integration, guard + gather, glue}
-extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[9]*/) {
+extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[15]*/) {
   if (!s) { hx_set_error("hx_sim_prof: null sim"); return -2; }
   if (which == 1) {
     if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 16)) return -3; s->p.prof = d; }
@@ -619,6 +622,6 @@ extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[9]*/) {
   }
   if (!s->p.prof || !out_h) { hx_set_error("hx_sim_prof: not started"); return -2; }
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipMemcpy(out_h, s->p.prof, 9 * sizeof(long long), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(out_h, s->p.prof, 15 * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }

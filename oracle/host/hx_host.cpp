@@ -110,7 +110,7 @@ template <class M> static void step_robot(hxh_env* s, const float* actions, cons
   const SLay SL(ND);
   auto LD = [&](int f) { return p.st[(size_t)f * n + e]; };
   SideConst<M> C[2]; C[0].bind(s->tbl.data(), 0); C[1].bind(s->tbl.data(), 1);
-  Rng rng; rng.pack = pack; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset);
+  Rng rng; rng.pack = pack; rng.share = nullptr; rng.lane = 0; rng.nlanes = 1; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset);
   rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
   DynStateT<M> S[2];
   for (int sd = 0; sd < 2; ++sd) {
