@@ -139,8 +139,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--task", default="hector", choices=["hector", "hector_full"],
-                    help="hector is BASELINE.json's metric config; hector_full (18 DoF, SURVEY 8f-4) is a side measurement")
+    ap.add_argument("--task", default="hector", choices=["hector", "hector_full", "humanoid_ppo"],
+                    help="hector is BASELINE.json's metric config; hector_full (18 DoF) and humanoid_ppo (XBot-L, 12 DoF) are the sibling "
+                         "tasks of SURVEY 8f-4, side measurements")
     ap.add_argument("--shards", type=int, default=1, help="env shards per GPU driven round-robin on separate streams (1 = off; measured slower than the deferred-critic overlap, see DESIGN.md)")
     ap.add_argument("--terrain", default="trimesh", choices=["trimesh", "heightfield", "plane"],
                     help="terrain.mesh_type; 'trimesh' is the reference's default for the hector task (hector_config.py:45)")
@@ -167,8 +168,8 @@ def main():
     __graft_entry__.build()
     from isaac_amd import capi
     from isaac_amd.parallel import init_comm
-    from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO, HectorFullCfg, HectorFullCfgPPO
-    from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv, PipelinedHectorEnv, class_to_dict
+    from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO, HectorFullCfg, HectorFullCfgPPO, XBotLCfg, XBotLCfgPPO
+    from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv, PipelinedHectorEnv, XBotLFreeEnv, class_to_dict
     from isaac_amd.algo.on_policy_runner import OnPolicyRunner
     from isaac_amd.utils.helpers import set_seed
 
@@ -186,17 +187,19 @@ def main():
     local = comm.local_rank % ndev       # one rank per GPU under the driver; wraps only in the one-GPU gloo-staged rehearsal
     capi.check(capi.lib().hx_set_device(local), "hx_set_device")
 
-    full = args.task == "hector_full"
+    full = args.task != "hector"              # a sibling task: no cpu_baseline / traffic bookkeeping of the headline config
     if full and args.shards > 1:
         raise SystemExit("--shards applies to the hector task only")
-    env_cfg, train_cfg = (HectorFullCfg(), HectorFullCfgPPO()) if full else (HectorCfg(), HectorCfgPPO())
+    env_cfg, train_cfg = {"hector": (HectorCfg, HectorCfgPPO), "hector_full": (HectorFullCfg, HectorFullCfgPPO),
+                          "humanoid_ppo": (XBotLCfg, XBotLCfgPPO)}[args.task]
+    env_cfg, train_cfg = env_cfg(), train_cfg()
     env_cfg.env.num_envs = args.envs
     env_cfg.terrain.mesh_type = args.terrain
     env_cfg.seed = set_seed(train_cfg.seed + comm.rank)
     if args.shards > 1:
         env = PipelinedHectorEnv(env_cfg, sim_device=f"cuda:{local}", headless=True, num_shards=args.shards)
     else:
-        env = (HectorFullFreeEnv if full else HectorFreeEnv)(env_cfg, sim_device=f"cuda:{local}", headless=True)
+        env = {"hector": HectorFreeEnv, "hector_full": HectorFullFreeEnv, "humanoid_ppo": XBotLFreeEnv}[args.task](env_cfg, sim_device=f"cuda:{local}", headless=True)
     tcfg = class_to_dict(train_cfg)
     if args.dtype != "f32":
         tcfg["algorithm"]["mlp_dtype"] = args.dtype          # extra PPO keyword of this build (hx_ppo_set_compute_dtype)

@@ -36,6 +36,7 @@ extern "C" {
 
 #define HX_NUM_DOF 10          /* hector */
 #define HX_MAX_DOF 18          /* hector_full (legs + arms, hector_w_arm_config.py:17); selected by hx_sim_cfg.num_dof */
+#define HX_XBOT_DOF 12         /* humanoid_ppo (XBot-L, humanoid_config.py:46): frames 47 / 73, privileged rows 3 frames deep */
 #define HX_MAX_OBS_FRAME 65    /* 11 + 3 * 18 (hector_w_arm_config.py:12) */
 #define HX_NUM_BODIES 11
 #define HX_OBS_FRAME 41        /* num_single_obs, hector_config.py:12 */

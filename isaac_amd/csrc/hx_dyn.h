@@ -25,19 +25,21 @@
 
 // ---- the robots of the family: generated tables (tools/compile_urdf.py) + what the task glue needs to know about them
 struct ModelHector : HXM_Hector {
-  static constexpr bool ARMS = false;
+  static constexpr bool ARMS = false, XBOT = false;
   static constexpr int KNEE = 3, FOOT = 4;       // side-local bodies named by asset.knee_name / foot_name (hector_config.py:31-32)
   HXD static const float* side_table() { return HXM_SIDE; }
   HXD static const float* base_table() { return HXM_BASE; }
   static constexpr float MASS0 = HXM_MASS0;
 };
 struct ModelFull : HXM_Full {             // hector with arms (task hector_full): leg bodies 0-4, arm bodies 5-8 per side
+  static constexpr bool ARMS = true, XBOT = false;
   static constexpr int KNEE = 3, FOOT = 4;
   HXD static const float* side_table() { return HXF_SIDE; }
   HXD static const float* base_table() { return HXF_BASE; }
   static constexpr float MASS0 = HXF_MASS0;
 };
 struct ModelXBot : HXM_XBot {             // XBot-L (task humanoid_ppo): roll, yaw, pitch, knee, ankle pitch, ankle roll
+  static constexpr bool ARMS = false, XBOT = true;
   static constexpr int KNEE = 3, FOOT = 5;       // 'knee' / 'ankle_roll' (humanoid_config.py:64-65)
   HXD static const float* side_table() { return HXX_SIDE; }
   HXD static const float* base_table() { return HXX_BASE; }

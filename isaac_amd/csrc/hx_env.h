@@ -170,8 +170,11 @@ HXD V3 euler_xyz_wrapped(const float* q) {
 HXD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 // compile-time sizes of a task's frames and random-pack rows (include/hx_sim.h HX_RP_* are these for 10 DoF)
+// hector / hector_full: privileged frame 40 + 3 ND wide, stacked 15 deep (hector_config.py:10-16).  humanoid_ppo (XBot-L): its
+// own privileged frame of 37 + 3 ND = 73 values, stacked c_frame_stack = 3 deep (humanoid_config.py:40-45)
 template <class M> struct TaskDims {
-  static constexpr int NL = M::NL, ND = 2 * M::NL, OBSF = 11 + 3 * ND, PRIVF = 40 + 3 * ND, PB = 5 + 3 * ND;
+  static constexpr int NL = M::NL, ND = 2 * M::NL, OBSF = 11 + 3 * ND, PRIVF = (M::XBOT ? 37 : 40) + 3 * ND, PB = 5 + 3 * ND;
+  static constexpr int PRIV_STACK = M::XBOT ? 3 : HX_FRAME_STACK;
   static constexpr int RP_DELAY = 0, RP_ACT_NOISE = 1, RP_CMD_A = 1 + ND, RP_PUSH = 4 + ND, RP_RESET_Q = 9 + ND, RP_RESET_XY = 9 + 2 * ND,
                        RP_CMD_B = 11 + 2 * ND, RP_OBS_NOISE = 14 + 2 * ND, RP_LEVEL = 14 + 2 * ND + OBSF;
 };
@@ -223,7 +226,7 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   using MI = ModelInfo<M>;
   constexpr int NL = D::NL, ND = D::ND, OBSF = D::OBSF, PRIVF = D::PRIVF, PB = D::PB;
   constexpr SLay SL(ND);
-  constexpr int SLOT_THIGH = MI::slot(2), SLOT_TOE = MI::slot(M::FOOT);
+  constexpr int SLOT_THIGH = M::XBOT ? -1 : MI::slot(2), SLOT_TOE = MI::slot(M::FOOT);      // XBot-L: no thigh shape; only 'base_link' terminates / is penalised
 #define LD(f) (p.st[(size_t)(f) * n + e])
 #define ST(f, val) (p.st[(size_t)(f) * n + e] = (val))
   float* act = R.act; float* qa = R.qa; float* qda = R.qda; const float* torques = R.torques;
@@ -289,7 +292,9 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   }
 
   // contact forces per body (world): only bodies with collision points can be non-zero
-  const V3 f_base = R.f_base, f_lthigh = R.side_force[0][SLOT_THIGH], f_rthigh = R.side_force[1][SLOT_THIGH];
+  const V3 f_base = R.f_base;
+  V3 f_lthigh = mk(0.f, 0.f, 0.f), f_rthigh = mk(0.f, 0.f, 0.f);
+  if constexpr (SLOT_THIGH >= 0) { f_lthigh = R.side_force[0][SLOT_THIGH]; f_rthigh = R.side_force[1][SLOT_THIGH]; }
   const V3 foot_f[2] = {R.side_force[0][SLOT_TOE], R.side_force[1][SLOT_TOE]};
   const V3 foot_pos[2] = {R.bo[1].pos, R.bo[3].pos}, foot_vel[2] = {R.bo[1].linvel, R.bo[3].linvel};
   const V3 knee_pos[2] = {R.bo[0].pos, R.bo[2].pos};
@@ -414,14 +419,18 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
       add(HX_R_FOOT_SLIP, r);
     }
     if (sc[HX_R_JOINT_POS] != 0.f) {
-      // hector_env.py:264-275 with compute_ref_state :90-111 (reference pose uses the phase of the PREVIOUS
-      // compute_observations call; this term is zero-scaled in HectorCfg)
-      const float phase = (float)(ep_len) * cfg.env_dt / cfg.cycle_time;
+      // hector_env.py:264-275 with compute_ref_state :90-111: ref_dof_pos is what the PREVIOUS compute_observations call left,
+      // i.e. the gait phase of the episode length before this step's increment (0 right after a reset).  Zero-scaled in
+      // HectorCfg, where the pose is far from the reference and the term barely depends on the phase; XBot-L (default pose = 0,
+      // scale 1.6) is what pins it (fixture H).  The one step after the runner overwrites episode_length_buf
+      // (on_policy_runner.py:103-106) reads the new clock here, the reference the stale pose.
+      const float phase = (float)(ep_len - 1) * cfg.env_dt / cfg.cycle_time;
       const float sp = sinf(TWO_PI * phase);
       float ref[ND]; for (int j = 0; j < ND; ++j) ref[j] = 0.f;      // indices 2-4 / 7-9 whatever the DoF count (hector_w_arm_env.py:107-114)
       const float s1 = cfg.target_joint_pos_scale, s2c = 2.f * s1;
       const float l = sp > 0.f ? 0.f : sp, r_ = sp < 0.f ? 0.f : sp;
-      ref[2] = l * s1; ref[3] = l * s2c; ref[4] = l * s1; ref[7] = r_ * s1; ref[8] = r_ * s2c; ref[9] = r_ * s1;
+      constexpr int RR = M::XBOT ? 8 : 7;                              // humanoid_env.py:131-138: 2-4 / 8-10
+      ref[2] = l * s1; ref[3] = l * s2c; ref[4] = l * s1; ref[RR] = r_ * s1; ref[RR + 1] = r_ * s2c; ref[RR + 2] = r_ * s1;
       if (fabsf(sp) < 0.1f) for (int j = 0; j < ND; ++j) ref[j] = 0.f;
       float s2 = 0; for (int j = 0; j < ND; ++j) { const float d = qa[j] - ref[j]; s2 += d * d; }
       const float nn = sqrtf(s2);
@@ -557,15 +566,33 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
       }
     }
     if (writer) for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
-    f[PB + 0] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[PB + 1] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[PB + 2] = base_lin_vel.z * cfg.obs_scale_lin_vel;
-    f[PB + 3] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[PB + 4] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[PB + 5] = base_ang_vel.z * cfg.obs_scale_ang_vel;
-    f[PB + 6] = euler.x * cfg.obs_scale_quat; f[PB + 7] = euler.y * cfg.obs_scale_quat; f[PB + 8] = euler.z * cfg.obs_scale_quat;
-    f[PB + 9] = foot_pos[0].x; f[PB + 10] = foot_pos[0].y; f[PB + 11] = foot_pos[0].z; f[PB + 12] = foot_pos[1].x; f[PB + 13] = foot_pos[1].y; f[PB + 14] = foot_pos[1].z;
-    f[PB + 15] = foot_vel[0].x; f[PB + 16] = foot_vel[0].y; f[PB + 17] = foot_vel[0].z; f[PB + 18] = foot_vel[1].x; f[PB + 19] = foot_vel[1].y; f[PB + 20] = foot_vel[1].z;
-    f[PB + 21] = R.pos.x; f[PB + 22] = R.pos.y; f[PB + 23] = R.pos.z;
-    f[PB + 24] = push_f[0]; f[PB + 25] = push_f[1]; f[PB + 26] = push_t[0]; f[PB + 27] = push_t[1]; f[PB + 28] = push_t[2];
-    f[PB + 29] = R.friction; f[PB + 30] = R.base_mass / 30.f;
-    f[PB + 31] = sm[0]; f[PB + 32] = sm[1]; f[PB + 33] = contact[0] ? 1.f : 0.f; f[PB + 34] = contact[1] ? 1.f : 0.f;
+    if constexpr (M::XBOT) {
+      // humanoid_env.py:218-236: [cmd 5, q, dq, a, q - ref_dof_pos, lin vel 3, ang vel 3, euler 3, push 2 + 3, friction, mass / 30,
+      // stance 2, contact 2]; ref_dof_pos of THIS call (compute_ref_state :121-143 runs first)
+      float ref[ND]; for (int j = 0; j < ND; ++j) ref[j] = 0.f;
+      const float s1 = cfg.target_joint_pos_scale, s2c = 2.f * s1;
+      const float l = sp > 0.f ? 0.f : sp, r_ = sp < 0.f ? 0.f : sp;
+      ref[2] = l * s1; ref[3] = l * s2c; ref[4] = l * s1; ref[8] = r_ * s1; ref[9] = r_ * s2c; ref[10] = r_ * s1;
+      if (fabsf(sp) < 0.1f) for (int j = 0; j < ND; ++j) ref[j] = 0.f;
+      for (int j = 0; j < ND; ++j) f[PB + j] = qa[j] - ref[j];
+      constexpr int Q = PB + ND;
+      f[Q + 0] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[Q + 1] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[Q + 2] = base_lin_vel.z * cfg.obs_scale_lin_vel;
+      f[Q + 3] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[Q + 4] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[Q + 5] = base_ang_vel.z * cfg.obs_scale_ang_vel;
+      f[Q + 6] = euler.x * cfg.obs_scale_quat; f[Q + 7] = euler.y * cfg.obs_scale_quat; f[Q + 8] = euler.z * cfg.obs_scale_quat;
+      f[Q + 9] = push_f[0]; f[Q + 10] = push_f[1]; f[Q + 11] = push_t[0]; f[Q + 12] = push_t[1]; f[Q + 13] = push_t[2];
+      f[Q + 14] = R.friction; f[Q + 15] = R.base_mass / 30.f;
+      f[Q + 16] = sm[0]; f[Q + 17] = sm[1]; f[Q + 18] = contact[0] ? 1.f : 0.f; f[Q + 19] = contact[1] ? 1.f : 0.f;
+    } else {
+      f[PB + 0] = base_lin_vel.x * cfg.obs_scale_lin_vel; f[PB + 1] = base_lin_vel.y * cfg.obs_scale_lin_vel; f[PB + 2] = base_lin_vel.z * cfg.obs_scale_lin_vel;
+      f[PB + 3] = base_ang_vel.x * cfg.obs_scale_ang_vel; f[PB + 4] = base_ang_vel.y * cfg.obs_scale_ang_vel; f[PB + 5] = base_ang_vel.z * cfg.obs_scale_ang_vel;
+      f[PB + 6] = euler.x * cfg.obs_scale_quat; f[PB + 7] = euler.y * cfg.obs_scale_quat; f[PB + 8] = euler.z * cfg.obs_scale_quat;
+      f[PB + 9] = foot_pos[0].x; f[PB + 10] = foot_pos[0].y; f[PB + 11] = foot_pos[0].z; f[PB + 12] = foot_pos[1].x; f[PB + 13] = foot_pos[1].y; f[PB + 14] = foot_pos[1].z;
+      f[PB + 15] = foot_vel[0].x; f[PB + 16] = foot_vel[0].y; f[PB + 17] = foot_vel[0].z; f[PB + 18] = foot_vel[1].x; f[PB + 19] = foot_vel[1].y; f[PB + 20] = foot_vel[1].z;
+      f[PB + 21] = R.pos.x; f[PB + 22] = R.pos.y; f[PB + 23] = R.pos.z;
+      f[PB + 24] = push_f[0]; f[PB + 25] = push_f[1]; f[PB + 26] = push_t[0]; f[PB + 27] = push_t[1]; f[PB + 28] = push_t[2];
+      f[PB + 29] = R.friction; f[PB + 30] = R.base_mass / 30.f;
+      f[PB + 31] = sm[0]; f[PB + 32] = sm[1]; f[PB + 33] = contact[0] ? 1.f : 0.f; f[PB + 34] = contact[1] ? 1.f : 0.f;
+    }
     if (writer) for (int k = 0; k < PRIVF; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
   }
 

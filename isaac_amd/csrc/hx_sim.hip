@@ -201,7 +201,8 @@ struct StackArgs {
   float* stat_sum; float* stat_last; float* stat_acc; int* stat_steps;
   const float* rew; float* rew_out; unsigned char* done_out; unsigned char* timeout_out;
   int n; float clip;
-  int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, or 65 / 94 with arms) and row strides
+  int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, 65 / 94 with arms, 47 / 73 for XBot-L) and row strides
+  int priv_stack;                          // frames in a privileged row: 15, or c_frame_stack = 3 for XBot-L
 };
 __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
   const int e = blockIdx.x;
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
     }
   }
   {
-    const int F = a.priv_f, ld = a.priv_ld, keep = (HX_FRAME_STACK - 1) * F;
+    const int F = a.priv_f, ld = a.priv_ld, keep = (a.priv_stack - 1) * F;
     const float* s = a.priv_src + (size_t)e * ld;
     float* d = a.priv_dst + (size_t)e * ld;
     for (int k = threadIdx.x; k < ld; k += blockDim.x) {
@@ -260,7 +261,7 @@ extern "C" int hx_sync(void* stream) { HX_CHECK(hipStreamSynchronize((hipStream_
 
 struct hx_sim {
   int nd;                          // DoF count of the robot: 10 (hector) or 18 (hector with arms)
-  int obs_f, priv_f, obs_ld, priv_ld;
+  int obs_f, priv_f, obs_ld, priv_ld, priv_stack;
   SLay L{10};                      // state layout for nd
   hx_sim_cfg cfg;
   hx_sim_cfg* cfg_d;
@@ -306,10 +307,11 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
                            const float* start_pos_h, uint64_t seed, void* stream, hx_sim* s) {
   s->cfg = *cfg;
   s->nd = cfg->num_dof ? cfg->num_dof : HX_NUM_DOF;
-  if (s->nd != HX_NUM_DOF && s->nd != HX_MAX_DOF) { hx_set_error("hx_sim_create: num_dof must be 10 (hector) or 18 (hector_full)"); return -2; }
+  if (s->nd != HX_NUM_DOF && s->nd != HX_MAX_DOF && s->nd != HX_XBOT_DOF) { hx_set_error("hx_sim_create: num_dof must be 10 (hector), 18 (hector_full) or 12 (humanoid_ppo)"); return -2; }
   s->L = SLay(s->nd);
-  s->obs_f = 11 + 3 * s->nd; s->priv_f = 40 + 3 * s->nd;
-  s->obs_ld = (HX_FRAME_STACK * s->obs_f + 3) / 4 * 4; s->priv_ld = (HX_FRAME_STACK * s->priv_f + 3) / 4 * 4;
+  s->obs_f = 11 + 3 * s->nd; s->priv_f = (s->nd == HX_XBOT_DOF ? 37 : 40) + 3 * s->nd;
+  s->priv_stack = (s->nd == HX_XBOT_DOF) ? 3 : HX_FRAME_STACK;
+  s->obs_ld = (HX_FRAME_STACK * s->obs_f + 3) / 4 * 4; s->priv_ld = (s->priv_stack * s->priv_f + 3) / 4 * 4;
   s->seed = seed;
   s->step_counter = 0;
   s->rng_step = 0;
@@ -361,12 +363,13 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
     st[(size_t)SL_.LAST_FEET_Z * n + e] = 0.05f;
     st[(size_t)(SL_.LAST_FEET_Z + 1) * n + e] = 0.05f;
     st[(size_t)SL_.FRICTION * n + e] = friction_h ? friction_h[e] : 1.f;
-    st[(size_t)SL_.BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : (s->nd == HX_NUM_DOF ? HXM_MASS0 : HXF_MASS0);
+    st[(size_t)SL_.BASE_MASS * n + e] = base_mass_h ? base_mass_h[e] : (s->nd == HX_NUM_DOF ? HXM_MASS0 : s->nd == HX_XBOT_DOF ? HXX_MASS0 : HXF_MASS0);
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
   // the env-step kernel keeps the height windows and the per-lane contact buffer in LDS: more than the 64 KB default
   HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelHector>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelHector>()));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelFull>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelFull>()));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelXBot>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelXBot>()));
   if (dalloc(s, &s->cfg_d, 1)) return -3;
   HX_CHECK(hipMemcpy(s->cfg_d, &s->cfg, sizeof(hx_sim_cfg), hipMemcpyHostToDevice));
   return 0;
@@ -456,7 +459,8 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
     timed = s->ev_used + 2 <= s->ev.size();
   }
   if (timed) (void)hipEventRecord(s->ev[s->ev_used], s->stream);
-  if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (s->nd == HX_XBOT_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelXBot>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelXBot>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], s->stream); s->ev_used += 2; }
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
@@ -471,7 +475,7 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   k.stat_sum = s->p.stat_sum; k.stat_last = s->p.stat_last; k.stat_acc = s->p.stat_acc; k.stat_steps = s->p.stat_steps;
   k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
   k.n = n; k.clip = s->cfg.clip_observations;
-  k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld;
+  k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld; k.priv_stack = s->priv_stack;
   hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
   s->obs_cur = od; s->priv_cur = pd;
   s->parity ^= 1;

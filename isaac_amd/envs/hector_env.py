@@ -62,8 +62,11 @@ def creation_randomisation(cfg, num_envs, env_origins, base_mass=BASE_MASS):
 
 
 class HectorFreeEnv(VecEnv):
-    # what a sibling task of the family overrides (HectorFullFreeEnv below)
+    # what a sibling task of the family overrides (HectorFullFreeEnv, XBotLFreeEnv below)
     DOF_NAMES, BODY_NAMES, URDF_EFFORT, BASE_MASS = DOF_NAMES, BODY_NAMES, URDF_EFFORT, BASE_MASS
+    PRIV_BASE, PRIV_STACK = 40, 15          # privileged frame = PRIV_BASE + 3 * num_dof values, PRIV_STACK frames per row
+    # side-local body indices the kernel's model descriptor names (asset.knee_name / foot_name; checked against the config)
+    KNEE_LOCAL, FOOT_LOCAL = 4, 5
 
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True, stream=None,
                  creation=None, init_pack=None, env_range=None):
@@ -111,10 +114,10 @@ class HectorFreeEnv(VecEnv):
         self.num_dof = self.num_dofs = nd
         self.num_bodies = len(BODY_NAMES)
         self.dof_names, self.body_names = DOF_NAMES, BODY_NAMES
-        self.obs_frame, self.priv_frame = 11 + 3 * nd, 40 + 3 * nd                     # 41 / 70, with arms 65 / 94
-        self.obs_ld, self.priv_ld = -(-15 * self.obs_frame // 4) * 4, -(-15 * self.priv_frame // 4) * 4
-        if (self.num_obs, self.num_privileged_obs, self.num_actions) != (15 * self.obs_frame, 15 * self.priv_frame, nd):
-            raise ValueError(f"{type(self).__name__} serves the {15 * self.obs_frame} / {15 * self.priv_frame} / {nd} layout only")
+        self.obs_frame, self.priv_frame = 11 + 3 * nd, self.PRIV_BASE + 3 * nd         # 41 / 70, with arms 65 / 94, XBot-L 47 / 73
+        self.obs_ld, self.priv_ld = -(-15 * self.obs_frame // 4) * 4, -(-self.PRIV_STACK * self.priv_frame // 4) * 4
+        if (self.num_obs, self.num_privileged_obs, self.num_actions) != (15 * self.obs_frame, self.PRIV_STACK * self.priv_frame, nd):
+            raise ValueError(f"{type(self).__name__} serves the {15 * self.obs_frame} / {self.PRIV_STACK * self.priv_frame} / {nd} layout only")
         self.feet_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.foot_name in n]
         self.knee_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.knee_name in n]
         self.termination_contact_indices = [i for k in cfg.asset.terminate_after_contacts_on
@@ -122,9 +125,9 @@ class HectorFreeEnv(VecEnv):
         self.penalised_contact_indices = [i for k in cfg.asset.penalize_contacts_on
                                           for i, n in enumerate(BODY_NAMES) if k in n]
         nl = nd // 2
-        assert self.feet_indices == [5, nl + 5] and self.knee_indices == [4, nl + 4]
-        assert sorted(self.penalised_contact_indices) == [0, 3, nl + 3]
-        assert sorted(self.termination_contact_indices) == ([0, 3, 8] if nd == 10 else [0, 3, 6, 7, 8, 12, 15, 16, 17])
+        assert self.feet_indices == [self.FOOT_LOCAL, nl + self.FOOT_LOCAL] and self.knee_indices == [self.KNEE_LOCAL, nl + self.KNEE_LOCAL]
+        assert sorted(self.penalised_contact_indices) == self._expected_penalised(nl)
+        assert sorted(self.termination_contact_indices) == self._expected_termination(nd)
 
         # ---- create_sim (hector_env.py:114-133): terrain first, then the robots
         n = self.total_envs
@@ -260,6 +263,14 @@ class HectorFreeEnv(VecEnv):
         self._keep = []
         # constructor tail: reset_idx(all) + compute_observations (hector_env.py:50-51)
         self._reset_all(init_pack)
+
+    @staticmethod
+    def _expected_penalised(nl):
+        return [0, 3, nl + 3]                     # 'base', 'thigh' (hector_config.py:35)
+
+    @staticmethod
+    def _expected_termination(nd):
+        return [0, 3, 8] if nd == 10 else [0, 3, 6, 7, 8, 12, 15, 16, 17]
 
     def _noise_scale_vec(self, ns, os_):
         """hector_env.py:135-155 (the last slice is [38:42] on a 41-vector there)"""
@@ -561,4 +572,34 @@ class HectorFullFreeEnv(HectorFreeEnv):
         v[41:59] = 0.0
         v[58:61] = ns.ang_vel * os_.ang_vel
         v[61:65] = ns.quat * os_.quat
+        return v
+
+
+class XBotLFreeEnv(HectorFreeEnv):
+    """Task `humanoid_ppo` (reference humanoid/envs/custom/humanoid_env.py XBotLFreeEnv + humanoid_config.py XBotLCfg): the
+    12-DoF XBot-L humanoid, whose joints turn about the z axes of rotated joint frames.  Same kernel source, instantiated with
+    the XBot model descriptor (hx_sim_cfg.num_dof = 12): observation frame 47 wide x 15, its own privileged frame of 73 values
+    x c_frame_stack = 3, gait reference on joints 2-4 / 8-10, only base_link terminates an episode."""
+    DOF_NAMES = [f"{s}_{j}_joint" for s in ("left", "right") for j in ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll")]
+    BODY_NAMES = ["base_link"] + [f"{s}_{j}_link" for s in ("left", "right") for j in ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll")]
+    URDF_EFFORT = [100.0, 100.0, 250.0, 250.0, 100.0, 100.0] * 2          # XBot-L.urdf <limit effort=...>
+    BASE_MASS = 29.900618661923257                                       # collapsed base link (tools/compile_urdf.py --xbot)
+    PRIV_BASE, PRIV_STACK = 37, 3
+    KNEE_LOCAL, FOOT_LOCAL = 4, 6
+
+    @staticmethod
+    def _expected_penalised(nl):
+        return [0]                                # 'base_link' (humanoid_config.py:67-68)
+
+    @staticmethod
+    def _expected_termination(nd):
+        return [0]
+
+    def _noise_scale_vec(self, ns, os_):
+        """humanoid_env.py:179-186"""
+        v = np.zeros(self.obs_frame, np.float32)
+        v[5:17] = ns.dof_pos * os_.dof_pos
+        v[17:29] = ns.dof_vel * os_.dof_vel
+        v[41:44] = ns.ang_vel * os_.ang_vel
+        v[44:47] = ns.quat * os_.quat
         return v

@@ -64,11 +64,17 @@ class Task:
     """What distinguishes one task of the hector family from another in the env glue (everything else is shared code)."""
 
     def __init__(self, name, model_json, default_q, kp, kd, torque_limit, feet, knees, term, penal, noise_vec, reward_scale,
-                 opts, max_contact_force, min_dist, djp_pairs, djp_arm_pairs=()):
+                 opts, max_contact_force, min_dist, djp_pairs, djp_arm_pairs=(), priv_base=40, priv_stack=15, ref_right=7,
+                 base_init_z=0.55, base_height_target=0.55, clip=100.0, xbot_priv=False):
         self.name, self.model_json = name, model_json
         self.default_q, self.kp, self.kd, self.torque_limit = (np.asarray(x, F) for x in (default_q, kp, kd, torque_limit))
         self.ndof = len(self.default_q)
-        self.nobs, self.npriv = 11 + 3 * self.ndof, 40 + 3 * self.ndof      # 41 / 70 for 10 DoF, 65 / 94 for 18
+        self.nobs, self.npriv = 11 + 3 * self.ndof, priv_base + 3 * self.ndof   # 41 / 70 for 10 DoF, 65 / 94 for 18, 47 / 73 XBot-L
+        # frames per privileged row (c_frame_stack); first right-leg joint of the gait reference (7: hector_env.py:105-107 and
+        # hector_w_arm_env.py:107-114; 8: humanoid_env.py:136-138); init_state.pos z; rewards.base_height_target; normalization clips;
+        # whether the privileged frame is humanoid_env.py:218-236's (no foot / root positions, with q - ref_dof_pos)
+        self.priv_stack, self.ref_right, self.base_init_z, self.base_height_target = priv_stack, ref_right, base_init_z, base_height_target
+        self.clip, self.xbot_priv = clip, xbot_priv
         self.feet, self.knees, self.term, self.penal = feet, knees, term, penal
         self.noise_vec = np.asarray(noise_vec, F)
         self.reward_scale, self.opts = dict(reward_scale), dict(opts)
@@ -113,6 +119,34 @@ def _hector_full():
 
 
 HECTOR_FULL = _hector_full()
+
+
+def _humanoid():
+    """XBot-L (reference humanoid_config.py XBotLCfg / humanoid_env.py XBotLFreeEnv; task humanoid_ppo)."""
+    names = ["leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll"]
+    kp = [{"leg_roll": 200.0, "leg_yaw": 200.0, "leg_pitch": 350.0, "knee": 350.0, "ankle": 15.0}[k] for k in
+          ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle", "ankle")]                                   # :99-102, substring match
+    eff = np.array([b["effort"] for b in P.load_model(P.MODEL_XBOT_JSON)["bodies"][1:]], F)
+    nv = np.zeros(47, F)                                     # humanoid_env.py:179-186
+    nv[5:17] = 0.05 * 1.0
+    nv[17:29] = 0.5 * 0.05
+    nv[41:44] = 0.1 * 1.0
+    nv[44:47] = 0.03 * 1.0
+    scale = dict(joint_pos=1.6, feet_clearance=1.0, feet_contact_number=1.2, feet_air_time=1.0, foot_slip=-0.05, feet_distance=0.2,
+                 knee_distance=0.2, feet_contact_forces=-0.01, tracking_lin_vel=1.2, tracking_ang_vel=1.1, vel_mismatch_exp=0.5,
+                 low_speed=0.2, track_vel_hard=0.5, default_joint_pos=0.5, orientation=1.0, base_height=0.2, base_acc=0.2,
+                 action_smoothness=-0.002, torques=-1e-5, dof_vel=-5e-4, dof_acc=-1e-7, collision=-1.0)           # :188-218
+    opts = dict(_OPTS)
+    opts["cmd_ranges"] = dict(_OPTS["cmd_ranges"], lin_vel_x=(-0.3, 0.6))                                      # :173
+    opts.update(max_push_vel_xy=0.2, action_delay=0.5)                                                         # :155-159
+    assert len(names) == 6
+    return Task("humanoid_ppo", P.MODEL_XBOT_JSON, [0.0] * 12, kp * 2, [10.0] * 12, eff * F(0.85), feet=[6, 12], knees=[4, 10],
+                term=[0], penal=[0], noise_vec=nv, reward_scale=scale, opts=opts, max_contact_force=700.0, min_dist=0.2,
+                djp_pairs=((0, 2), (6, 8)), priv_base=37, priv_stack=3, ref_right=8, base_init_z=0.95, base_height_target=0.89,
+                clip=18.0, xbot_priv=True)
+
+
+HUMANOID = _humanoid()
 
 
 def quat_rotate_inverse(q, v):
@@ -222,7 +256,7 @@ class HectorEnvOracle:
         self.rew_buf = z(n)
         self.torques = z(n, T.ndof)
         self.obs_hist = z(15, n, T.nobs)       # oldest .. newest
-        self.priv_hist = z(15, n, T.npriv)
+        self.priv_hist = z(T.priv_stack, n, T.npriv)
         self.extras_episode = {}
         # tensors the glue reads from the simulator
         self._refresh(full=True)
@@ -269,12 +303,12 @@ class HectorEnvOracle:
 
     # ---- step (hector_env.py:158-169 -> legged_robot.py:84-108)
     def step(self, actions, pack):
-        a = np.clip(np.asarray(actions, F), -100, 100)
         RP, T = self.task.rp, self.task
+        a = np.clip(np.asarray(actions, F), -F(T.clip), F(T.clip))
         delay = pack[RP["delay"]][:, None] * F(self.opts["action_delay"])
         a = (F(1) - delay) * a + delay * self.actions
         a = a + F(self.opts["action_noise"]) * pack[RP["act_noise"]:RP["act_noise"] + T.ndof].T * a
-        self.actions = np.clip(a, -100, 100).astype(F)
+        self.actions = np.clip(a, -F(T.clip), F(T.clip)).astype(F)
         target = (self.actions * F(0.25) + self.task.default_q).astype(F)
         for _ in range(10):
             self.phys.substep(self.state, target.astype(np.float64), T.kp.astype(np.float64),
@@ -283,8 +317,8 @@ class HectorEnvOracle:
         self.torques = self.phys.tau.astype(F)
         self._refresh(full=True)
         self.post_physics_step(pack)
-        obs = np.clip(self.obs_buf, -100, 100)
-        priv = np.clip(self.priv_buf, -100, 100)
+        obs = np.clip(self.obs_buf, -F(T.clip), F(T.clip))
+        priv = np.clip(self.priv_buf, -F(T.clip), F(T.clip))
         return obs, priv, self.rew_buf.copy(), self.reset_buf.copy()
 
     def post_physics_step(self, pack):
@@ -366,7 +400,7 @@ class HectorEnvOracle:
         self.dof_pos[ids] = self.task.default_q + unif(-0.15, 0.15, pack[o:o + self.task.ndof].T[ids])
         self.dof_vel[ids] = 0
         self._push_dofs(ids)
-        base_init = np.array([0, 0, 0.55, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], F)
+        base_init = np.array([0, 0, self.task.base_init_z, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], F)
         self.root[ids] = base_init
         self.root[ids, :3] += self.env_origins[ids]
         if self.custom_origins:
@@ -419,7 +453,7 @@ class HectorEnvOracle:
         sm = self._stance_mask()
         mh = np.sum(self.rigid_state[:, self.task.feet, 2] * sm, 1) / np.sum(sm, 1)
         bh = self.root[:, 2] - (mh - F(0.05))
-        return np.exp(-np.abs(bh - F(0.55)) * F(100))
+        return np.exp(-np.abs(bh - F(self.task.base_height_target)) * F(100))
 
     def _reward_collision(self):
         fn = np.sqrt(np.sum(self.contact_forces[:, self.task.penal] ** 2, -1))
@@ -549,7 +583,8 @@ class HectorEnvOracle:
         ref = np.zeros((self.n, self.task.ndof), F)
         s1 = F(0.17)                                        # rewards.target_joint_pos_scale (hector_config.py:151)
         ref[:, 2], ref[:, 3], ref[:, 4] = sl * s1, sl * (2 * s1), sl * s1
-        ref[:, 7], ref[:, 8], ref[:, 9] = sr * s1, sr * (2 * s1), sr * s1
+        rr = self.task.ref_right
+        ref[:, rr], ref[:, rr + 1], ref[:, rr + 2] = sr * s1, sr * (2 * s1), sr * s1
         ref[np.abs(sp) < 0.1] = 0
         self.ref_dof_pos = ref
         sin_pos = np.sin(F(2 * np.pi) * ph).astype(F)[:, None]
@@ -559,11 +594,16 @@ class HectorEnvOracle:
         cmd = np.concatenate([sin_pos, cos_pos, self.commands[:, :3] * np.array([2, 2, 1], F)], 1)
         qd = (self.dof_pos - self.task.default_q).astype(F)
         dq = self.dof_vel * F(0.05)
-        priv = np.concatenate([cmd, qd, dq, self.actions, self.base_lin_vel * F(2), self.base_ang_vel,
-                               self.base_euler, self.rigid_state[:, self.task.feet, :3].reshape(self.n, 6),
-                               self.rigid_state[:, self.task.feet, 7:10].reshape(self.n, 6), self.root[:, :3],
-                               self.rand_push_force[:, :2], self.rand_push_torque, self.env_frictions,
-                               self.body_mass / F(30.0), sm, cm], 1).astype(F)
+        if self.task.xbot_priv:                              # humanoid_env.py:218-236
+            priv = np.concatenate([cmd, qd, dq, self.actions, (self.dof_pos - ref).astype(F), self.base_lin_vel * F(2), self.base_ang_vel,
+                                   self.base_euler, self.rand_push_force[:, :2], self.rand_push_torque, self.env_frictions,
+                                   self.body_mass / F(30.0), sm, cm], 1).astype(F)
+        else:
+            priv = np.concatenate([cmd, qd, dq, self.actions, self.base_lin_vel * F(2), self.base_ang_vel,
+                                   self.base_euler, self.rigid_state[:, self.task.feet, :3].reshape(self.n, 6),
+                                   self.rigid_state[:, self.task.feet, 7:10].reshape(self.n, 6), self.root[:, :3],
+                                   self.rand_push_force[:, :2], self.rand_push_torque, self.env_frictions,
+                                   self.body_mass / F(30.0), sm, cm], 1).astype(F)
         obs = np.concatenate([cmd, qd, dq, self.actions, self.base_ang_vel, self.base_euler], 1).astype(F)
         if self.add_noise:
             o = self.task.rp["obs_noise"]
@@ -571,4 +611,4 @@ class HectorEnvOracle:
         self.obs_hist = np.concatenate([self.obs_hist[1:], obs[None]], 0)
         self.priv_hist = np.concatenate([self.priv_hist[1:], priv[None]], 0)
         self.obs_buf = self.obs_hist.transpose(1, 0, 2).reshape(self.n, 15 * self.task.nobs)
-        self.priv_buf = self.priv_hist.transpose(1, 0, 2).reshape(self.n, 15 * self.task.npriv)
+        self.priv_buf = self.priv_hist.transpose(1, 0, 2).reshape(self.n, self.task.priv_stack * self.task.npriv)

@@ -62,18 +62,18 @@ class HostEnv:
     product's own host-side derivation of the flat config (HectorFreeEnv._derive: no library call), so both see the
     same numbers."""
 
-    def __init__(self, cfg, creation=None, init_pack=None, full=False, asan=False):
+    def __init__(self, cfg, creation=None, init_pack=None, full=False, asan=False, task=None):
         from isaac_amd import capi
-        from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv
-        cls = HectorFullFreeEnv if full else HectorFreeEnv
+        from isaac_amd.envs.hector_env import HectorFreeEnv, HectorFullFreeEnv, XBotLFreeEnv
+        cls = {"hector": HectorFreeEnv, "hector_full": HectorFullFreeEnv, "humanoid_ppo": XBotLFreeEnv}[task or ("hector_full" if full else "hector")]
         self.host = cls.__new__(cls)
         self.host.cfg = cfg
         c, friction, mass, start, terrain_grid, rough = self.host._derive(cfg, None, creation, None)
         self.ccfg = c
         self.L = lib(asan)
         self.n, self.nd = c.num_envs, c.num_dof
-        self.obs_f, self.priv_f = 11 + 3 * self.nd, 40 + 3 * self.nd
-        self.obs_ld, self.priv_ld = -(-15 * self.obs_f // 4) * 4, -(-15 * self.priv_f // 4) * 4
+        self.obs_f, self.priv_f, self.priv_stack = 11 + 3 * self.nd, cls.PRIV_BASE + 3 * self.nd, cls.PRIV_STACK
+        self.obs_ld, self.priv_ld = -(-15 * self.obs_f // 4) * 4, -(-self.priv_stack * self.priv_f // 4) * 4
         seed = (int(getattr(cfg, "seed", 0)) & 0xFFFFFFFF) | (0x5EED << 32)
         f32 = lambda a: np.ascontiguousarray(a, np.float32)
         self._keep = [f32(friction), f32(mass), f32(self.host.env_origins), f32(start)]
@@ -99,7 +99,7 @@ class HostEnv:
 
     @property
     def privileged_obs_buf(self):
-        return self._view(self.capi.BUF_PRIV, (self.n, self.priv_ld))[:, :15 * self.priv_f].copy()
+        return self._view(self.capi.BUF_PRIV, (self.n, self.priv_ld))[:, :self.priv_stack * self.priv_f].copy()
 
     def step(self, actions, pack=None):
         a = np.ascontiguousarray(actions, np.float32)

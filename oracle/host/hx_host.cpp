@@ -18,7 +18,7 @@ struct hxh_env {
   hx_sim_cfg cfg;
   SimPtrs p;
   SLay L{10};
-  int obs_f, priv_f, obs_ld, priv_ld;
+  int obs_f, priv_f, obs_ld, priv_ld, priv_stack;
   std::vector<float> tbl;                 // what the kernel stages in LDS: side tables, base table, PD constants
   std::vector<float> obs[2], priv[2];
   int cur;
@@ -45,10 +45,11 @@ extern "C" hxh_env* hxh_create(const hx_sim_cfg* cfg, const float* friction, con
   hxh_env* s = new hxh_env();
   s->cfg = *cfg;
   s->nd = cfg->num_dof ? cfg->num_dof : HX_NUM_DOF;
-  if (s->nd != 10 && s->nd != 18) { delete s; return nullptr; }
+  if (s->nd != 10 && s->nd != 18 && s->nd != 12) { delete s; return nullptr; }
   s->L = SLay(s->nd);
-  s->obs_f = 11 + 3 * s->nd; s->priv_f = 40 + 3 * s->nd;
-  s->obs_ld = (HX_FRAME_STACK * s->obs_f + 3) / 4 * 4; s->priv_ld = (HX_FRAME_STACK * s->priv_f + 3) / 4 * 4;
+  s->obs_f = 11 + 3 * s->nd; s->priv_f = (s->nd == 12 ? 37 : 40) + 3 * s->nd;
+  s->priv_stack = s->nd == 12 ? 3 : HX_FRAME_STACK;
+  s->obs_ld = (HX_FRAME_STACK * s->obs_f + 3) / 4 * 4; s->priv_ld = (s->priv_stack * s->priv_f + 3) / 4 * 4;
   s->seed = seed; s->step_counter = 0; s->rng_step = 0; s->cur = 0;
   const size_t n = cfg->num_envs;
   SimPtrs& p = s->p;
@@ -79,9 +80,9 @@ extern "C" hxh_env* hxh_create(const hx_sim_cfg* cfg, const float* friction, con
     p.st[(size_t)SL_.LAST_FEET_Z * n + e] = 0.05f;
     p.st[(size_t)(SL_.LAST_FEET_Z + 1) * n + e] = 0.05f;
     p.st[(size_t)SL_.FRICTION * n + e] = friction ? friction[e] : 1.f;
-    p.st[(size_t)SL_.BASE_MASS * n + e] = base_mass ? base_mass[e] : (s->nd == 10 ? ModelHector::MASS0 : ModelFull::MASS0);
+    p.st[(size_t)SL_.BASE_MASS * n + e] = base_mass ? base_mass[e] : (s->nd == 10 ? ModelHector::MASS0 : s->nd == 12 ? ModelXBot::MASS0 : ModelFull::MASS0);
   }
-  if (s->nd == 10) stage<ModelHector>(s); else stage<ModelFull>(s);
+  if (s->nd == 10) stage<ModelHector>(s); else if (s->nd == 12) stage<ModelXBot>(s); else stage<ModelFull>(s);
   return s;
 }
 
@@ -182,7 +183,7 @@ static void stack_frames(hxh_env* s) {
   for (int e = 0; e < n; ++e) {
     const bool rst = s->p.reset[e] != 0;
     for (int stream = 0; stream < 2; ++stream) {
-      const int F = stream ? s->priv_f : s->obs_f, ld = stream ? s->priv_ld : s->obs_ld, keep = (HX_FRAME_STACK - 1) * F;
+      const int F = stream ? s->priv_f : s->obs_f, ld = stream ? s->priv_ld : s->obs_ld, keep = ((stream ? s->priv_stack : HX_FRAME_STACK) - 1) * F;
       const float* src = (stream ? sp.data() : so.data()) + (size_t)e * ld;
       float* dst = (stream ? dpr.data() : dob.data()) + (size_t)e * ld;
       const float* fr = stream ? s->p.priv_frame : s->p.obs_frame;
@@ -215,6 +216,7 @@ static void run_step(hxh_env* s, const float* actions, const float* pack, int mo
 #pragma omp parallel for schedule(dynamic, 16)
   for (int e = 0; e < n; ++e) {
     if (s->nd == 10) step_robot<ModelHector>(s, actions, pack, A, e);
+    else if (s->nd == 12) step_robot<ModelXBot>(s, actions, pack, A, e);
     else step_robot<ModelFull>(s, actions, pack, A, e);
   }
   stack_frames(s);

@@ -39,12 +39,13 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
     env_mod, cfg_mod, helpers = loader.load_env(task)
     from isaacgym import gymapi, torch_utils
     import isaacgym.torch_utils  # noqa: F401
-    from oracle.env import HECTOR, HECTOR_FULL
-    T = HECTOR_FULL if task == "hector_full" else HECTOR
+    from oracle.env import HECTOR, HECTOR_FULL, HUMANOID
+    T = {"hector": HECTOR, "hector_full": HECTOR_FULL, "humanoid_ppo": HUMANOID}[task]
     RP, RP_SIZE, ND, NOBS, NPRIV = T.rp, T.rp_size, T.ndof, T.nobs, T.npriv
-    env_cls = env_mod.HectorFullFreeEnv if task == "hector_full" else env_mod.HectorFreeEnv
+    env_cls = {"hector": "HectorFreeEnv", "hector_full": "HectorFullFreeEnv", "humanoid_ppo": "XBotLFreeEnv"}[task]
+    env_cls = getattr(env_mod, env_cls)
 
-    cfg = cfg_mod.HectorFullCfg() if task == "hector_full" else cfg_mod.HectorCfg()
+    cfg = getattr(cfg_mod, {"hector": "HectorCfg", "hector_full": "HectorFullCfg", "humanoid_ppo": "XBotLCfg"}[task])()
     cfg.terrain.mesh_type = "plane"
     if terrain is not None:
         for k, v in terrain.items():
@@ -299,6 +300,12 @@ if __name__ == "__main__":
     #    the same stub -- pins the oracle's restatement of that task's glue (SURVEY 8f-4 groundwork; no kernel yet)
     if want("env_rollout_g"):
         generate("env_rollout_g", N, 80, seed=37, action_std=0.5, task="hector_full",
+                 ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390)
+    # H: the sibling task humanoid_ppo (XBot-L, 12 DoF, joints about the z axes of rotated frames; reference humanoid_env.py /
+    #    humanoid_config.py) through the same stub: 47-wide frames x 15, the 73-wide privileged frame x 3, the joint_pos reward that
+    #    follows the gait reference (default pose = 0, so the term is sensitive to the reference's phase), action delay 0.5
+    if want("env_rollout_h"):
+        generate("env_rollout_h", N, 80, seed=41, action_std=0.6, task="humanoid_ppo",
                  ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390)
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others

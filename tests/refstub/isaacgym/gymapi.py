@@ -128,6 +128,8 @@ class Gym:
         # the compiled model of the asset the task names: robot.urdf (hector) or robot_w_arm.urdf (hector_full)
         if "w_arm" in str(file):
             self.model = _phys.load_model(_phys.MODEL_FULL_JSON)
+        elif "XBot" in str(file):
+            self.model = _phys.load_model(_phys.MODEL_XBOT_JSON)
         self.nd, self.nbod = len(self.model["bodies"]) - 1, len(self.model["bodies"])
         return "asset"
 

@@ -33,8 +33,8 @@ def load_ppo():
 
 
 def load_env(task="hector"):
-    """reference HectorFreeEnv / HectorCfg (task "hector") or HectorFullFreeEnv / HectorFullCfg (task "hector_full") over
-    the stub isaacgym (tests/refstub/isaacgym)."""
+    """reference HectorFreeEnv / HectorCfg (task "hector"), HectorFullFreeEnv / HectorFullCfg ("hector_full") or XBotLFreeEnv /
+    XBotLCfg ("humanoid_ppo") over the stub isaacgym (tests/refstub/isaacgym)."""
     sys.dont_write_bytecode = True
     if _REPO not in sys.path:
         sys.path.insert(0, _REPO)
@@ -52,8 +52,6 @@ def load_env(task="hector"):
         lr = importlib.import_module("humanoid.envs.base.legged_robot")
         e.LeggedRobot = lr.LeggedRobot
     stem = {"hector_full": "hector_w_arm", "humanoid_ppo": "humanoid"}.get(task, "hector")
-    if task == "humanoid_ppo":             # configs only: this task's env glue is not restated yet
-        return None, importlib.import_module("humanoid.envs.custom.humanoid_config"), importlib.import_module("humanoid.utils.helpers")
     env_mod = importlib.import_module(f"humanoid.envs.custom.{stem}_env")
     cfg_mod = importlib.import_module(f"humanoid.envs.custom.{stem}_config")
     helpers = importlib.import_module("humanoid.utils.helpers")

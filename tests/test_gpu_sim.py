@@ -25,8 +25,12 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 def make_env(fx):
     n, steps, seed, sc0, noise = (int(x) for x in fx["meta"])
-    full = "task" in fx and str(fx["task"]) == "hector_full"          # fixture G: the 18-DoF sibling task
-    cfg = HectorFullCfg() if full else HectorCfg()
+    task = str(fx["task"]) if "task" in fx else "hector"             # fixture G: hector_full, fixture H: humanoid_ppo (XBot-L)
+    from isaac_amd.envs.configs import XBotLCfg
+    from isaac_amd.envs.hector_env import XBotLFreeEnv
+    cfg_cls, env_cls = {"hector": (HectorCfg, HectorFreeEnv), "hector_full": (HectorFullCfg, HectorFullFreeEnv),
+                        "humanoid_ppo": (XBotLCfg, XBotLFreeEnv)}[task]
+    cfg = cfg_cls()
     cfg.env.num_envs = n
     cfg.noise.add_noise = bool(noise)
     cfg.seed = seed
@@ -53,11 +57,11 @@ def make_env(fx):
             cfg.terrain.num_rows, cfg.terrain.num_cols = (int(x) for x in fx["terrain_origins"].shape[:2])
             cfg.terrain.terrain_length = cfg.terrain.terrain_width = float(fx["terrain_env_length"])
             creation["terrain_levels"], creation["terrain_origins"] = fx["init_terrain_levels"], fx["terrain_origins"]
-    env = (HectorFullFreeEnv if full else HectorFreeEnv)(cfg, sim_device="cuda:0", creation=creation, init_pack=fx["packs"][0])
+    env = env_cls(cfg, sim_device="cuda:0", creation=creation, init_pack=fx["packs"][0])
     return env, n, steps, sc0
 
 
-@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_g"])
+@pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_g", "env_rollout_h"])
 def test_constructor_reset_and_first_observation(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)
@@ -70,7 +74,7 @@ def test_constructor_reset_and_first_observation(hxlib, name):
 
 
 @pytest.mark.parametrize("name", ["env_rollout_a", "env_rollout_b", "env_rollout_c", "env_rollout_d", "env_rollout_e", "env_rollout_f",
-                                  "env_rollout_g"])
+                                  "env_rollout_g", "env_rollout_h"])
 def test_teacher_forced_steps(hxlib, name):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     env, n, steps, sc0 = make_env(fx)

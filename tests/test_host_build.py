@@ -25,18 +25,18 @@ def _creation(fx):
 
 
 def _env_from_fixture(fx, asan=False):
-    from isaac_amd.envs.configs import HectorCfg, HectorFullCfg
+    from isaac_amd.envs.configs import HectorCfg, HectorFullCfg, XBotLCfg
     from oracle.host import HostEnv
     n, _, seed, sc0, noise = (int(x) for x in fx["meta"])
-    full = "task" in fx and str(fx["task"]) == "hector_full"
-    cfg = HectorFullCfg() if full else HectorCfg()
+    task = str(fx["task"]) if "task" in fx else "hector"
+    cfg = {"hector": HectorCfg, "hector_full": HectorFullCfg, "humanoid_ppo": XBotLCfg}[task]()
     cfg.env.num_envs = n
     cfg.noise.add_noise = bool(noise)
     cfg.terrain.mesh_type = "trimesh" if "terrain_heights" in fx else "plane"
-    return HostEnv(cfg, creation=_creation(fx), init_pack=fx["packs"][0], full=full, asan=asan), n, sc0
+    return HostEnv(cfg, creation=_creation(fx), init_pack=fx["packs"][0], task=task, asan=asan), n, sc0
 
 
-@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 50), ("env_rollout_g", 80)])
+@pytest.mark.parametrize("name,steps", [("env_rollout_a", 60), ("env_rollout_b", 40), ("env_rollout_c", 50), ("env_rollout_g", 80), ("env_rollout_h", 80)])
 def test_host_build_replays_reference_fixture(name, steps):
     """Teacher-forced like tests/test_gpu_sim.py: every step starts from the fixture's recorded physics state."""
     fx = np.load(os.path.join(GOLD, name + ".npz"))

@@ -19,9 +19,9 @@ def make_oracle_env(fx, **kw):
         from oracle.terrain import HeightField
         hs, vs, border = fx["terrain_params"]
         terrain = HeightField(fx["terrain_heights"], hs, vs, border, wall_height=float(fx["terrain_wall_height"]) if "terrain_wall_height" in fx else 0.0)
-    if "task" in fx and str(fx["task"]) == "hector_full":
-        from oracle.env import HECTOR_FULL
-        kw.setdefault("task", HECTOR_FULL)
+    if "task" in fx and str(fx["task"]) != "hector":
+        from oracle.env import HECTOR_FULL, HUMANOID
+        kw.setdefault("task", {"hector_full": HECTOR_FULL, "humanoid_ppo": HUMANOID}[str(fx["task"])])
     if "cfg_override_names" in fx and len(fx["cfg_override_names"]):
         import json
         ov = {str(k): json.loads(str(v)) for k, v in zip(fx["cfg_override_names"], fx["cfg_override_values"])}
@@ -47,7 +47,7 @@ def make_oracle_env(fx, **kw):
 
 
 @pytest.mark.parametrize("name,steps", [("env_rollout_a", 40), ("env_rollout_b", 40), ("env_rollout_c", 30), ("env_rollout_d", 150),
-                                        ("env_rollout_e", 90), ("env_rollout_f", 60), ("env_rollout_g", 80)])
+                                        ("env_rollout_e", 90), ("env_rollout_f", 60), ("env_rollout_g", 80), ("env_rollout_h", 80)])
 def test_oracle_env_reproduces_reference(name, steps):
     fx = np.load(os.path.join(GOLD, name + ".npz"))
     n, total, seed, sc0, noise = (int(x) for x in fx["meta"])
@@ -55,7 +55,7 @@ def test_oracle_env_reproduces_reference(name, steps):
     np.testing.assert_allclose(env.obs_buf, fx["init_obs_full"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(env.priv_buf, fx["init_priv_full"], rtol=0, atol=1e-6)
     assert list(fx["reward_names"]) == env.reward_order      # alphabetical dir() order (helpers.py:47)
-    if name not in ("env_rollout_e", "env_rollout_g"):
+    if name not in ("env_rollout_e", "env_rollout_g", "env_rollout_h"):
         assert env.reward_order == REWARD_ORDER
     if name == "env_rollout_f":
         assert fx["rew"].min() < 0 and not env.opts["heading_command"]       # unclipped rewards, yaw-rate commands
