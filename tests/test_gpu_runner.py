@@ -154,3 +154,26 @@ def test_hector_full_trains_through_the_registry(hxlib, tmp_path):
     root, q, qd = env.get_state()
     assert q.shape == (128, 18) and np.all(np.isfinite(q)) and np.all(np.isfinite(root))
     env.close()
+
+
+def test_humanoid_ppo_trains_through_the_registry(hxlib, tmp_path):
+    """The XBot-L task (reference humanoid/envs/__init__.py:47, humanoid_config.py / humanoid_env.py) end to end: registry ->
+    XBotLFreeEnv (kernel instantiated with rotated joint frames and 6-joint legs) -> runner; 47 x 15 observations, a 73 x 3
+    privileged row, 12 actions, checkpoint with the reference's tensor shapes."""
+    from isaac_amd.envs import task_registry
+    from isaac_amd.utils import get_args
+    args = get_args(["--task=humanoid_ppo", "--headless", "--num_envs", "128", "--max_iterations", "2", "--seed", "3"])
+    env, env_cfg = task_registry.make_env("humanoid_ppo", args=args)
+    assert (env.num_obs, env.num_privileged_obs, env.num_actions) == (705, 219, 12)
+    runner, train_cfg = task_registry.make_alg_runner(env, name="humanoid_ppo", args=args, log_root=str(tmp_path))
+    runner.learn(2, init_at_random_ep_len=True)
+    rows = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
+    assert len(rows) == 2 and np.isfinite(rows[-1]["Loss/value_function"]) and np.isfinite(rows[-1]["Loss/surrogate"])
+    assert "Episode/rew_joint_pos" in rows[-1] and "Episode/rew_track_vel_hard" in rows[-1]          # this task's reward set
+    sd = runner.alg.actor_critic.state_dict()
+    assert sd["actor.0.weight"].shape == (512, 705) and sd["critic.0.weight"].shape == (768, 219) and sd["std"].shape == (12,)
+    obs, priv = env.get_observations().numpy(), env.get_privileged_observations().numpy()
+    assert obs.shape == (128, 705) and priv.shape == (128, 219) and np.all(np.isfinite(obs)) and np.all(np.abs(obs) <= 18.0)
+    root, q, qd = env.get_state()
+    assert q.shape == (128, 12) and np.all(np.isfinite(q)) and 0.6 < np.median(root[:, 2] - env.env_origins[:, 2]) < 1.1   # standing height
+    env.close()
