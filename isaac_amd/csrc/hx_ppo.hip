@@ -789,6 +789,7 @@ struct hx_ppo {
   hx_ppo_cfg cfg;
   hipStream_t stream; bool own_stream;
   hipStream_t stream2; hipEvent_t ev_fork, ev_join;   // critic chain of the rollout runs beside the actor chain
+  hipStream_t stream_b = nullptr; hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // update phase, optional (HX_UPDATE_STREAMS=2): the critic's GEMM chain beside the actor's
   Layer L[8];                  // actor 0..3, critic 4..7
   size_t std_off, padded, stats_off;
   int64_t torch_count;
@@ -1228,6 +1229,13 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
       HX_CHECK(hipStreamCreateWithPriority(&s->stream2, hipStreamNonBlocking, least));
     }
   }
+  // measured (profiles/r02_c_update_phase.txt): no gain at 4096 envs (31.70 ms against 31.41 ms on one stream) -- the launches
+  // of one chain already keep every CU busy; kept behind HX_UPDATE_STREAMS=2 for other sizes
+  if (getenv("HX_UPDATE_STREAMS") && atoi(getenv("HX_UPDATE_STREAMS")) == 2) {
+    HX_CHECK(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
+    HX_CHECK(hipEventCreateWithFlags(&s->ev_b0, hipEventDisableTiming));
+    HX_CHECK(hipEventCreateWithFlags(&s->ev_b1, hipEventDisableTiming));
+  }
   HX_CHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   HX_CHECK(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   HX_CHECK(hipEventCreateWithFlags(&s->ev_priv, hipEventDisableTiming));
@@ -1342,6 +1350,8 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
   // null checks: hx_ppo_create also ends here with a half-built object, and a failed destroy call would leave a
   // sticky HIP error for the next launch check to trip over
   if (s->stream2) { (void)hipStreamSynchronize(s->stream2); (void)hipStreamDestroy(s->stream2); }
+  if (s->stream_b) { (void)hipStreamSynchronize(s->stream_b); (void)hipStreamDestroy(s->stream_b); }
+  for (hipEvent_t e : {s->ev_b0, s->ev_b1}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {s->ev_fork, s->ev_join, s->ev_priv, s->ev_crit})
     if (e) (void)hipEventDestroy(e);
   if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -1646,9 +1656,14 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
     hipLaunchKernelGGL(hx_gather_kernel, dim3(M), dim3(256), 0, st, ga);
     s->mb_gathered |= (1ull << mb);
   }
-  // forward
-  mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a);
-  mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c);
+  // forward.  The actor's and the critic's chains are independent up to the loss head: they run on two streams, so that the
+  // short launches of one (240 .. 480 workgroups on 768 slots) fill up beside the other's and no launch waits for the
+  // previous one's tail; the critic joins before the loss head and forks again for the backward pass.
+  hipStream_t sb = s->stream_b ? s->stream_b : st;
+  if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
+  mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a, st);
+  mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c, sb);
+  if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   // heads: losses + gradient into the third hidden layer
   const int hw = c.actor_hidden[2], hwc = c.critic_hidden[2];
   const int hblocks = (M + HEAD_ROWS - 1) / HEAD_ROWS;
@@ -1668,7 +1683,9 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab2, hchunks, s->head_slab_w, s->grads, hs, (float)M);
   // backward through the hidden layers of both networks; partial slabs go to per-layer regions, one reduce at the end
   ReduceTable rt{}; unsigned blocks = 0;
+  if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
   for (int net = 0; net < 2; ++net) {
+    const hipStream_t st = net ? sb : s->stream;          // shadows: the critic's backward chain on the second stream
     const Layer* L = s->L + net * 4;
     float** act = net ? s->act_c : s->act_a;
     float** dz = net ? s->dz_c : s->dz_a;
@@ -1691,6 +1708,7 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
     }
   }
   rt.block0[rt.nseg] = blocks;
+  if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   hipLaunchKernelGGL(hx_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, rt);
   HX_CHECK(hipGetLastError());
   if (grad_buffer) *grad_buffer = s->grads;
