@@ -267,7 +267,7 @@ if __name__ == "__main__":
     N = 8
     # A: ordinary rollout from the initial reset; falls (contact terminations) happen on their own
     if want("env_rollout_a"):
-        generate("env_rollout_a", 64, 60, seed=5, action_std=1.0)      # 64 robots (SURVEY 8d config 1's env count)
+        generate("env_rollout_a", 64, 60, seed=5, action_std=2.5)      # 64 robots (SURVEY 8d config 1's env count)
     # B: exercises the calendar events: command resampling (ep_len % 800 == 0), time-outs (> 2400),
     #    the global push (counter % 400 == 0); observation noise off so stacks are exact
     if want("env_rollout_b"):

@@ -58,11 +58,11 @@ def test_hector_full_cfgs_match_reference():
 
 def test_humanoid_ppo_configs_equal_reference():
     """XBotLCfg / XBotLCfgPPO (reference humanoid_config.py; written here as overrides of the hector classes) leaf by leaf.
-    Configs only: this sibling's env step is not built, and the registry must not pretend otherwise."""
+    The env step of this sibling is built since round 2 (isaac_amd/envs/hector_env.py XBotLFreeEnv), so the registry lists it."""
     from isaac_amd.envs.configs import XBotLCfg, XBotLCfgPPO
     from isaac_amd.envs import task_registry
     ref = json.load(open(GOLD))
     assert _diff(json.loads(json.dumps(class_to_dict(XBotLCfg()))), ref["XBotLCfg"]) == []
     assert _diff(json.loads(json.dumps(class_to_dict(XBotLCfgPPO()))), ref["XBotLCfgPPO"]) == []
     assert XBotLCfg.env.num_observations == 705 and XBotLCfg.env.num_privileged_obs == 219
-    assert "humanoid_ppo" not in task_registry.task_classes and "hector_full" in task_registry.task_classes
+    assert "humanoid_ppo" in task_registry.task_classes and "hector_full" in task_registry.task_classes
