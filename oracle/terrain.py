@@ -15,9 +15,10 @@ Two layers:
 Plus the continuous height function used by the physics oracle: every grid cell is split into two triangles along
 the (i,j)-(i+1,j+1) diagonal -- the split `convert_heightfield_to_trimesh` produces -- and a query returns the
 height and unit normal of the triangle under (x, y).  The slope-threshold vertex shift that the reference applies
-for `mesh_type='trimesh'` (legged_robot_config.py `slope_treshold`) is available in `heightfield_to_trimesh` for
-inspection but the contact model (oracle/physics.py and the HIP kernel alike) collides with the unshifted
-triangles; see DESIGN.md "Terrain".
+for `mesh_type='trimesh'` (legged_robot_config.py `slope_treshold`) turns steep grid steps into vertical walls:
+`heightfield_to_trimesh` produces the shifted mesh (pinned by the fixture), and `HeightField(wall_height=...)` collides
+with it the way the HIP kernel does (`contact()`: cliff cells continue at their low level, a point that entered a
+plateau through a wall is pushed back horizontally; isaac_amd/csrc/hx_dyn.h terrain_query / wall_push); see DESIGN.md 4.1.
 """
 import numpy as np
 
