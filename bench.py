@@ -209,17 +209,25 @@ def main():
     # HIP-event brackets cost GPU time (every GEMM launch bracketed: -1.5 % env-steps/s), so the full per-kernel table is
     # taken during the untimed warm-up iterations and only the dominant kernel found there is bracketed in the timed region.
     prof_all = None
+    env_step_ms, env_step_from = None, None
+    time_env = (not args.no_prof) and args.shards == 1          # the env-step kernel's brackets: same rule, warm-up when there is one
     if not args.no_prof and args.warmup > 0:
         runner.alg.prof_begin()
+        if time_env:
+            capi.check(capi.lib().hx_sim_time(env._h, 1, None), "hx_sim_time")
     runner.learn(args.warmup, init_at_random_ep_len=True)          # untimed warm-up iterations
     env.sync()
     if not args.no_prof and args.warmup > 0:
         prof_all = runner.alg.prof_end()
+        if time_env:
+            env_step_ms = np.zeros(2, np.float64)
+            capi.check(capi.lib().hx_sim_time(env._h, 0, env_step_ms.ctypes.data), "hx_sim_time")
+            env_step_from, time_env = "warm-up iterations", False
     comm.barrier()
     if not args.no_prof:
         dominant = max(prof_all["kernels"], key=lambda r: r["ms"])["name"] if prof_all and prof_all["kernels"] else None
         runner.alg.prof_begin(only=dominant)
-        if args.shards == 1:
+        if time_env:
             capi.check(capi.lib().hx_sim_time(env._h, 1, None), "hx_sim_time")
     t0 = time.perf_counter()
     runner.learn(args.steps, init_at_random_ep_len=False)
@@ -227,11 +235,10 @@ def main():
     comm.barrier()
     elapsed = time.perf_counter() - t0
     prof = None if args.no_prof else runner.alg.prof_end()
-    env_step_ms = None
-    if not args.no_prof and args.shards == 1:
-        tt = np.zeros(2, np.float64)
-        capi.check(capi.lib().hx_sim_time(env._h, 0, tt.ctypes.data), "hx_sim_time")
-        env_step_ms = tt
+    if time_env:
+        env_step_ms = np.zeros(2, np.float64)
+        capi.check(capi.lib().hx_sim_time(env._h, 0, env_step_ms.ctypes.data), "hx_sim_time")
+        env_step_from = "timed region"
     elapsed = comm.max_over_ranks(elapsed)
 
     if comm.rank == 0:
@@ -270,7 +277,7 @@ def main():
             pmc = None if full else pmc_env_step()
             peak = 1024 * 2.4e9 / 4
             es = {"kernel": "hx_env_step_kernel", "bound": "valu-issue", "launches": int(env_step_ms[1]), "avg_launch_us": us,
-                  "waves": (args.envs + 7) // 8, "peak_wave_insts_per_s": peak, "valu_insts_per_launch": None, "achieved_wave_insts_per_s": None, "frac": None}
+                  "measured_in": env_step_from, "waves": (args.envs + 7) // 8, "peak_wave_insts_per_s": peak, "valu_insts_per_launch": None, "achieved_wave_insts_per_s": None, "frac": None}
             if pmc and args.envs == 4096 and args.terrain == pmc.get("terrain", "trimesh"):
                 es["valu_insts_per_launch"] = pmc["valu_insts_per_launch"]
                 es["achieved_wave_insts_per_s"] = pmc["valu_insts_per_launch"] / (us * 1e-6)

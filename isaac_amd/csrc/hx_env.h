@@ -72,12 +72,16 @@ struct StepArgs {
 };
 
 // ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
+// One out-of-line copy on the device (it is called from ~40 places of the glue); the four words come back BY VALUE, i.e. in
+// registers: an output array would live on the stack, and a kernel that touches scratch memory at all pays ~7 us per launch
+// on this part (tools/micro/launch_gap.hip).
+struct U4 { uint32_t v[4]; };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __attribute__((noinline))
 #else
 inline
 #endif
-void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+U4 philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint32_t hi0 = hx_mulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -86,7 +90,8 @@ void philox4(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, ui
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  U4 o; o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
 }
 
 struct Rng {
@@ -100,9 +105,8 @@ struct Rng {
   uint32_t k0, k1, step;
   HXD float uni(int field) const {
     if (pack) return pack[(size_t)field * n + env];
-    uint32_t o[4];
-    philox4(k0, k1, gid, step, (uint32_t)field, 0u, o);
-    return (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+    const U4 o = philox4(k0, k1, gid, step, (uint32_t)field, 0u);
+    return (float)(o.v[0] >> 8) * (1.0f / 16777216.0f);
   }
   // N(0,1) draws of `count` consecutive fields.  One Philox call yields the four normals of fields 4b .. 4b+3 (two
   // Box-Muller pairs), so a run costs count / 4 calls.
@@ -110,11 +114,10 @@ struct Rng {
     if (pack) { for (int k = 0; k < count; ++k) out[k] = pack[(size_t)(field0 + k) * n + env]; return; }
     const int b0 = field0 >> 2, b1 = (field0 + count - 1) >> 2;
     auto block = [&](int b, float* z) {
-      uint32_t o[4];
-      philox4(k0, k1, gid, step, (uint32_t)b, 1u, o);
+      const U4 o = philox4(k0, k1, gid, step, (uint32_t)b, 1u);
       for (int h = 0; h < 2; ++h) {
-        const float u1 = 1.0f - (float)(o[2 * h] >> 8) * (1.0f / 16777216.0f);   // (0,1]
-        const float u2 = (float)(o[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+        const float u1 = 1.0f - (float)(o.v[2 * h] >> 8) * (1.0f / 16777216.0f);   // (0,1]
+        const float u2 = (float)(o.v[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
         const float r = sqrtf(-2.0f * logf(u1)), a = 6.283185307179586f * u2;
         z[2 * h] = r * cosf(a); z[2 * h + 1] = r * sinf(a);
       }

@@ -1515,7 +1515,10 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     // The critic's values are first needed by GAE, so the critic runs DEFERRED: every HX_CRITIC_CHUNK slots one
     // large batch (chunk * N rows -> full-size tiles) on the second stream, where it fills the CUs that the
     // latency-bound env-step kernels (128 waves) leave idle.
-    HX_CHECK(hipEventRecord(s->ev_priv, st));                 // slot t's privileged rows are in the storage
+    // slot t's privileged rows are in the storage; the event is only looked at by a flush (an event record costs the
+    // stream ~6 us, so not every step)
+    const bool flush_now = t + 1 - s->crit_done >= HX_CRITIC_CHUNK;
+    if (flush_now) HX_CHECK(hipEventRecord(s->ev_priv, st));
     const Layer* La = s->L;
     const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
     if (fused_ok) {
@@ -1541,7 +1544,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
                          s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
                          s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
     }
-    if (t + 1 - s->crit_done >= HX_CRITIC_CHUNK) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
+    if (flush_now) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
   } else {
     mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
     mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);

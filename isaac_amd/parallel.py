@@ -164,6 +164,7 @@ class HxComm(Comm):
     """RCCL communicator owned by libhx.so.  in_library = True tells PPO that the library issues the collectives itself
     (hx_ppo_set_comm): PPO.update is then the same single C call as on one GPU."""
     in_library = True
+    _created = 0
 
     def __init__(self, rank=None, world_size=None, local_rank=None):
         import ctypes as C
@@ -180,13 +181,17 @@ class HxComm(Comm):
             # host-side rendezvous: rank 0's unique id through a TCPStore on MASTER_ADDR:MASTER_PORT (plumbing only)
             from datetime import timedelta
             from torch.distributed import TCPStore
+            # under torch.distributed.run the launcher's agent already serves a store on MASTER_PORT: every rank is a client
+            agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
             store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29511")), self.world_size,
-                             self.rank == 0, timeout=timedelta(seconds=300))
+                             self.rank == 0 and not agent_store, timeout=timedelta(seconds=300))
+            key = "hx_rccl_unique_id_%d" % HxComm._created           # one key per communicator of the job
+            HxComm._created += 1
             if self.rank == 0:
                 capi.check(L.hx_comm_get_unique_id(uid), "hx_comm_get_unique_id")
-                store.set("hx_rccl_unique_id", bytes(uid))
+                store.set(key, bytes(uid))
             else:
-                raw = store.get("hx_rccl_unique_id")
+                raw = store.get(key)
                 C.memmove(uid, raw, 128)
             self._store = store
         else:
