@@ -268,7 +268,7 @@ def main():
                                "launches": k["launches"], "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
                                "flop_per_launch": k["flops"] / max(1, k["launches"]),
                                "all_gemm_kernels": (prof_all or prof)["kernels"],
-                               "all_gemm_kernels_from": "warm-up iterations (all launches bracketed)" if prof_all else "timed region",
+                               "all_gemm_kernels_from": "warm-up iterations (every launch on the learner's stream bracketed; the deferred critic's background launches overlap the rollout and are not)" if prof_all else "timed region",
                                "whole_iteration_mfma_frac": None if full else value / world * FLOP_PER_ENV_STEP / (peak * 1e12)}
         if env_step_ms is not None and env_step_ms[1] > 0 and "roofline" in out:
             # the env-step kernel: top kernel of the rollout, bound by VALU issue (it reads and writes ~1.3 KB per robot).

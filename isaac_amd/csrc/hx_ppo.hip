@@ -785,6 +785,12 @@ __global__ void __launch_bounds__(256) hx_adam_kernel(float* __restrict__ p, con
 // ================================================================= host side
 struct Layer { int out, in, in_ld; size_t w, b; };
 
+// Rollout slots per deferred critic batch.  Measured at 4096 envs (profiles/r02_e_critic_chunk.txt): a batch of 2 slots
+// (8192 rows, 128 x 128 BK16 tiles) starting beside the actor kernel costs the rollout 1.0 ms per iteration, 5 slots 2.7 ms,
+// 1 slot 2.1-3.8 ms; starting the batch after the actor (beside the env step only) is worse for every size.
+#ifndef HX_CRITIC_CHUNK
+#define HX_CRITIC_CHUNK 2
+#endif
 struct hx_ppo {
   hx_ppo_cfg cfg;
   hipStream_t stream; bool own_stream;
@@ -799,6 +805,9 @@ struct hx_ppo {
   unsigned char* s_dones; unsigned char* s_timeouts;
   int crit_done;                 // rollout slots [0, crit_done) already have their critic values
   hipEvent_t ev_priv, ev_crit;   // priv rows of a slot copied (main stream) / deferred critic finished (stream2)
+  int critic_chunk;              // rollout slots per deferred critic batch (HX_CRITIC_CHUNK, default 2)
+  int critic_late;               // 1: a deferred critic batch starts after the actor kernel of its step instead of beside it
+  int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
   int step;
   // workspace
@@ -839,7 +848,9 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL = fals
   const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
   // kernel id for the profiler: 0 fwd128, 1 fwd64, 2 dgrad128, 3 dgrad64, 4 wgrad
   constexpr int kid = (EPI == EPI_SLAB) ? 4 : ((EPI == EPI_ELU_GRAD) ? (BM == 128 ? 2 : 3) : (BM == 128 ? 0 : 1));
-  const bool timed = s && s->prof && ((s->prof_mask >> kid) & 1);
+  // launches of the deferred critic on the background stream are not bracketed: they share the chip with the rollout's
+  // kernels, so an event pair there measures contended time, not the kernel
+  const bool timed = s && s->prof && ((s->prof_mask >> kid) & 1) && st != s->stream2;
   if (timed) {
     while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
   }
@@ -918,7 +929,8 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   // the env-step kernel waited for LDS (440 us instead of 200 us on the steps a critic burst overlaps,
   // profiles/r01_j_rollout_interference.txt).
   if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // every hidden-layer forward product in bf16 mode
-  else if (background && M >= 16384) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
+  else if (background && (s->bg_tile == 128 || (s->bg_tile == 0 && M >= 8192))) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
+  else if (background && s->bg_tile == 64) launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, g, st);     // whole K tiles only
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
@@ -1327,6 +1339,9 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   // 8 waves (each streams 1/8 of a layer's weight rows) keep twice the bytes in flight per CU: 68 us per call against
   // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
   { const char* e = getenv("HX_ACTOR_WAVES"); s->actor_waves = (e && atoi(e) == 4) ? 4 : 8; }
+  { const char* e = getenv("HX_CRITIC_LATE"); s->critic_late = e ? atoi(e) : 0; }
+  { const char* e = getenv("HX_BG_TILE"); s->bg_tile = e ? atoi(e) : 0; }
+  { const char* e = getenv("HX_CRITIC_CHUNK"); s->critic_chunk = (e && atoi(e) > 0) ? atoi(e) : HX_CRITIC_CHUNK; }
   {
     const int ha_ = cfg->actor_hidden[2], hc_ = cfg->critic_hidden[2];
     const size_t head_lds = head_lds_bytes(ha_, hc_, A, head_lds_bytes(ha_, hc_, A, true) <= 64 * 1024);
@@ -1469,9 +1484,6 @@ static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, f
   gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld, bg, fp32_only);
 }
 
-#ifndef HX_CRITIC_CHUNK
-#define HX_CRITIC_CHUNK 5
-#endif
 // values for rollout slots [crit_done, upto) on the second stream: one critic forward over (slots * N) rows
 static int critic_flush(hx_ppo* s, int upto) {
   const int N = s->cfg.num_envs;
@@ -1517,8 +1529,8 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     // latency-bound env-step kernels (128 waves) leave idle.
     // slot t's privileged rows are in the storage; the event is only looked at by a flush (an event record costs the
     // stream ~6 us, so not every step)
-    const bool flush_now = t + 1 - s->crit_done >= HX_CRITIC_CHUNK;
-    if (flush_now) HX_CHECK(hipEventRecord(s->ev_priv, st));
+    const bool flush_now = t + 1 - s->crit_done >= s->critic_chunk;
+    if (flush_now && !s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));
     const Layer* La = s->L;
     const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
     if (fused_ok) {
@@ -1544,7 +1556,10 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
                          s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
                          s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
     }
-    if (flush_now) { const int rc = critic_flush(s, t + 1); if (rc) return rc; }
+    if (flush_now) {
+      if (s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));      // the burst starts when the actor has finished, beside the env step
+      const int rc = critic_flush(s, t + 1); if (rc) return rc;
+    }
   } else {
     mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
     mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);
