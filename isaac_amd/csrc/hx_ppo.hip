@@ -177,9 +177,38 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float hx_bf16r(float x) { return (float)(__bf16)x; }
 __device__ __forceinline__ f32x4v hx_bf16r4(f32x4v v) { return (f32x4v){hx_bf16r(v[0]), hx_bf16r(v[1]), hx_bf16r(v[2]), hx_bf16r(v[3])}; }
 
+// Weight stream of the fused actor in FRAGMENT ORDER (hx_actor_pack_kernel below): for every 16-column tile nt and 16-deep
+// k block kb the 64 float4 that the 64 lanes feed to four MFMAs lie in one contiguous KB,
+//   P[((nt * nkb + kb) * 64 + lane) * 4 + j] = W[nt * 16 + (lane & 15)][kb * 16 + 4 * (lane >> 4) + j]      (0 beyond K),
+// so a wave's load instruction reads 1 KB of consecutive addresses instead of 16 rows x 64 B, and a wave walks its tile's
+// nkb KB front to back.  The row-major form kept the texture addresser busy half the time on 16 lines per instruction
+// (profiles/r01_g_actor_ring.txt).  Same operands in the same MFMAs: outputs are bitwise those of the row-major stream.
+__global__ void __launch_bounds__(256) hx_actor_pack_kernel(const float* __restrict__ W, int N, int K, int ldw, float* __restrict__ P) {
+  const int nkb = (K + 15) / 16;
+  const size_t total = (size_t)(N / 16) * nkb * 256;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const size_t blk = i >> 8;
+    const int kb = (int)(blk % nkb), nt = (int)(blk / nkb);
+    const int k = kb * 16 + 4 * (lane >> 4) + j;
+    P[i] = (k < K) ? W[(size_t)(nt * 16 + (lane & 15)) * ldw + k] : 0.f;
+  }
+}
+
+// First two k blocks of a wave's weight stream, requested ahead of the barrier that precedes the layer: the L2 round trip
+// then runs while the workgroup is still staging rows / finishing the previous layer.
+template <int NT>
+__device__ __forceinline__ void fa_prefetch(const float* __restrict__ W, int K, int n_wave0, int lane, f32x4v* b0, f32x4v* b1) {
+  const int nkb = (K + 15) / 16;
+  const f32x4v* __restrict__ Wp = reinterpret_cast<const f32x4v*>(W) + (size_t)(n_wave0 >> 4) * nkb * 64 + lane;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { b0[t] = Wp[((size_t)t * nkb) * 64]; b1[t] = Wp[((size_t)t * nkb + min(1, nkb - 1)) * 64]; }
+}
+
 template <int NT, bool BF, bool ROUND_OUT>   // NT = 16-column tiles per wave; BF: round the weight operand; ROUND_OUT: round what is stored
 __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, int ldw,
-                                         const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane) {
+                                         const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane,
+                                         f32x4v* b0, f32x4v* b1) {      // b0 / b1: blocks 0 and 1, already requested (fa_prefetch)
   const int r16 = lane & 15, kq = lane >> 4;
   f32x4v acc[NT];
 #pragma unroll
@@ -188,15 +217,17 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
   // weights are streamed from L2 with TWO k-blocks in flight per wave (one was L2-latency bound: 80 us per call).
   // The loop is written out for three named buffers on purpose: a generic register-ring version of the same
   // schedule compiled to 86 us instead of 74 us (profiles/r01_g_actor_ring.txt).
-  f32x4v b0[NT], b1[NT], b2[NT];
+  f32x4v b2[NT];
   // Branch-free on purpose: with a guard around each load hipcc loses track of the VM counter across the divergent
   // regions and waits `vmcnt(0)` before every group of MFMAs, i.e. also for the blocks just requested (the stream
   // then pays a full L2 round trip every third block: 74-86 us per call).  Out-of-range blocks re-read the last valid
   // 16 bytes of the row instead; their A operand is zero (step() guards it), so they contribute nothing.
+  // W is the packed stream of this layer (see hx_actor_pack_kernel); ldw is unused.  Out-of-range blocks re-read the last one.
+  const f32x4v* __restrict__ Wp = reinterpret_cast<const f32x4v*>(W) + (size_t)(n_wave0 >> 4) * nkb * 64 + lane;
   auto loadB = [&](int kb, f32x4v* dst) {
-    const int k = min(min(kb, nkb - 1) * 16 + 4 * kq, K - 4);
+    const int kc = min(kb, nkb - 1);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) dst[t] = *reinterpret_cast<const f32x4v*>(W + (size_t)(n_wave0 + t * 16 + r16) * ldw + k);
+    for (int t = 0; t < NT; ++t) dst[t] = Wp[((size_t)t * nkb + kc) * 64];
   };
   auto roundB = [&](f32x4v* b) {
     if (BF) {
@@ -214,8 +245,6 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bc[t][i], acc[t], 0, 0, 0);
   };
-  loadB(0, b0);
-  loadB(1, b1);
   int kb = 0;
   for (; kb + 2 < nkb; kb += 3) {
     loadB(kb + 2, b2); step(kb, b0);
@@ -254,6 +283,8 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   float* sMu = H3 + FA_ROWS * ld3;          // [16][MAX_A]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * FA_ROWS;
+  f32x4v p1a[32 / NW], p1b[32 / NW], p2a[16 / NW], p2b[16 / NW], p3a[8 / NW], p3b[8 / NW];
+  fa_prefetch<32 / NW>(W1, K1, wave * (512 / NW), lane, p1a, p1b);
   // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
   for (int i = tid; i < FA_ROWS * (K1 / 4); i += 64 * NW) {
     const int r = i / (K1 / 4), c4 = i % (K1 / 4);
@@ -262,25 +293,24 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = BF ? hx_bf16r4(v) : v;
   }
   __syncthreads();
-  fa_layer<32 / NW, BF, BF>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane);      // 615(616) -> 512
+  fa_prefetch<16 / NW>(W2, N1, wave * (256 / NW), lane, p2a, p2b);
+  fa_layer<32 / NW, BF, BF>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane, p1a, p1b);      // 615(616) -> 512
   __syncthreads();
-  fa_layer<16 / NW, BF, BF>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * (256 / NW), lane);      // 512 -> 256
+  fa_prefetch<8 / NW>(W3, N2, wave * (128 / NW), lane, p3a, p3b);
+  fa_layer<16 / NW, BF, BF>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * (256 / NW), lane, p2a, p2b);      // 512 -> 256
   __syncthreads();
-  fa_layer<8 / NW, BF, false>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
+  fa_layer<8 / NW, BF, false>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane, p3a, p3b);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
   __syncthreads();
-  // head: mu[r][j] = W4[j] . H3[r] + b4[j]
+  // head: mu[r][j] = W4[j] . H3[r] + b4[j]; one thread per (row, action) also samples its action and leaves its
+  // log-prob term in LDS; the row's thread then adds the terms in action order (the order of the serial loop it replaces)
+  float* sTerm = H1;                         // layer-1 activations are dead by now
   for (int i = tid; i < FA_ROWS * A; i += 64 * NW) {
     const int r = i / A, j = i % A;
     float m = 0.f;
     for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4[j * N3 + k], m);
-    sMu[r * MAX_A + j] = m + b4[j];
-  }
-  __syncthreads();
-  if (tid < FA_ROWS && row0 + tid < n) {
-    const int e = row0 + tid;
-    float lp = 0.f;
-    for (int j = 0; j < A; ++j) {
-      const float m = sMu[tid * MAX_A + j];
+    m += b4[j];
+    const int e = row0 + r;
+    if (e < n) {
       const float sg = m * 0.f + stdp[j];
       float z;
       if (eps) z = eps[(size_t)e * A + j];
@@ -295,9 +325,14 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
       actions[(size_t)e * A + j] = a;
       mu_out[(size_t)e * A + j] = m;
       const float d = a - m;
-      lp += -(d * d) / (2.0f * sg * sg) - logf(sg) - LOG_SQRT_2PI;
+      sTerm[r * MAX_A + j] = -(d * d) / (2.0f * sg * sg) - logf(sg) - LOG_SQRT_2PI;
     }
-    logp[e] = lp;
+  }
+  __syncthreads();
+  if (tid < FA_ROWS && row0 + tid < n) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) lp += sTerm[tid * MAX_A + j];
+    logp[row0 + tid] = lp;
   }
 }
 
@@ -806,6 +841,7 @@ struct hx_ppo {
   int crit_done;                 // rollout slots [0, crit_done) already have their critic values
   hipEvent_t ev_priv, ev_crit;   // priv rows of a slot copied (main stream) / deferred critic finished (stream2)
   int critic_chunk;              // rollout slots per deferred critic batch (HX_CRITIC_CHUNK, default 2)
+  float* apack[3]; bool apack_dirty;   // actor hidden-layer weights in MFMA fragment order for the fused rollout actor; stale after any parameter change
   int critic_late;               // 1: a deferred critic batch starts after the actor kernel of its step instead of beside it
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
@@ -1340,6 +1376,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
   { const char* e = getenv("HX_ACTOR_WAVES"); s->actor_waves = (e && atoi(e) == 4) ? 4 : 8; }
   { const char* e = getenv("HX_CRITIC_LATE"); s->critic_late = e ? atoi(e) : 0; }
+  for (int l = 0; l < 3; ++l) s->apack[l] = nullptr;
+  s->apack_dirty = true;
   { const char* e = getenv("HX_BG_TILE"); s->bg_tile = e ? atoi(e) : 0; }
   { const char* e = getenv("HX_CRITIC_CHUNK"); s->critic_chunk = (e && atoi(e) > 0) ? atoi(e) : HX_CRITIC_CHUNK; }
   {
@@ -1381,6 +1419,7 @@ extern "C" int hx_ppo_set_comm(hx_ppo* s, hx_comm* c) {
 extern "C" int hx_ppo_broadcast_params(hx_ppo* s, int root) {
   if (!s || !s->comm) { hx_set_error("hx_ppo_broadcast_params: no communicator set"); return -2; }
   int rc = hx_comm_broadcast(s->comm, s->params, s->padded, root, s->stream); if (rc) return rc;
+  s->apack_dirty = true;
   refresh_transposes(s, s->stream);
   HX_CHECK(hipGetLastError());
   return 0;
@@ -1443,6 +1482,7 @@ static int download_flat(hx_ppo* s, const float* src, float* flat) {
 }
 extern "C" int hx_ppo_set_params_h(hx_ppo* s, const float* flat) {
   const int rc = upload_flat(s, s->params, flat);
+  s->apack_dirty = true;
   if (rc == 0) refresh_transposes(s, s->stream);
   return rc;
 }
@@ -1534,9 +1574,16 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     const Layer* La = s->L;
     const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
     if (fused_ok) {
+      if (s->apack_dirty) {
+        for (int l = 0; l < 3; ++l) {
+          if (!s->apack[l]) { const int rc = palloc(s, &s->apack[l], (size_t)(La[l].out / 16) * ((La[l].in_ld + 15) / 16) * 256); if (rc) return rc; }
+          hipLaunchKernelGGL(hx_actor_pack_kernel, dim3(256), dim3(256), 0, st, s->params + La[l].w, La[l].out, La[l].in_ld, La[l].in_ld, s->apack[l]);
+        }
+        s->apack_dirty = false;
+      }
       const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
-#define HX_FA_ARGS so, s->cfg.obs_ld, count, s->params + La[0].w, s->params + La[0].b, La[0].in_ld, La[0].out, s->params + La[1].w,          \
-                   s->params + La[1].b, La[1].out, s->params + La[2].w, s->params + La[2].b, La[2].out, s->params + La[3].w,              \
+#define HX_FA_ARGS so, s->cfg.obs_ld, count, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                        \
+                   s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,                     \
                    s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
@@ -1751,6 +1798,7 @@ extern "C" int hx_ppo_minibatch_step(hx_ppo* s, float inv_world) {
   const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)s->adam_t));
   hipLaunchKernelGGL(hx_adam_kernel, dim3((unsigned)((s->padded + 255) / 256)), dim3(256), 0, st, s->params, s->grads, s->m, s->v, s->padded,
                      inv_world, s->sumsq, c.max_grad_norm, s->sched, bc1, bc2s);
+  s->apack_dirty = true;
   refresh_transposes(s, st);
   HX_CHECK(hipGetLastError());
   s->mb_done += 1;
