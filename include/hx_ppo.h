@@ -53,7 +53,11 @@ enum hx_ppo_buffer_id {
   HX_PPO_BUF_RETURNS,       /* float [T][N] */
   HX_PPO_BUF_ADVANTAGES,    /* float [T][N] */
   HX_PPO_BUF_GRADS,         /* float [padded params + 4] flat gradient + statistics buffer */
-  HX_PPO_BUF_PERM           /* int32 [T*N] minibatch permutation in use */
+  HX_PPO_BUF_PERM,          /* int32 [T*N] minibatch permutation in use */
+  HX_PPO_BUF_OBS,           /* float [T][N][obs_ld]   RolloutStorage.observations (rollout_storage.py:60) */
+  HX_PPO_BUF_PRIV,          /* float [T][N][priv_ld]  RolloutStorage.privileged_observations */
+  HX_PPO_BUF_DONES,         /* uint8 [T][N] */
+  HX_PPO_BUF_TIMEOUTS       /* uint8 [T][N]  infos["time_outs"] as the step saw them (stale on steps without a reset) */
 };
 
 int hx_ppo_create(const hx_ppo_cfg* cfg, void* hip_stream, void* ext_grad_buffer /*nullable*/, hx_ppo** out);
@@ -130,6 +134,13 @@ int hx_ppo_update(hx_ppo* p, const int32_t* perm, float* stats_h);
  * to the host language; sims[h] simulates env rows [env0[h], env0[h]+count[h]).  hx_sim is declared in hx_sim.h. */
 struct hx_sim;
 int hx_rollout(hx_ppo* p, struct hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps);
+/* PPO.act (ppo.py:91-101) on observation rows that a deferred env step left for the consumer to assemble
+ * (include/hx_sim.h hx_sim_step_deferred): the fused rollout actor builds the rows of the current slot from `pending`
+ * while staging them, stores them to the slot and does the step's bookkeeping.  Whole batch only; what hx_rollout uses
+ * on every step but the first and the last of a rollout.  `priv` = the slot's privileged rows (assembled by the next
+ * env-step launch; not read here). */
+struct hx_pending_step;
+int hx_ppo_act_pending(hx_ppo* p, const struct hx_pending_step* pending, const float* priv, float** actions_out);
 
 int hx_ppo_buffer(hx_ppo* p, int which, void** dptr);
 int hx_ppo_get_lr(hx_ppo* p, float* lr_h);

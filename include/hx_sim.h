@@ -179,6 +179,28 @@ int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const flo
  * HX_BUF_OBS / HX_BUF_PRIV then point at obs_dst / priv_dst until the next step. */
 int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
                    float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst);
+/* Deferred frame stacking (the rollout fast path of hx_rollout; no reference counterpart: it moves WHERE the rows of
+ * hector_env.py:246-254 are assembled, not what they are).  hx_sim_step_deferred is hx_sim_step_ex without the stacking
+ * launch: the observation rows of the step and its per-step bookkeeping (extras["time_outs"], reward / done hand-over,
+ * episode statistics) are described in *pending for the consumer that reads the rows next -- the fused rollout actor
+ * builds them while staging its input -- and the privileged rows are assembled by spare workgroups of the NEXT env-step
+ * launch.  The caller must either consume *pending (then call hx_sim_pending_consumed) or take another hx_sim_* step, which
+ * flushes whatever is still pending before it does anything else.  Plain device pointers, valid until the next step. */
+typedef struct hx_row_stack {      /* dst[e] = [ reset[e] ? 0 : src[e][f:] | clip(frame[:, e]) ], `stack` frames of width f, row stride ld */
+  const float* src; float* dst; const float* frame; const uint8_t* reset;
+  int32_t n, f, ld, stack; float clip;
+} hx_row_stack;
+typedef struct hx_step_book {      /* what the stacking launch does besides the rows */
+  const uint8_t* reset; const uint8_t* timeout; uint8_t* timeout_visible;
+  const int32_t* num_reset; int32_t* num_reset_next;
+  float* stat_sum; float* stat_last; float* stat_acc; int32_t* stat_steps;
+  const float* rew; float* rew_out; uint8_t* done_out; uint8_t* timeout_out;
+  int32_t n;
+} hx_step_book;
+typedef struct hx_pending_step { int32_t valid; hx_row_stack obs; hx_step_book book; } hx_pending_step;
+int hx_sim_step_deferred(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
+                         float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst, hx_pending_step* pending);
+int hx_sim_pending_consumed(hx_sim* s);
 int hx_sim_buffer(hx_sim* s, int which, void** dptr);
 int hx_sim_get_state(hx_sim* s, float* root13_h /*[N][13]*/, float* q_h /*[N][10]*/, float* qd_h /*[N][10]*/);
 int hx_sim_set_state(hx_sim* s, const float* root13_h, const float* q_h, const float* qd_h);

@@ -149,6 +149,9 @@ def lib():
     L.hx_ppo_update_end.argtypes = [vp, vp]
     L.hx_ppo_update.argtypes = [vp, vp, vp]
     L.hx_rollout.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int]
+    L.hx_sim_step_deferred.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]        # last: hx_pending_step* (include/hx_sim.h)
+    L.hx_sim_pending_consumed.argtypes = [vp]
+    L.hx_ppo_act_pending.argtypes = [vp, vp, vp, C.POINTER(vp)]
     L.hx_ppo_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hx_ppo_get_lr.argtypes = [vp, vp]
     L.hx_ppo_set_lr.argtypes = [vp, C.c_float]

@@ -69,6 +69,10 @@ struct StepArgs {
   int mode;                  // 0: step, 1: constructor reset (reset all + first observation)
   long long step_counter;    // common_step_counter AFTER the increment of this step
   uint32_t k0, k1, rng_step;
+  // device launches only: workgroups [env_blocks, env_blocks + stack_blocks) assemble the privileged rows of the PREVIOUS
+  // step (deferred frame stacking, include/hx_sim.h) on SIMDs the env-step waves leave idle
+  int env_blocks, stack_blocks;
+  hx_row_stack pstack;
 };
 
 // ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
                                                              const float* __restrict__ W4, const float* __restrict__ b4,
                                                              const float* __restrict__ stdp, const float* __restrict__ eps, int A,
                                                              uint32_t k0, uint32_t k1, uint32_t step,
-                                                             float* actions, float* mu_out, float* logp) {
+                                                             float* actions, float* mu_out, float* logp, hx_pending_step pend) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
   float* Xs = fsm;
@@ -285,12 +285,44 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   const int row0 = blockIdx.x * FA_ROWS;
   f32x4v p1a[32 / NW], p1b[32 / NW], p2a[16 / NW], p2b[16 / NW], p3a[8 / NW], p3b[8 / NW];
   fa_prefetch<32 / NW>(W1, K1, wave * (512 / NW), lane, p1a, p1b);
-  // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
-  for (int i = tid; i < FA_ROWS * (K1 / 4); i += 64 * NW) {
-    const int r = i / (K1 / 4), c4 = i % (K1 / 4);
-    const int gr = min(row0 + r, n - 1);
-    const f32x4v v = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
-    *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = BF ? hx_bf16r4(v) : v;
+  if (pend.valid) {
+    // Deferred frame stacking (include/hx_sim.h): the rows this workgroup is about to read do not exist yet -- they are the
+    // previous rows shifted by one frame plus the frame the env step just produced.  Assemble them into LDS, store them to
+    // their slot (`obs`, = pend.obs.dst) for the update, and do the step's bookkeeping for these 16 robots.
+    // all of a thread's loads in flight together (the stores may alias later loads as far as the compiler knows, so the
+    // batching is written out)
+    const int total = FA_ROWS * K1;
+    constexpr int NB = 96 / NW;              // 16 rows x <= 768 values = all of a thread's share in one batch
+    for (int i0 = tid; i0 < total; i0 += 64 * NW * NB) {
+      float v[NB]; unsigned char rs[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = min(i0 + 64 * NW * u, total - 1);
+        const int r = i / K1, k = i - r * K1, gr = min(row0 + r, n - 1);
+        v[u] = *hx_row_stack_addr(pend.obs, gr, k);
+        rs[u] = pend.obs.reset[gr];
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = i0 + 64 * NW * u;
+        if (i < total) {
+          const int r = i / K1, k = i - r * K1, gr = min(row0 + r, n - 1);
+          const float o = hx_row_stack_finish(pend.obs, rs[u] != 0, k, v[u]);
+          Xs[r * ldx + k] = BF ? hx_bf16r(o) : o;
+          if (row0 + r < n) pend.obs.dst[(size_t)gr * obs_ld + k] = o;
+        }
+      }
+    }
+    if (tid < FA_ROWS && row0 + tid < n) hx_step_book_row(pend.book, row0 + tid);
+    if (blockIdx.x == 0 && tid == 64) hx_step_book_global(pend.book);
+  } else {
+    // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
+    for (int i = tid; i < FA_ROWS * (K1 / 4); i += 64 * NW) {
+      const int r = i / (K1 / 4), c4 = i % (K1 / 4);
+      const int gr = min(row0 + r, n - 1);
+      const f32x4v v = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
+      *reinterpret_cast<f32x4v*>(Xs + r * ldx + c4 * 4) = BF ? hx_bf16r4(v) : v;
+    }
   }
   __syncthreads();
   fa_prefetch<16 / NW>(W2, N1, wave * (256 / NW), lane, p2a, p2b);
@@ -1548,14 +1580,15 @@ static int critic_flush(hx_ppo* s, int upto) {
 // with `dual` the critic chain is forked onto the learner's second stream (whole-batch call), otherwise both
 // chains run back to back on `st` and the overlap comes from the other shard's stream.
 static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float* eps, int env0, int count, hipStream_t st,
-                    bool dual, float** actions_out) {
+                    bool dual, float** actions_out, const hx_pending_step* pending = nullptr) {
   const int N = s->cfg.num_envs, A = s->cfg.num_actions, t = s->step;
   if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }   // rollout_storage.py:88-89
   if (env0 < 0 || count <= 0 || env0 + count > N) { hx_set_error("hx_ppo_act: env range out of bounds"); return -2; }
   float* so = s->s_obs + ((size_t)t * N + env0) * s->cfg.obs_ld;
   float* sp = s->s_priv + ((size_t)t * N + env0) * s->cfg.priv_ld;
   // rows already in place when the env step wrote them straight into the storage (hx_sim_step_ex)
-  if (obs != so) HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (pending && (pending->obs.dst != so || !dual || env0 != 0 || count != N)) { hx_set_error("hx_ppo_act_pending: the pending rows are not this slot's"); return -2; }
+  if (obs != so && !pending) HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (priv != sp) HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)count * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
   float* aa[3]; float* ac[3];
   for (int l = 0; l < 3; ++l) { aa[l] = s->act_a[l] + (size_t)env0 * s->cfg.actor_hidden[l]; ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l]; }
@@ -1569,11 +1602,15 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     // latency-bound env-step kernels (128 waves) leave idle.
     // slot t's privileged rows are in the storage; the event is only looked at by a flush (an event record costs the
     // stream ~6 us, so not every step)
-    const bool flush_now = t + 1 - s->crit_done >= s->critic_chunk;
+    // with deferred stacking the privileged rows of slot t are assembled during env step t: a flush before it covers t - 1
+    const int flush_upto = pending ? t : t + 1;
+    const bool flush_now = flush_upto - s->crit_done >= s->critic_chunk;
     if (flush_now && !s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));
     const Layer* La = s->L;
     const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
+    if (pending && !fused_ok) { hx_set_error("hx_ppo_act_pending: needs the fused rollout actor (hidden widths 512 / 256 / 128)"); return -2; }
     if (fused_ok) {
+      hx_pending_step pend{}; if (pending) pend = *pending;
       if (s->apack_dirty) {
         for (int l = 0; l < 3; ++l) {
           if (!s->apack[l]) { const int rc = palloc(s, &s->apack[l], (size_t)(La[l].out / 16) * ((La[l].in_ld + 15) / 16) * 256); if (rc) return rc; }
@@ -1585,7 +1622,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
 #define HX_FA_ARGS so, s->cfg.obs_ld, count, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                        \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,                     \
-                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0
+                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, pend
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
       // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
       const dim3 fgrid((count + FA_ROWS - 1) / FA_ROWS);
@@ -1605,7 +1642,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     }
     if (flush_now) {
       if (s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));      // the burst starts when the actor has finished, beside the env step
-      const int rc = critic_flush(s, t + 1); if (rc) return rc;
+      const int rc = critic_flush(s, flush_upto); if (rc) return rc;
     }
   } else {
     mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
@@ -1623,6 +1660,13 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
 
 extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const float* eps, float** actions_out) {
   const int rc = act_impl(s, obs, priv, eps, 0, s->cfg.num_envs, s->stream, true, actions_out);
+  s->act_counter++;
+  return rc;
+}
+// PPO.act on rows that a deferred env step (hx_sim_step_deferred) left for the consumer to assemble
+extern "C" int hx_ppo_act_pending(hx_ppo* s, const hx_pending_step* pending, const float* priv, float** actions_out) {
+  if (!s || !pending || !pending->valid) { hx_set_error("hx_ppo_act_pending: nothing pending"); return -2; }
+  const int rc = act_impl(s, pending->obs.dst, priv, nullptr, 0, s->cfg.num_envs, s->stream, true, actions_out, pending);
   s->act_counter++;
   return rc;
 }
@@ -1836,6 +1880,10 @@ extern "C" int hx_ppo_buffer(hx_ppo* s, int which, void** d) {
     case HX_PPO_BUF_ADVANTAGES: *d = s->s_adv; break;
     case HX_PPO_BUF_GRADS: *d = s->grads; break;
     case HX_PPO_BUF_PERM: *d = s->perm; break;
+    case HX_PPO_BUF_OBS: *d = s->s_obs; break;
+    case HX_PPO_BUF_PRIV: *d = s->s_priv; break;
+    case HX_PPO_BUF_DONES: *d = s->s_dones; break;
+    case HX_PPO_BUF_TIMEOUTS: *d = s->s_timeouts; break;
     default: hx_set_error("hx_ppo_buffer: unknown id"); return -2;
   }
   return 0;
@@ -1884,6 +1932,9 @@ extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
 // shard advances on its own stream; one shard's env-step kernel overlaps the other shards' GEMMs.
 extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps) {
   const int N = p->cfg.num_envs, T = p->cfg.num_steps;
+  hx_pending_step pend{};
+  const Layer* La = p->L;
+  const bool defer_ok = nshards == 1 && La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && p->cfg.obs_ld == La[0].in_ld && getenv("HX_DEFER_STACK") && atoi(getenv("HX_DEFER_STACK")) == 1;
   for (int t = 0; t < steps; ++t) {
     for (int h = 0; h < nshards; ++h) {
       void *obs, *priv, *rew, *rst, *tov;
@@ -1895,11 +1946,21 @@ extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const i
         // the rollout storage (slot t+1 rows / slot t scalars); 3 launches per step: actor, env step, stack
         const int slot = p->step;
         if (slot >= T) { hx_set_error("Rollout buffer overflow"); return -10; }
-        rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act); if (rc) return rc;
+        if (pend.valid) { rc = hx_ppo_act_pending(p, &pend, (const float*)priv, &act); if (rc) return rc; hx_sim_pending_consumed(sims[h]); pend.valid = 0; }
+        else { rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act); if (rc) return rc; }
         float* od = nullptr; float* pd = nullptr;
         if (slot + 1 < T) { od = p->s_obs + (size_t)(slot + 1) * N * p->cfg.obs_ld; pd = p->s_priv + (size_t)(slot + 1) * N * p->cfg.priv_ld; }
-        rc = hx_sim_step_ex(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
-                            p->s_timeouts + (size_t)slot * N);
+        // HX_DEFER_STACK=1: every step but the last one defers its frame stacking -- the observation rows are assembled by
+        // the next actor launch, the privileged rows by spare workgroups of the next env-step launch (2 launches per step
+        // instead of 3).  Same storage contents bit for bit (tests/test_gpu_runner.py).  Off by default: 16 us per step
+        // faster undisturbed, but beside the deferred critic the longer actor prologue gives the gain back
+        // (profiles/r02_f_deferred_stacking.txt: 49.6 ms per iteration either way).
+        if (defer_ok && od != nullptr && t + 1 < steps)
+          rc = hx_sim_step_deferred(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
+                                    p->s_timeouts + (size_t)slot * N, &pend);
+        else
+          rc = hx_sim_step_ex(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
+                              p->s_timeouts + (size_t)slot * N);
         if (rc) return rc;
         p->step += 1;
       } else {

@@ -21,16 +21,48 @@
 // One launch per env step; the ten 1 ms substeps run inside with the robot's state in registers.  The arithmetic lives
 // in hx_dyn.h (dynamics) and hx_env.h (task glue), both shared with the host build; this kernel is the lane-group driver:
 // eight lanes per robot (four per body side, hx_math.h), HX_RPW = 8 robots per 64-lane workgroup.
-#define HX_RPW (64 / HX_LANES_PER_ROBOT)      /* robots per wave = per workgroup */
+#define HX_RPW (64 / HX_LANES_PER_ROBOT)      /* robots per wave */
+#ifndef HX_ENV_WPB
+#define HX_ENV_WPB 1                          /* waves per workgroup (each wave is self-contained: own LDS region, own robots) */
+#endif
+template <class M> __host__ __device__ static constexpr size_t env_step_lds_bytes() {
+  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + HX_RPW * HX_PATCH_LD + 2 * HX_RPW * HX_POOL_LD + 2 * HX_RPW + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + HX_RPW * 80);
+}
 template <class M>
-__global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim_cfg* __restrict__ cfgp, const float* __restrict__ actions,
+__global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p, const hx_sim_cfg* __restrict__ cfgp, const float* __restrict__ actions,
                                                          const float* __restrict__ pack, StepArgs A) {
   using D = TaskDims<M>;
   using MI = ModelInfo<M>;
   constexpr int NL = D::NL, ND = D::ND;
   constexpr SLay SL(ND);
   // dynamic LDS: staged constants | HX_RPW height windows | pooled bounds | cliff flags | window origins | per-lane contact buffer
+  if ((int)blockIdx.x >= A.env_blocks && A.stack_blocks > 0) {
+    // Spare workgroups of this launch: the privileged rows of the PREVIOUS step (deferred frame stacking).  They run on
+    // SIMDs the env-step waves leave idle (512 waves for 1024 SIMDs at 4096 robots) and read the previous step's frame /
+    // reset buffers, which this step's robots do not touch (ping-pong pairs).  The whole workgroup leaves before any barrier.
+    const hx_row_stack& ps = A.pstack;
+    for (int row = ((int)blockIdx.x - A.env_blocks) * HX_ENV_WPB + (int)(threadIdx.x >> 6); row < ps.n; row += A.stack_blocks * HX_ENV_WPB) {
+      const bool rst = ps.reset[row] != 0;
+      float* d = ps.dst + (size_t)row * ps.ld;
+      // a whole row in flight per pass where it fits (one wave has the SIMD's register file to itself)
+      for (int k0 = threadIdx.x & 63; k0 < ps.ld; k0 += 64 * 24) {
+        float v[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) v[u] = *hx_row_stack_addr(ps, row, min(k0 + 64 * u, ps.ld - 1));
+#pragma unroll
+        for (int u = 0; u < 24; ++u) { const int k = k0 + 64 * u; if (k < ps.ld) d[k] = hx_row_stack_finish(ps, rst, k, v[u]); }
+      }
+    }
+    return;
+  }
+#if HX_ENV_WPB > 1
+  extern __shared__ float lds_all0[];
+  const int tidx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* lds_all = lds_all0 + (size_t)wv * (env_step_lds_bytes<M>() / sizeof(float));
+#else
   extern __shared__ float lds_all[];
+  const int tidx = threadIdx.x, wv = 0;
+#endif
   float* lds_const = lds_all;
   float* lds_patch = lds_const + (MI::LDS_FLOATS + 3) / 4 * 4;
   float* lds_pool = lds_patch + HX_RPW * HX_PATCH_LD;
@@ -39,24 +71,24 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   float* lds_cb = lds_poolw + HX_RPW * HX_POOL_LD + 2 * HX_RPW;
 #if defined(HX_STEP_PROF)
   __shared__ long long lds_prof[16];
-  if (threadIdx.x < 16) lds_prof[threadIdx.x] = 0;
+  if (tidx < 16) lds_prof[tidx] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) lds_prof[15] = clock64();
+  if (tidx == 0) lds_prof[15] = clock64();
   long long* const prof = (p.prof != nullptr) ? lds_prof : nullptr;
 #else
   long long* const prof = nullptr;
 #endif
   const hx_sim_cfg& cfg = *cfgp;
-  dyn_stage_constants<M>(lds_const, threadIdx.x, 64, cfg.p_gains, cfg.d_gains, cfg.torque_limits, cfg.default_dof_pos);
+  dyn_stage_constants<M>(lds_const, tidx, 64, cfg.p_gains, cfg.d_gains, cfg.torque_limits, cfg.default_dof_pos);
   const int n = cfg.num_envs;
-  const int e = blockIdx.x * HX_RPW + (threadIdx.x >> 3);
-  const int side = (threadIdx.x >> 2) & 1, sub = threadIdx.x & 3, r = threadIdx.x >> 3;      // body side, lane of the side, robot of the wave
+  const int e = ((int)blockIdx.x * HX_ENV_WPB + wv) * HX_RPW + (tidx >> 3);
+  const int side = (tidx >> 2) & 1, sub = tidx & 3, r = tidx >> 3;      // body side, lane of the side, robot of the wave
   const bool use_terrain = (p.terrain != nullptr) && (A.mode == 0);
   if (use_terrain) {
     // Every lane fetches an eighth of its own robot's windows: 2 of the 16 rows of the height window, 1 of the 8 rows of
     // the two pooled maps.  All addresses follow from the robot's own base position, so the loads of a lane are
     // independent and stay in flight together.
-    const int ec = min(e, n - 1), part = threadIdx.x & 7;
+    const int ec = min(e, n - 1), part = tidx & 7;
     int oi, oj;
     patch_origin(p, p.st[(size_t)SL.ROOT_POS * n + ec], p.st[(size_t)(SL.ROOT_POS + 1) * n + ec], oi, oj);
     if (part == 0) { lds_patch_org[r][0] = oi; lds_patch_org[r][1] = oj; }
@@ -83,7 +115,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   if (e >= n) return;                      // both lanes of a pair leave together
   const bool writer = (side == 0) && (sub == 0);         // env-level results are computed by all eight lanes, stored by one
   SideConst<M> C; C.bind(lds_const, side);
-  Rng rng; rng.pack = pack; rng.share = lds_cb + (size_t)MI::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + r * 80; rng.lane = threadIdx.x & 7; rng.nlanes = HX_LANES_PER_ROBOT; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
+  Rng rng; rng.pack = pack; rng.share = lds_cb + (size_t)MI::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + r * 80; rng.lane = tidx & 7; rng.nlanes = HX_LANES_PER_ROBOT; rng.n = n; rng.env = e; rng.gid = (uint32_t)(e + cfg.env_id_offset); rng.k0 = A.k0; rng.k1 = A.k1; rng.step = A.rng_step;
 #define LD(f) (p.st[(size_t)(f) * n + e])
   // ---- load state: base (both lanes) + this lane's side; only what the physics needs (the glue loads its own state)
   DynStateT<M> S;
@@ -120,7 +152,7 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
     // one buffer column per body side: the four lanes of a side hold the same body states and (after the quad sums) write the
     // same contact terms, so they share it -- 16 columns per wave instead of 64 keeps the kernel's LDS footprint small enough
     // for the deferred critic's GEMM workgroups to stay resident beside it
-    ContactBuf cb; cb.base = lds_cb + (threadIdx.x >> 2); cb.stride = 64 / HX_LANES_PER_SIDE;
+    ContactBuf cb; cb.base = lds_cb + (tidx >> 2); cb.stride = 64 / HX_LANES_PER_SIDE;
     float target[NL];
     for (int j = 0; j < NL; ++j) {
       const float aj = side ? R.act[NL + j] : R.act[j];
@@ -180,13 +212,10 @@ __global__ void __launch_bounds__(64) hx_env_step_kernel(SimPtrs p, const hx_sim
   env_glue<M>(p, cfg, A, n, e, writer, rng, R);
   HX_T(prof, 8);
 #if defined(HX_STEP_PROF)
-  if (prof != nullptr && threadIdx.x == 0) for (int k = 0; k < 15; ++k) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
+  if (prof != nullptr && tidx == 0) for (int k = 0; k < 15; ++k) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
 #endif
 }
 
-template <class M> static constexpr size_t env_step_lds_bytes() {
-  return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + HX_RPW * HX_PATCH_LD + 2 * HX_RPW * HX_POOL_LD + 2 * HX_RPW + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + HX_RPW * 80);
-}
 
 // Frame stacking for BOTH observation streams (hector_env.py:246-254 + clip of legged_robot.py:104-107), one
 // workgroup per env, coalesced along the rows:
@@ -272,6 +301,11 @@ struct hx_sim {
   int cur;
   float *obs_cur, *priv_cur;      // where the current observation rows live (own buffer or the learner's storage)
   int* num_reset2[2]; int parity;
+  // deferred frame stacking (hx_sim_step_deferred): frame / reset buffers in ping-pong pairs so that the next launch can
+  // still read the previous step's; what is still owed from the previous step
+  unsigned char* reset2[2]; float* priv_frame2[2]; int fpar;
+  hx_row_stack pend_priv; bool pend_priv_valid; hx_pending_step pend; bool pend_obs_valid;
+  int stack_blocks;
   unsigned char* timeout_visible;
   long long step_counter;
   uint32_t rng_step;
@@ -338,9 +372,12 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   rc |= dalloc(s, &s->p.contact, (size_t)(1 + s->nd) * 3 * n);
   rc |= dalloc(s, &s->p.bodies, 52 * n);
   rc |= dalloc(s, &s->p.obs_frame, (size_t)s->obs_f * n);
-  rc |= dalloc(s, &s->p.priv_frame, (size_t)s->priv_f * n);
+  rc |= dalloc(s, &s->priv_frame2[0], (size_t)s->priv_f * n); rc |= dalloc(s, &s->priv_frame2[1], (size_t)s->priv_f * n);
   rc |= dalloc(s, &s->p.rew, n);
-  rc |= dalloc(s, &s->p.reset, n);
+  rc |= dalloc(s, &s->reset2[0], n); rc |= dalloc(s, &s->reset2[1], n);
+  s->fpar = 0; s->p.priv_frame = s->priv_frame2[0]; s->p.reset = s->reset2[0];
+  s->pend_priv_valid = false; s->pend_obs_valid = false; s->pend.valid = 0;
+  { const char* e = getenv("HX_STACK_BLOCKS"); s->stack_blocks = (e && atoi(e) > 0) ? atoi(e) : 256; }
   rc |= dalloc(s, &s->p.timeout, n);
   rc |= dalloc(s, &s->num_reset2[0], 1); rc |= dalloc(s, &s->num_reset2[1], 1);
   s->p.num_reset = s->num_reset2[0]; s->parity = 0;
@@ -367,9 +404,9 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   }
   HX_CHECK(hipMemcpy(s->p.st, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
   // the env-step kernel keeps the height windows and the per-lane contact buffer in LDS: more than the 64 KB default
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelHector>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelHector>()));
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelFull>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelFull>()));
-  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelXBot>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)env_step_lds_bytes<ModelXBot>()));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelHector>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HX_ENV_WPB * env_step_lds_bytes<ModelHector>())));
+  if (HX_ENV_WPB * env_step_lds_bytes<ModelFull>() <= 160 * 1024) HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelFull>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HX_ENV_WPB * env_step_lds_bytes<ModelFull>())));
+  if (HX_ENV_WPB * env_step_lds_bytes<ModelXBot>() <= 160 * 1024) HX_CHECK(hipFuncSetAttribute((const void*)hx_env_step_kernel<ModelXBot>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(HX_ENV_WPB * env_step_lds_bytes<ModelXBot>())));
   if (dalloc(s, &s->cfg_d, 1)) return -3;
   HX_CHECK(hipMemcpy(s->cfg_d, &s->cfg, sizeof(hx_sim_cfg), hipMemcpyHostToDevice));
   return 0;
@@ -442,9 +479,29 @@ extern "C" void hx_sim_destroy(hx_sim* s) {
 
 struct StepOut { float* obs; float* priv; float* rew; unsigned char* done; unsigned char* timeout; };
 
-static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode, const StepOut* out) {
+// obs rows + bookkeeping of a deferred step that nobody consumed (hx_sim_step_deferred followed by a plain step)
+__global__ void __launch_bounds__(256) hx_flush_pending_kernel(hx_pending_step pd) {
+  const int e = blockIdx.x;
+  const bool rst = pd.obs.reset[e] != 0;
+  for (int k = threadIdx.x; k < pd.obs.ld; k += blockDim.x) pd.obs.dst[(size_t)e * pd.obs.ld + k] = hx_row_stack_value(pd.obs, e, rst, k);
+  if (threadIdx.x == 0) { hx_step_book_row(pd.book, e); if (e == 0) hx_step_book_global(pd.book); }
+}
+
+static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode, const StepOut* out, hx_pending_step* defer = nullptr) {
   const int n = s->cfg.num_envs;
+  if (s->pend_obs_valid) {          // a deferred step whose observation rows were never consumed: assemble them now
+    hipLaunchKernelGGL(hx_flush_pending_kernel, dim3(n), dim3(256), 0, s->stream, s->pend);
+    s->pend_obs_valid = false; s->pend.valid = 0;
+  }
   StepArgs A;
+  const int env_blocks = ((n + HX_RPW - 1) / HX_RPW + HX_ENV_WPB - 1) / HX_ENV_WPB;       // workgroups of HX_ENV_WPB waves
+  A.env_blocks = env_blocks;
+  A.stack_blocks = s->pend_priv_valid ? s->stack_blocks : 0;
+  A.pstack = s->pend_priv;
+  s->pend_priv_valid = false;
+  // this step's robots write the other halves of the frame / reset pairs; the spare workgroups read the previous step's
+  s->fpar ^= 1;
+  s->p.priv_frame = s->priv_frame2[s->fpar]; s->p.reset = s->reset2[s->fpar];
   A.mode = mode;
   if (mode == 0) s->step_counter += 1;
   A.step_counter = s->step_counter;
@@ -459,9 +516,9 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
     timed = s->ev_used + 2 <= s->ev.size();
   }
   if (timed) (void)hipEventRecord(s->ev[s->ev_used], s->stream);
-  if (s->nd == HX_XBOT_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelXBot>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelXBot>(), s->stream, s->p, s->cfg_d, actions, pack, A);
-  else if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
-  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3((n + HX_RPW - 1) / HX_RPW), dim3(64), env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (s->nd == HX_XBOT_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelXBot>, dim3(env_blocks + A.stack_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelXBot>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3(env_blocks + A.stack_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3(env_blocks + A.stack_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], s->stream); s->ev_used += 2; }
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
@@ -476,7 +533,21 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
   k.n = n; k.clip = s->cfg.clip_observations;
   k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld; k.priv_stack = s->priv_stack;
-  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
+  if (defer != nullptr) {
+    // no stacking launch: the observation rows and the bookkeeping travel to the consumer, the privileged rows to the
+    // spare workgroups of the next env-step launch
+    hx_pending_step& P = s->pend;
+    P.valid = 1;
+    P.obs = hx_row_stack{k.obs_src, k.obs_dst, k.obs_frame, k.reset, n, k.obs_f, k.obs_ld, HX_FRAME_STACK, k.clip};
+    P.book = hx_step_book{k.reset, k.timeout, k.timeout_visible, k.num_reset, k.num_reset_next, k.stat_sum, k.stat_last, k.stat_acc, k.stat_steps,
+                          k.rew, k.rew_out, k.done_out, k.timeout_out, n};
+    s->pend_obs_valid = true;
+    s->pend_priv = hx_row_stack{k.priv_src, k.priv_dst, k.priv_frame, k.reset, n, k.priv_f, k.priv_ld, k.priv_stack, k.clip};
+    s->pend_priv_valid = true;
+    *defer = P;
+  } else {
+    hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
+  }
   s->obs_cur = od; s->priv_cur = pd;
   s->parity ^= 1;
   HX_CHECK(hipGetLastError());
@@ -495,6 +566,18 @@ extern "C" int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack
   if (!actions) { hx_set_error("hx_sim_step_ex: actions is NULL"); return -2; }
   StepOut o{obs_dst, priv_dst, rew_dst, done_dst, timeout_dst};
   return launch_step(s, actions, pack, 0, &o);
+}
+
+extern "C" int hx_sim_step_deferred(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
+                                    float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst, hx_pending_step* pending) {
+  if (!s || !actions || !pending || !obs_dst || !priv_dst) { hx_set_error("hx_sim_step_deferred: null argument"); return -2; }
+  StepOut o{obs_dst, priv_dst, rew_dst, done_dst, timeout_dst};
+  return launch_step(s, actions, pack, 0, &o, pending);
+}
+extern "C" int hx_sim_pending_consumed(hx_sim* s) {
+  if (!s) { hx_set_error("hx_sim_pending_consumed: null sim"); return -2; }
+  s->pend_obs_valid = false; s->pend.valid = 0;
+  return 0;
 }
 
 extern "C" int hx_sim_buffer(hx_sim* s, int which, void** dptr) {

@@ -89,6 +89,58 @@ def test_pipelined_runner_trains(hxlib):
     env.close()
 
 
+def test_deferred_stacking_fills_the_storage_identically(hxlib, monkeypatch):
+    """HX_DEFER_STACK=1 (include/hx_sim.h hx_sim_step_deferred: observation rows assembled by the next actor launch, privileged
+    rows by spare workgroups of the next env-step launch, no stacking launch) against the default three-launch step: same
+    kernels on the same numbers in another place, so every stored array -- stacked rows, rewards, dones, the stale
+    extras["time_outs"], values -- must be equal bit for bit, and the episode statistics up to the order of their atomic sums.  Robots start near their time limit so that
+    resets (zeroed history) and the time-out bookkeeping occur inside the 16 steps."""
+    from isaac_amd.envs.configs import HectorCfg
+    from isaac_amd.envs.hector_env import HectorFreeEnv
+    from isaac_amd.algo.ppo import PPO, ActorCritic
+    from isaac_amd.utils.helpers import set_seed
+    from oracle.ppo import ActorCriticOracle
+    N, T = 200, 16                       # not a multiple of the actor's 16-row workgroups nor of the 8 robots per wave
+    init = ActorCriticOracle.default_init(np.random.default_rng(4)).state_dict()
+    res = []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("HX_DEFER_STACK", defer)
+        cfg = HectorCfg(); cfg.env.num_envs = N; cfg.seed = set_seed(9)
+        env = HectorFreeEnv(cfg)
+        ep = np.random.default_rng(1).integers(0, 2000, N).astype(np.int32)
+        ep[::7] = 2394 + (np.arange(len(ep[::7])) % 5)
+        env.episode_length_buf = ep
+        ac = ActorCritic(615, 1050, 10, [512, 256, 128], [768, 256, 128]); ac.load_state_dict(init)
+        alg = PPO(ac, num_learning_epochs=1, num_mini_batches=4, gamma=0.994, lam=0.9, learning_rate=1e-5, schedule="adaptive",
+                  desired_kl=0.01, stream=env.stream)
+        alg.init_storage(N, T, [615], [1050], [10], obs_ld=616, priv_ld=1052)
+        out = {}
+        for it in range(2):              # two rollouts: the second starts from rows the first one's last (plain) step left
+            alg.rollout([env], T)
+            alg.compute_returns(env.get_privileged_observations())
+            out.update({f"{k}{it}": alg.buffer(i, shp, dt).numpy().copy() for k, i, shp, dt in
+                        (("actions", 0, (T, N, 10), np.float32), ("values", 1, (T, N), np.float32), ("logp", 2, (T, N), np.float32),
+                         ("rewards", 4, (T, N), np.float32), ("returns", 5, (T, N), np.float32))})
+            out[f"obs{it}"] = alg.buffer(9, (T, N, 616)).numpy().copy()            # HX_PPO_BUF_OBS .. HX_PPO_BUF_TIMEOUTS
+            out[f"priv{it}"] = alg.buffer(10, (T, N, 1052)).numpy().copy()
+            out[f"dones{it}"] = alg.buffer(11, (T, N), np.uint8).numpy().copy()
+            out[f"timeouts{it}"] = alg.buffer(12, (T, N), np.uint8).numpy().copy()
+            out[f"final_obs{it}"] = env.get_observations().numpy().copy()
+            out[f"final_priv{it}"] = env.get_privileged_observations().numpy().copy()
+            alg.update()
+        info, n_ep = env.episode_stats()
+        out["stats"] = np.array([info[k] for k in sorted(info)] + [n_ep], np.float64)
+        res.append(out)
+        env.close()
+    a, b = res
+    assert a["dones0"].sum() > 0 and a["timeouts0"].sum() > 0
+    for k in a:
+        if k == "stats":      # sums of float atomics over the robots that reset: equal up to the order of the additions
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-9, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_c_rollout_equals_stepwise_api(hxlib):
     """hx_rollout (zero-copy env -> storage, fused actor kernel, deferred critic) must fill the rollout storage exactly
     like the reference-style loop  act -> env.step -> process_env_step  driven through the per-call API."""
