@@ -13,6 +13,13 @@ __global__ void k_scratch(float* p, int n) {
   for (int i = 0; i < n; ++i) s += a[(i * 7 + threadIdx.x) & 63];
   if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = s * 0.f + p[0] + 1.f;
 }
+// kernels that stay busy for a set time (wall_clock64 = 100 MHz), with the footprints of the rollout's three launches
+__global__ void k_spin(float* p, long long ticks) {
+  extern __shared__ float sm[];
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); }
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += sm[0] * 0.f + 1.f;
+}
 template <class F> static float run(const char* name, int iters, hipStream_t st, F launch) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 20; ++i) launch();
@@ -48,6 +55,18 @@ int main() {
     hipLaunchKernelGGL(k_plain, dim3(256), dim3(512), 0, st, d);
     hipLaunchKernelGGL(k_plain, dim3(512), dim3(64), 0, st, d);
     hipLaunchKernelGGL(k_plain, dim3(4096), dim3(256), 0, st, d); });
+  CK(hipFuncSetAttribute((const void*)k_spin, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  // 100 MHz ticks: 47 us, 188 us, 16 us = the undisturbed durations of actor, env step, stack kernel (sum 251 us)
+  run("busy chain: actor-like 47us -> env-like 188us -> stack-like 16us  (per 3 launches)", 300, st, [&] {
+    hipLaunchKernelGGL(k_spin, dim3(256), dim3(512), 128 * 1024, st, d, 4700LL);
+    hipLaunchKernelGGL(k_spin, dim3(512), dim3(64), 37 * 1024, st, d, 18800LL);
+    hipLaunchKernelGGL(k_spin, dim3(4096), dim3(256), 0, st, d, 1600LL); });
+  run("busy chain, all three as 256x256 without LDS                        (per 3 launches)", 300, st, [&] {
+    hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, d, 4700LL);
+    hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, d, 18800LL);
+    hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, d, 1600LL); });
+  run("one busy kernel 251us 256x256                                       (per launch)", 300, st, [&] {
+    hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, d, 25100LL); });
   hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   run("plain + event record (no timing) per launch", N, st, [&] { hipLaunchKernelGGL(k_plain, dim3(256), dim3(256), 0, st, d); (void)hipEventRecord(ev, st); });
   hipEvent_t evt; CK(hipEventCreate(&evt));
