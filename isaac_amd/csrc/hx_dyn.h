@@ -118,16 +118,10 @@ template <class M> struct SideConst {
   const float* pd;     // [NL][4] kp, kd, tau_lim, default position of this side's joints
   const int* ent;      // [NENT][3] contact-loop entries of this side
   const float* bsub;   // this lane's BASE_NSUB base sub-shapes
-  float base_reach;    // radius of a sphere about the base origin that holds all of this side's base sub-shapes
   HXD void bind(const float* l, int side) {
     lds = l; t = l + side * M::SIDE_STRIDE; bt = l + 2 * M::SIDE_STRIDE; pd = l + ModelInfo<M>::PD_OFF + side * M::NL * 4;
     ent = reinterpret_cast<const int*>(l + ModelInfo<M>::ENT_OFF) + side * ModelInfo<M>::NENT * 3;
     bsub = bt + side * M::BASE_NSUB * (4 + 3 * M::BASE_NP);
-    base_reach = 0.f;
-    for (int k = 0; k < M::BASE_NSUB; ++k) {
-      const float* sp = bsub + k * (4 + 3 * M::BASE_NP);
-      base_reach = fmaxf(base_reach, sqrtf(sp[0] * sp[0] + sp[1] * sp[1] + sp[2] * sp[2]) + sp[3]);
-    }
   }
   HXD V3 off(int b) const { return ld3(t + b * M::JSTRIDE); }
   HXD V3 h(int b) const { return ld3(t + b * M::JSTRIDE + 3); }
@@ -171,23 +165,11 @@ HXD SV rb_bias(const SI& in, V3 hh, float m, SV v) {
 // vertices the reference moved under the high ones (slope_treshold, utils/terrain.py:70-73): the low ground continues
 // flat through the cell and a vertical wall stands on the high vertices' grid line.  Such a cell returns its low level
 // here; the wall itself is handled by wall_push() for points that have crossed it.
-// The four corner heights of the cell under (u, w) and the position inside it: the memory half of terrain_query, split
-// off so that a caller can fetch the corners together with the pooled bound (one LDS round trip instead of three
-// dependent ones per contact point; the env-step kernel is latency-bound on exactly such chains).
-struct TerrainCell { float h00, h01, h10, h11, fu, fw; };
-HXD TerrainCell terrain_cell(const DynParams& P, float u, float w) {
+HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls) {
   const int i = hx_imin(hx_imax((int)floorf(u), 0), HX_PATCH - 2), j = hx_imin(hx_imax((int)floorf(w), 0), HX_PATCH - 2);
+  const float fu = fminf(fmaxf(u - (float)i, 0.f), 1.f), fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
   const float* c = P.patch + i * HX_PATCH + j;
-  TerrainCell t;
-  t.h00 = c[0]; t.h01 = c[1]; t.h10 = c[HX_PATCH]; t.h11 = c[HX_PATCH + 1];
-  t.fu = fminf(fmaxf(u - (float)i, 0.f), 1.f); t.fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
-  return t;
-}
-HXD float terrain_query_cell(const DynParams& P, const TerrainCell& t, V3& nw, bool walls);
-HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls) { return terrain_query_cell(P, terrain_cell(P, u, w), nw, walls); }
-HXD float terrain_query_cell(const DynParams& P, const TerrainCell& t, V3& nw, bool walls) {
-  const float fu = t.fu, fw = t.fw;
-  float h00 = t.h00, h01 = t.h01, h10 = t.h10, h11 = t.h11;
+  float h00 = c[0], h01 = c[1], h10 = c[HX_PATCH], h11 = c[HX_PATCH + 1];
   if (hx_any(walls)) {
     const float lo = fminf(fminf(h00, h01), fminf(h10, h11));
     if (fmaxf(fmaxf(h00, h01), fmaxf(h10, h11)) - lo > P.wall) {
@@ -329,12 +311,10 @@ HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const Con
     if (P.patch != nullptr) {
       const float u = (pb.x + dot(row(Rb, 0), r) - P.px0) * P.inv_hs, w = (pb.y + dot(row(Rb, 1), r) - P.py0) * P.inv_hs;
       const int pi = terrain_pool_index(u, w);
-      const float bound = P.pool[pi], wflag = P.poolw[pi];
-      const TerrainCell cell = terrain_cell(P, u, w);          // fetched with the bound: one round trip
-      if (!hx_any(z < bound)) continue;
-      const bool walls = wflag != 0.f;               // never set without walls (P.wall = 0)
+      if (!hx_any(z < P.pool[pi])) continue;
+      const bool walls = P.poolw[pi] != 0.f;         // never set without walls (P.wall = 0)
       V3 nw;
-      const float h = terrain_query_cell(P, cell, nw, walls);
+      const float h = terrain_query(P, u, w, nw, walls);
       pen = (h - z) * nw.z;
       if (hx_any(walls && pen > 0.f)) {
         float wp = pen; V3 wn = nw;
@@ -464,26 +444,11 @@ HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, cons
       if (K == 1) W.v[B].w.y += S.qd[B];
       if (K == 2) W.v[B].w.z += S.qd[B];
       for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
-      if constexpr (MI::slot(B) >= 0) {
-        const float gp = shape_gap(P, C.shape(B), Rc, pc);
-        gap[MI::slot(B)] = gp;
-        if (hx_any(gp < 0.f)) cb.put_body(MI::slot(B), W.v[B], Rc, pc);      // only bodies that can touch are ever read back
-      }
+      if constexpr (MI::slot(B) >= 0) { gap[MI::slot(B)] = shape_gap(P, C.shape(B), Rc, pc); cb.put_body(MI::slot(B), W.v[B], Rc, pc); }
     });
   });
-  // the base: one test for everything this side carries on it first (a sphere of radius base_reach about the base origin
-  // against the 3 x 3 pooled bound, valid up to 0.4 m); only a base that may touch looks at its sub-shapes one by one
-  bool base_near = false;
-  {
-    const float whole[4] = {0.f, 0.f, 0.f, fmaxf(C.base_reach, 0.21f)};
-    const bool look = (C.base_reach > 0.4f) || (shape_gap(P, whole, W.R0, S.pos) < 0.f);
-    if (hx_any(look)) {
-      for (int k = 0; k < M::BASE_NSUB; ++k) { gap[MI::NSHAPE + k] = shape_gap(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos); base_near = base_near || (gap[MI::NSHAPE + k] < 0.f); }
-    } else {
-      for (int k = 0; k < M::BASE_NSUB; ++k) gap[MI::NSHAPE + k] = 1.f;
-    }
-  }
-  if (hx_any(base_near)) cb.put_body(MI::NSHAPE, W.v0, W.R0, S.pos);
+  for (int k = 0; k < M::BASE_NSUB; ++k) gap[MI::NSHAPE + k] = shape_gap(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos);
+  cb.put_body(MI::NSHAPE, W.v0, W.R0, S.pos);
   uint32_t maybe = 0u;
   for (int k = 0; k < MI::NENT; ++k) maybe |= hx_any(gap[k] < 0.f) ? (1u << k) : 0u;
 #if defined(HX_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
