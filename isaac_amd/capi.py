@@ -25,6 +25,9 @@ REWARD_NAMES = ["action_smoothness", "base_acc", "base_height", "collision", "de
                 "track_vel_hard", "tracking_ang_vel", "tracking_lin_vel", "vel_mismatch_exp"]
 (BUF_OBS, BUF_PRIV, BUF_REW, BUF_RESET, BUF_TIMEOUT, BUF_TIMEOUT_VISIBLE, BUF_EP_LEN, BUF_COMMANDS, BUF_TORQUES,
  BUF_CONTACT, BUF_BODY_STATE, BUF_EPISODE_SUMS, BUF_FEET_AIR_TIME, BUF_FEET_HEIGHT, BUF_NUM_RESET) = range(15)
+# enum hx_ppo_buffer_id (include/hx_ppo.h)
+(PPO_BUF_ACTIONS, PPO_BUF_VALUES, PPO_BUF_LOGP, PPO_BUF_MU, PPO_BUF_REWARDS, PPO_BUF_RETURNS, PPO_BUF_ADVANTAGES, PPO_BUF_GRADS,
+ PPO_BUF_PERM, PPO_BUF_OBS, PPO_BUF_PRIV, PPO_BUF_DONES, PPO_BUF_TIMEOUTS) = range(13)
 
 
 class SimCfg(C.Structure):

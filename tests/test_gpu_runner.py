@@ -95,6 +95,7 @@ def test_deferred_stacking_fills_the_storage_identically(hxlib, monkeypatch):
     kernels on the same numbers in another place, so every stored array -- stacked rows, rewards, dones, the stale
     extras["time_outs"], values -- must be equal bit for bit, and the episode statistics up to the order of their atomic sums.  Robots start near their time limit so that
     resets (zeroed history) and the time-out bookkeeping occur inside the 16 steps."""
+    from isaac_amd import capi
     from isaac_amd.envs.configs import HectorCfg
     from isaac_amd.envs.hector_env import HectorFreeEnv
     from isaac_amd.algo.ppo import PPO, ActorCritic
@@ -121,10 +122,10 @@ def test_deferred_stacking_fills_the_storage_identically(hxlib, monkeypatch):
             out.update({f"{k}{it}": alg.buffer(i, shp, dt).numpy().copy() for k, i, shp, dt in
                         (("actions", 0, (T, N, 10), np.float32), ("values", 1, (T, N), np.float32), ("logp", 2, (T, N), np.float32),
                          ("rewards", 4, (T, N), np.float32), ("returns", 5, (T, N), np.float32))})
-            out[f"obs{it}"] = alg.buffer(9, (T, N, 616)).numpy().copy()            # HX_PPO_BUF_OBS .. HX_PPO_BUF_TIMEOUTS
-            out[f"priv{it}"] = alg.buffer(10, (T, N, 1052)).numpy().copy()
-            out[f"dones{it}"] = alg.buffer(11, (T, N), np.uint8).numpy().copy()
-            out[f"timeouts{it}"] = alg.buffer(12, (T, N), np.uint8).numpy().copy()
+            out[f"obs{it}"] = alg.buffer(capi.PPO_BUF_OBS, (T, N, 616)).numpy().copy()
+            out[f"priv{it}"] = alg.buffer(capi.PPO_BUF_PRIV, (T, N, 1052)).numpy().copy()
+            out[f"dones{it}"] = alg.buffer(capi.PPO_BUF_DONES, (T, N), np.uint8).numpy().copy()
+            out[f"timeouts{it}"] = alg.buffer(capi.PPO_BUF_TIMEOUTS, (T, N), np.uint8).numpy().copy()
             out[f"final_obs{it}"] = env.get_observations().numpy().copy()
             out[f"final_priv{it}"] = env.get_privileged_observations().numpy().copy()
             alg.update()
