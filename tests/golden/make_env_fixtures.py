@@ -305,7 +305,7 @@ if __name__ == "__main__":
     #    humanoid_config.py) through the same stub: 47-wide frames x 15, the 73-wide privileged frame x 3, the joint_pos reward that
     #    follows the gait reference (default pose = 0, so the term is sensitive to the reference's phase), action delay 0.5
     if want("env_rollout_h"):
-        generate("env_rollout_h", N, 80, seed=41, action_std=0.6, task="humanoid_ppo",
+        generate("env_rollout_h", N, 80, seed=41, action_std=2.0, task="humanoid_ppo",
                  ep_len_init=[795, 2396, 0, 799, 2399, 1599, 10, 2390], step_counter_init=390)
     # D: terrain curriculum (legged_robot.py:399-419) on a 3 x 2 map of 1.6 m tiles: the reset xy offset alone carries
     #    about half of the robots past env_length / 2 = 0.8 m (move up; past the last row -> a random row), the others

@@ -141,10 +141,14 @@ def test_rotated_joint_frames_on_the_xbot_model():
     s = State(n, ndof=12)
     s.root_pos[:, 2] = 0.89
     R, p, _, _ = ph.kinematics(s)
-    feet = {}
-    for body, pts in ph.contacts[1:]:
-        feet[body] = p[body][0] + pts @ R[body][0].T
-    (bl, fl), (br, fr) = sorted(feet.items())
+    world = {}
+    for body, pts in ph.contacts:
+        world.setdefault(int(body), []).append(p[body][0] + pts @ R[body][0].T)
+    world = {b: np.concatenate(v) for b, v in world.items()}
+    assert sorted(world) == [0, 3, 4, 6, 9, 10, 12]          # base (box + head + arms), thighs, calves, feet (XBot-L.urdf's enabled collisions)
+    fl, fr = world[6], world[12]
+    for b in (0, 3, 4, 9, 10):                                # nothing but the feet reaches the ground in the standing pose
+        assert world[b][:, 2].min() > 0.03, b                 # the calf mesh ends 4.8 cm above the ground, at the ankle
     assert abs(fl[:, 2].min()) < 0.01 and abs(fr[:, 2].min()) < 0.01            # soles at the ground (measured: 5 mm)
     assert fl[:, 2].max() < 0.15 and fl[:, 1].mean() > 0.05 > -0.05 > fr[:, 1].mean()
     np.testing.assert_allclose(np.sort(fl[:, 0]), np.sort(fr[:, 0]), atol=2e-3)   # mirror images in the sagittal plane

@@ -120,7 +120,7 @@ def foot_points(path):
     return out
 
 
-def collapse(urdf_path, sort_children=False):
+def collapse(urdf_path, sort_children=False, link_poses=None):
     """URDF -> list of collapsed bodies (dicts) in depth-first order.  sort_children: visit the movable children of a
     link in alphabetical order of their joint names -- the order Isaac Gym gives bodies and DoFs (the hector-with-arms
     task indexes L leg 0-4, L arm 5-8, R leg 9-13, R arm 14-17: hector_w_arm_env.py:371-373, although the URDF lists
@@ -152,6 +152,8 @@ def collapse(urdf_path, sort_children=False):
 
     def collect(name, p, R, acc):
         """Accumulate link `name` (pose p,R in the collapsed body's frame) and its fixed subtree."""
+        if link_poses is not None:
+            link_poses[name] = (len(bodies), p.copy(), R.copy())      # the body being built gets index len(bodies)
         m, c, I = link_inertial(name)
         if m > 0:
             acc.append((m, p + R @ c, R @ I @ R.T))
@@ -334,7 +336,7 @@ def emit_model_header(prefix, struct, title, bodies, contacts, nl, chains, path)
         blocks.insert(nsub if len(base_subs) > 1 else len(blocks), [0.0, 0.0, 0.0, -1.0e9] + [0.0] * (3 * base_np))
     for k in range(nl):
         if npts[k]:
-            assert sphere(by_body[1 + k])[3] <= 0.2, "side shapes must fit the 0.2 m reach of one terrain pool entry"
+            assert sphere(by_body[1 + k])[3] <= 0.4, "side shapes must fit the 0.4 m reach of the 3 x 3 terrain pool entries (hx_dyn.h shape_gap)"
     base = [v for blk in blocks for v in blk] + Io(bodies[0]) + list(bodies[0]["mass"] * np.array(bodies[0]["com"])) + [bodies[0]["mass"]]
     axis = [bodies[1 + k]["axis"] for k in range(nl)]
     assert axis == [bodies[1 + nl + k]["axis"] for k in range(nl)]
@@ -407,25 +409,58 @@ def main_full():
     print("total mass %.5f" % model["total_mass"])
 
 
+def link_collision_points(urdf, link_poses, name):
+    """Vertices of link `name`'s collision mesh in the frame of the collapsed body that carries it (None: no mesh / file)."""
+    root = ET.parse(urdf).getroot()
+    link = root.find(f"link[@name='{name}']")
+    col = link.find("collision") if link is not None else None
+    mesh = col.find("geometry").find("mesh") if col is not None and col.find("geometry") is not None else None
+    if mesh is None:
+        return None
+    path = os.path.normpath(os.path.join(os.path.dirname(urdf), mesh.get("filename")))
+    if not os.path.exists(path):          # two hand meshes are referenced as ./meshes/... in the URDF
+        path = os.path.normpath(os.path.join(os.path.dirname(urdf), "..", "meshes", os.path.basename(mesh.get("filename"))))
+    if not os.path.exists(path):
+        return None
+    _, p, R = link_poses[name]
+    co, cR = parse_origin(col.find("origin"))
+    return (stl_points(path) @ (R @ cR).T) + (p + R @ co)
+
+
 def main_xbot():
     """XBot-L (task humanoid_ppo): model data for the oracle only.  Twelve revolute joints about the local z
     of frames rotated against their parents ("rot"), upper body and hands collapsed into the base."""
     urdf = os.path.join(REF, "resources/robots/XBot/urdf/XBot-L.urdf")
-    bodies = collapse(urdf)
+    poses = {}
+    bodies = collapse(urdf, link_poses=poses)
     assert len(bodies) == 13, len(bodies)
     assert [b.get("joint") for b in bodies[1:]] == [f"{s}_{j}_joint" for s in ("left", "right") for j in
                                                     ("leg_roll", "leg_yaw", "leg_pitch", "knee", "ankle_pitch", "ankle_roll")]
     name_to_idx = {b["name"]: i for i, b in enumerate(bodies)}
+    # Collision geometry = what XBot-L.urdf enables (round 2): the base_link box; everything fixed to the base -- head,
+    # both arms with their hands -- as three groups of 8 hull support points; per leg the thigh (leg_pitch_link), the
+    # calf (knee_link) and the foot (ankle_roll_link) meshes, 8 hull support points each, in the frames of their collapsed
+    # bodies (a body turned by a negative joint axis carries its mesh turned with it: link_poses holds that turn).
     contacts = [{"body": 0, "points": box_corners((0, 0, 0.1), (0.4, 0.4, 0.4)), "source": "XBot-L.urdf base_link collision box"}]
+    groups = {"head": [], "left arm": [], "right arm": []}
+    for nm, (bi, _, _) in poses.items():
+        if bi != 0 or nm == "base_link":
+            continue
+        pts = link_collision_points(urdf, poses, nm)
+        if pts is None:
+            continue
+        groups["left arm" if nm.startswith("left_") else "right arm" if nm.startswith("right_") else "head"].append(pts)
+    for g in ("head", "left arm", "right arm"):
+        assert groups[g], g
+        contacts.append({"body": 0, "points": hull_support(np.concatenate(groups[g]), DIAG8),
+                         "source": f"{g}: {len(groups[g])} collision meshes fixed to base_link, convex-hull support points of their union"})
     for side in ("left", "right"):
-        nm = f"{side}_ankle_roll_link"
-        lo, hi = stl_bbox(os.path.join(os.path.dirname(urdf), "../meshes", nm + ".STL"))
-        b = bodies[name_to_idx[nm]]
-        # the mesh is given in the URDF link frame; a body whose frame was turned (negative axis) would need the same turn
-        # here -- the ankle_roll joints are about +z
-        assert vec(ET.parse(urdf).getroot().find(f"joint[@name='{side}_ankle_roll_joint']").find("axis").get("xyz"))[2] > 0
-        contacts.append({"body": name_to_idx[nm], "points": box_corners((lo + hi) / 2, hi - lo),
-                         "source": nm + ".STL axis-aligned bounding box", "bbox": [lo.tolist(), hi.tolist()]})
+        for link in ("leg_pitch_link", "knee_link", "ankle_roll_link"):
+            nm = f"{side}_{link}"
+            pts = link_collision_points(urdf, poses, nm)
+            assert pts is not None and poses[nm][0] == name_to_idx[nm], nm
+            contacts.append({"body": name_to_idx[nm], "points": hull_support(pts, DIAG8),
+                             "source": nm + ".STL convex-hull support points"})
     model = {"source": "resources/robots/XBot/urdf/XBot-L.urdf (collapse_fixed_joints)",
              "total_mass": sum(b["mass"] for b in bodies), "bodies": bodies, "contacts": contacts}
     with open(os.path.join(ROOT, "isaac_amd/assets/xbot_model.json"), "w") as f:
