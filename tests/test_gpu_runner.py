@@ -142,6 +142,37 @@ def test_deferred_stacking_fills_the_storage_identically(hxlib, monkeypatch):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+def test_deferred_critic_batching_does_not_change_the_values(hxlib, monkeypatch):
+    """The critic runs beside the rollout in batches of HX_CRITIC_CHUNK slots (tile shape by batch size): however the slots are
+    grouped -- one at a time, the default pairs, seven at a time (leaving a remainder for compute_returns), or all at the end --
+    values, returns and advantages must come out the same (same fp32 k order in every tile shape: bitwise)."""
+    from isaac_amd import capi
+    from isaac_amd.envs.configs import HectorCfg
+    from isaac_amd.envs.hector_env import HectorFreeEnv
+    from isaac_amd.algo.ppo import PPO, ActorCritic
+    from isaac_amd.utils.helpers import set_seed
+    from oracle.ppo import ActorCriticOracle
+    N, T = 96, 20
+    init = ActorCriticOracle.default_init(np.random.default_rng(4)).state_dict()
+    res = []
+    for chunk in ("2", "1", "7", "60"):
+        monkeypatch.setenv("HX_CRITIC_CHUNK", chunk)
+        cfg = HectorCfg(); cfg.env.num_envs = N; cfg.seed = set_seed(9)
+        env = HectorFreeEnv(cfg)
+        ac = ActorCritic(615, 1050, 10, [512, 256, 128], [768, 256, 128]); ac.load_state_dict(init)
+        alg = PPO(ac, num_learning_epochs=1, num_mini_batches=4, gamma=0.994, lam=0.9, learning_rate=1e-5, schedule="adaptive",
+                  desired_kl=0.01, stream=env.stream)
+        alg.init_storage(N, T, [615], [1050], [10], obs_ld=616, priv_ld=1052)
+        alg.rollout([env], T)
+        alg.compute_returns(env.get_privileged_observations())
+        res.append({k: alg.buffer(i, (T, N)).numpy().copy() for k, i in
+                    (("values", capi.PPO_BUF_VALUES), ("returns", capi.PPO_BUF_RETURNS), ("adv", capi.PPO_BUF_ADVANTAGES))})
+        env.close()
+    for other in res[1:]:
+        for k in res[0]:
+            np.testing.assert_array_equal(res[0][k], other[k], err_msg=k)
+
+
 def test_c_rollout_equals_stepwise_api(hxlib):
     """hx_rollout (zero-copy env -> storage, fused actor kernel, deferred critic) must fill the rollout storage exactly
     like the reference-style loop  act -> env.step -> process_env_step  driven through the per-call API."""
