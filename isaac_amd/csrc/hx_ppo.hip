@@ -280,7 +280,6 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   float* H1 = Xs + FA_ROWS * ldx;
   float* H2 = H1 + FA_ROWS * ld1;
   float* H3 = H2 + FA_ROWS * ld2;
-  float* sMu = H3 + FA_ROWS * ld3;          // [16][MAX_A]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * FA_ROWS;
   f32x4v p1a[32 / NW], p1b[32 / NW], p2a[16 / NW], p2b[16 / NW], p3a[8 / NW], p3b[8 / NW];

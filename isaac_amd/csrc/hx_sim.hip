@@ -471,9 +471,9 @@ extern "C" int hx_sim_get_terrain_levels(hx_sim* s, int32_t* levels_h) {
 extern "C" void hx_sim_destroy(hx_sim* s) {
   if (!s) return;
   (void)hipDeviceSynchronize();
-  for (void* a : s->allocs) hipFree(a);
+  for (void* a : s->allocs) (void)hipFree(a);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-  if (s->own_stream) hipStreamDestroy(s->stream);
+  if (s->own_stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
 
