@@ -4,8 +4,8 @@
 //   LeggedRobot.post_physics_step legged_robot.py:118-153 (+ callback :303-335, termination :155-160,
 //                                 rewards hector_env.py:277-539 in dir() order, reset :162-214 / :256-261,
 //                                 observations hector_env.py:172-254)
-// written per robot on whole-robot values.  On the device both lanes of a robot run it redundantly (identical inputs
-// after the lane-pair gather) and the even lane stores; on the host it runs once per robot.
+// written per robot on whole-robot values.  On the device all eight lanes of a robot run it redundantly (identical
+// inputs after the cross-side gather) and one lane stores; on the host it runs once per robot.
 #pragma once
 #include "../../include/hx_sim.h"
 #include "hx_dyn.h"

@@ -1596,9 +1596,9 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
   float* acts = s->s_actions + ((size_t)t * N + env0) * A;
   if (dual) {
     // Whole-batch rollout: only the ACTOR is on the critical path (action -> env step -> next observation).
-    // The critic's values are first needed by GAE, so the critic runs DEFERRED: every HX_CRITIC_CHUNK slots one
-    // large batch (chunk * N rows -> full-size tiles) on the second stream, where it fills the CUs that the
-    // latency-bound env-step kernels (128 waves) leave idle.
+    // The critic's values are first needed by GAE, so the critic runs DEFERRED: every critic_chunk slots one batch
+    // (chunk * N rows) on the second, lowest-priority stream, started beside the actor kernel of the step -- the env
+    // step, whose waves need a whole SIMD's registers each, is what a resident GEMM wave hurts.
     // slot t's privileged rows are in the storage; the event is only looked at by a flush (an event record costs the
     // stream ~6 us, so not every step)
     // with deferred stacking the privileged rows of slot t are assembled during env step t: a flush before it covers t - 1

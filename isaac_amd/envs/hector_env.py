@@ -464,7 +464,7 @@ class HectorFreeEnv(VecEnv):
 
 class PipelinedHectorEnv(VecEnv):
     """The same batch of robots as HectorFreeEnv(cfg), run as `num_shards` independent simulators on their own HIP
-    streams.  The env-step kernel is latency-bound (one lane pair per robot: 128 waves on 1024 SIMDs) while the
+    streams.  The env-step kernel is latency-bound (eight lanes per robot: 512 waves on 1024 SIMDs) while the
     policy GEMMs are throughput-bound, so when the runner drives the shards round-robin
     (OnPolicyRunner.learn) one shard's physics overlaps the other shards' GEMMs on the same GPU.
     Robots, random streams (Philox keyed by global env id) and results are those of the unsharded env.
