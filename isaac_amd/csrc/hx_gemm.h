@@ -50,26 +50,22 @@ __device__ __forceinline__ float hx_elu(float x) { return x > 0.f ? x : (__expf(
 #define HX_GEMM_OCC
 #endif
 // KFULL: the host guarantees that every reduction range is a whole number of K tiles (no partial-tile path in the loop)
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
-__global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM> struct GemmLds {
+  static constexpr int A_ELEMS = A_KM ? BM * (HX_BK + HX_KPAD) : HX_BK * BM;
+  static constexpr int B_ELEMS = B_KM ? BN * (HX_BK + HX_KPAD) : HX_BK * BN;
+  static constexpr int FLOATS = 2 * (A_ELEMS + B_ELEMS);
+};
+
+// One output tile (`logical` = tile index, times the split for EPI_SLAB), start to finish, by the whole workgroup.
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL>
+__device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logical, float* __restrict__ lds) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
-  constexpr int A_ELEMS = A_KM ? BM * (HX_BK + HX_KPAD) : HX_BK * BM;
-  constexpr int B_ELEMS = B_KM ? BN * (HX_BK + HX_KPAD) : HX_BK * BN;
+  constexpr int A_ELEMS = GemmLds<BM, BN, HX_BK, A_KM, B_KM>::A_ELEMS;
+  constexpr int B_ELEMS = GemmLds<BM, BN, HX_BK, A_KM, B_KM>::B_ELEMS;
   constexpr int A_LOADS = BM * HX_BK / 4 / 256;   // float4 per thread per tile
   constexpr int B_LOADS = BN * HX_BK / 4 / 256;
   constexpr bool PIPE_HALVES = (EPI == EPI_BIAS_ELU || EPI == EPI_BIAS);   // forward products only (see the main loop)
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
-
-  // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
-  // contiguous run of logical tiles so neighbours re-use the same A rows out of L2.
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  int logical;
-  {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-  }
   const int tiles_mn = g.tiles_m * g.tiles_n;
   const int split = logical / tiles_mn;
   const int t = logical % tiles_mn;
@@ -377,5 +373,33 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
   }
   if (EPI == EPI_SLAB && !A_KM) {
     if (db_owner && m0 + tid < g.M) g.dbias[((size_t)split * g.db_parts + tile_n) * g.M + m0 + tid] = dbacc;
+  }
+}
+
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
+__global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
+  // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
+  // contiguous run of logical tiles so neighbours re-use the same A rows out of L2.
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  int logical;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL>(g, logical, lds);
+}
+
+// The same product with a SMALL fixed grid whose workgroups walk the tiles (tile t, t + grid, ...).  Not faster per se
+// (profiles/README.md "persistent tiles"); its use is the background critic of the rollout: 128 workgroups settle on 128
+// CUs, one wave per SIMD there, and leave the other CUs entirely free -- an env-step wave needs a whole SIMD's registers,
+// and with an ordinary launch every SIMD of the chip soon holds a GEMM wave.
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
+__global__ void __launch_bounds__(256) hx_gemm_persistent_kernel(GemmArgs g, int total_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
+  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL>(g, t, lds);
+    __syncthreads();          // the next tile's first LDS stores must not overtake this tile's last fragment reads
   }
 }

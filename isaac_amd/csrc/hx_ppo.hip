@@ -874,6 +874,7 @@ struct hx_ppo {
   int critic_chunk;              // rollout slots per deferred critic batch (HX_CRITIC_CHUNK, default 2)
   float* apack[3]; bool apack_dirty;   // actor hidden-layer weights in MFMA fragment order for the fused rollout actor; stale after any parameter change
   int critic_late;               // 1: a deferred critic batch starts after the actor kernel of its step instead of beside it
+  int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
   int step;
@@ -996,6 +997,16 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   // the env-step kernel waited for LDS (440 us instead of 200 us on the steps a critic burst overlaps,
   // profiles/r01_j_rollout_interference.txt).
   if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // every hidden-layer forward product in bf16 mode
+  else if (background && s->bg_persist > 0) {
+    // the rollout's background critic on a small fixed grid: see hx_gemm_persistent_kernel
+    if (s->bg_tile != 128) {        // 64-row tiles: 31 KB of LDS beside the actor's 99 KB, and measured better (profiles/r02_e)
+      g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 127) / 128;
+      hipLaunchKernelGGL((hx_gemm_persistent_kernel<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>), dim3(s->bg_persist), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
+    } else {
+      g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
+      hipLaunchKernelGGL((hx_gemm_persistent_kernel<128, 128, 16, true, true, EPI_BIAS_ELU>), dim3(s->bg_persist), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
+    }
+  }
   else if (background && (s->bg_tile == 128 || (s->bg_tile == 0 && M >= 8192))) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (background && s->bg_tile == 64) launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, g, st);     // whole K tiles only
@@ -1409,6 +1420,15 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   { const char* e = getenv("HX_CRITIC_LATE"); s->critic_late = e ? atoi(e) : 0; }
   for (int l = 0; l < 3; ++l) s->apack[l] = nullptr;
   s->apack_dirty = true;
+  {
+    // Background critic on a persistent grid of HALF the CUs (one workgroup each): the env-step kernel's waves need a
+    // whole SIMD's registers, so they can only land on CUs that hold no GEMM wave at all; 4096 robots = 512 such waves =
+    // the SIMDs of the other half.  More robots than that need every CU for the env step itself: ordinary launches then.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* e = getenv("HX_BG_PERSIST");
+    s->bg_persist = e ? atoi(e) : ((cfg->num_envs <= 16 * cus) ? cus / 2 : 0);
+  }
   { const char* e = getenv("HX_BG_TILE"); s->bg_tile = e ? atoi(e) : 0; }
   { const char* e = getenv("HX_CRITIC_CHUNK"); s->critic_chunk = (e && atoi(e) > 0) ? atoi(e) : HX_CRITIC_CHUNK; }
   {
