@@ -20,6 +20,18 @@ __global__ void k_spin(float* p, long long ticks) {
   while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(8); }
   if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += sm[0] * 0.f + 1.f;
 }
+// copy kernel with the stack kernel's traffic (n floats in, n floats out), grid-stride
+__global__ void k_copy(const float* __restrict__ a, float* __restrict__ b, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<float4*>(b)[i] = reinterpret_cast<const float4*>(a)[i];
+}
+// busy kernel whose arguments are a large by-value struct (the env-step kernel takes ~800 B of pointers that way)
+struct BigArgs { float* p[100]; long long ticks; };
+__global__ void k_spin_big(BigArgs a) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < a.ticks) { __builtin_amdgcn_s_sleep(8); }
+  if (threadIdx.x == 0 && blockIdx.x == 0) a.p[blockIdx.x % 100][0] += 1.f;
+}
 template <class F> static float run(const char* name, int iters, hipStream_t st, F launch) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 20; ++i) launch();
@@ -67,6 +79,41 @@ int main() {
     hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, d, 1600LL); });
   run("one busy kernel 251us 256x256                                       (per launch)", 300, st, [&] {
     hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, d, 25100LL); });
+  // the same busy chain with realistic grids (stack-like kernel as 1024 x 256), stream launches vs one captured graph of 20 steps
+  auto chain = [&](hipStream_t q) {
+    hipLaunchKernelGGL(k_spin, dim3(256), dim3(512), 100 * 1024, q, d, 4700LL);
+    hipLaunchKernelGGL(k_spin, dim3(512), dim3(64), 37 * 1024, q, d, 18800LL);
+    hipLaunchKernelGGL(k_spin, dim3(1024), dim3(256), 0, q, d, 1600LL); };
+  run("busy chain 47 + 188 + 16 us, stream launches                  (per 3 launches)", 300, st, [&] { chain(st); });
+  {
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < 20; ++i) chain(st);
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    const float ms = run("busy chain x 20 as ONE hipGraph launch                       (per graph)", 15, st, [&] { (void)hipGraphLaunch(exec, st); });
+    printf("   -> %.2f us per 3-kernel step inside the graph\n", 1e3f * ms / 15 / 20);
+  }
+  {
+    // does the data a kernel writes cost the NEXT launch boundary?  (8 XCDs with private L2s: written lines are written back
+    // at the end of a kernel and the next kernel starts on cold L2s)
+    const size_t n = (size_t)4096 * (616 + 1052);          // the stack kernel's rows: 27 MB
+    float *a, *b; CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4)); CK(hipMemset(a, 0, n * 4));
+    const float t_copy = run("copy 27 MB -> 27 MB alone, 4096 x 256                        (per launch)", 300, st, [&] { hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, st, a, b, n); });
+    const float t_chain = run("busy 47 us -> busy 188 us -> that copy                      (per 3 launches)", 300, st, [&] {
+      hipLaunchKernelGGL(k_spin, dim3(256), dim3(512), 100 * 1024, st, d, 4700LL);
+      hipLaunchKernelGGL(k_spin, dim3(512), dim3(64), 37 * 1024, st, d, 18800LL);
+      hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, st, a, b, n); });
+    printf("   -> chain minus (235 us busy + copy alone) = %.2f us\n", 1e3f * (t_chain / 300) - 235.f - 1e3f * (t_copy / 300));
+  }
+  {
+    BigArgs ba; for (int i = 0; i < 100; ++i) ba.p[i] = d; ba.ticks = 4700LL;
+    BigArgs bb = ba; bb.ticks = 18800LL; BigArgs bc = ba; bc.ticks = 1600LL;
+    run("busy chain 47 + 188 + 16 us, 808-byte by-value arguments      (per 3 launches)", 300, st, [&] {
+      hipLaunchKernelGGL(k_spin_big, dim3(256), dim3(512), 0, st, ba);
+      hipLaunchKernelGGL(k_spin_big, dim3(512), dim3(64), 0, st, bb);
+      hipLaunchKernelGGL(k_spin_big, dim3(1024), dim3(256), 0, st, bc); });
+  }
   hipEvent_t ev; CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   run("plain + event record (no timing) per launch", N, st, [&] { hipLaunchKernelGGL(k_plain, dim3(256), dim3(256), 0, st, d); (void)hipEventRecord(ev, st); });
   hipEvent_t evt; CK(hipEventCreate(&evt));
