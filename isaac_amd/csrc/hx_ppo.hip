@@ -874,6 +874,7 @@ struct hx_ppo {
   int critic_chunk;              // rollout slots per deferred critic batch (HX_CRITIC_CHUNK, default 2)
   float* apack[3]; bool apack_dirty;   // actor hidden-layer weights in MFMA fragment order for the fused rollout actor; stale after any parameter change
   int critic_late;               // 1: a deferred critic batch starts after the actor kernel of its step instead of beside it
+  int fwd_in_tile;               // rows per tile of the input layers' forward products at update size (HX_FWD_IN_TILE, 128 or 64)
   int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
@@ -1010,6 +1011,10 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   else if (background && (s->bg_tile == 128 || (s->bg_tile == 0 && M >= 8192))) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (background && s->bg_tile == 64) launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
   else if (M >= 16384 && K % 32 == 0) launch_gemm<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, g, st);     // whole K tiles only
+  // the two input layers (K = 616 / 1052, not multiples of 32) at update size: 128-row BK16 tiles -- 2880 tiles on 768 slots
+  // (3.75 rounds) against 5760 on 1280 (4.5 rounds) for the critic's; re-measured in round 2: update 31.9 -> 31.6 ms
+  // (profiles/r02_l_fwd_input_tiles.txt; HX_FWD_IN_TILE=64 restores the round-1 choice)
+  else if (M >= 16384 && s->fwd_in_tile == 128) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU>(s, g, st);
   else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>(s, g, st);
 }
 static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, const float* W, int ldw, const float* H, float* dX, int M, int N, int K,
@@ -1429,6 +1434,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     const char* e = getenv("HX_BG_PERSIST");
     s->bg_persist = e ? atoi(e) : ((cfg->num_envs <= 16 * cus) ? cus / 2 : 0);
   }
+  { const char* e = getenv("HX_FWD_IN_TILE"); s->fwd_in_tile = (e && atoi(e) == 64) ? 64 : 128; }
   { const char* e = getenv("HX_BG_TILE"); s->bg_tile = e ? atoi(e) : 0; }
   { const char* e = getenv("HX_CRITIC_CHUNK"); s->critic_chunk = (e && atoi(e) > 0) ? atoi(e) : HX_CRITIC_CHUNK; }
   {
