@@ -6,6 +6,12 @@ library is missing or fails to load the import raises -- there is no CPU or PyTo
 import ctypes as C
 import os
 
+# Kernel arguments in device memory instead of host-coherent memory: the rollout is a chain of ~180 dependent launches per
+# iteration and every launch reads its arguments first; with host-side kernargs the chain is 0.6 ms per iteration slower
+# (profiles/r02_e_critic_chunk.txt).  The default of recent ROCm releases on this part; made explicit here, before the HIP
+# runtime of this process initialises.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
