@@ -1093,6 +1093,18 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
     HX_CHECK(hipGetLastError());
     return 0;
   }
+  if (mode == 8 || mode == 9) {      // forward product on the persistent grid of the rollout's background critic (8: 64-row, 9: 128-row tiles)
+    const int grid = 7;              // deliberately small and odd: every workgroup walks many tiles, the last round is ragged
+    if (mode == 8) {
+      g.tiles_m = (M + 63) / 64; g.tiles_n = (N + 127) / 128;
+      hipLaunchKernelGGL((hx_gemm_persistent_kernel<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>), dim3(grid), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
+    } else {
+      g.tiles_m = (M + 127) / 128; g.tiles_n = (N + 127) / 128;
+      hipLaunchKernelGGL((hx_gemm_persistent_kernel<128, 128, 16, true, true, EPI_BIAS_ELU>), dim3(grid), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
+    }
+    HX_CHECK(hipGetLastError());
+    return 0;
+  }
   const int variant = mode / 10;     // 0: BK 16, 1: BK 32
   mode %= 10;
 #define HX_DISPATCH(BKV)                                                                                   \

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def _run(hxlib, mode, M, N, K, rng):
     r4 = lambda x: (x + 3) // 4 * 4
-    if mode in (0, 3):      # FWD: Y = elu(X W^T + b); X [M][K], W [N][K]
+    if mode in (0, 3, 8, 9):      # FWD: Y = elu(X W^T + b); X [M][K], W [N][K]  (8 / 9: on the persistent grid)
         lda, ldb, ldc = r4(K), r4(K), N
         A = np.zeros((M, lda), np.float32); A[:, :K] = rng.standard_normal((M, K))
         B = np.zeros((N, ldb), np.float32); B[:, :K] = rng.standard_normal((N, K)) / np.sqrt(K)
@@ -59,6 +59,12 @@ def _run(hxlib, mode, M, N, K, rng):
     (2, 512, 616, 2048), (2, 768, 1052, 1000), (2, 128, 256, 960), (2, 100, 36, 77),
 ])
 def test_gemm_modes(hxlib, mode, M, N, K):
+    _run(hxlib, mode, M, N, K, np.random.default_rng(mode * 1000 + M + N + K))
+
+
+@pytest.mark.parametrize("mode,M,N,K", [(8, 8192, 768, 1052), (8, 1000, 256, 768), (8, 70, 100, 36), (9, 8192, 256, 256), (9, 333, 130, 615)])
+def test_persistent_forward(hxlib, mode, M, N, K):
+    """The background critic's persistent-grid forward product (hx_gemm_persistent_kernel; 7 workgroups walking all tiles)."""
     _run(hxlib, mode, M, N, K, np.random.default_rng(mode * 1000 + M + N + K))
 
 
