@@ -10,10 +10,12 @@ store} for `--envs` (default 4096) robots per GPU, then GAE and the PPO update (
 value = num_steps_per_env * num_envs * n_gpus * K / max-over-ranks(elapsed)      [env-steps / s, whole job]
        = the reference's own `Perf/total_fps` (on_policy_runner.py:199-203).
 
-Launch: `python bench.py` (1 GPU) or
+Launch: `python bench.py` (1 GPU), or for N GPUs of one node either
         `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
-         bench.py --gpus N --steps K --warmup W`   (one rank per GPU, weak scaling: 4096 envs on every rank,
-         one RCCL all-reduce of the flat gradient per optimiser step).
+         bench.py --gpus N --steps K --warmup W`   (the driver's form), or simply
+        `python bench.py --gpus N --steps K --warmup W`: without WORLD_SIZE in the environment this process starts the N
+         ranks itself as child processes (before it touches the GPU or the library; never by exec) and relays rank 0's line.
+        One rank per GPU, weak scaling: 4096 envs on every rank, one RCCL all-reduce of the flat gradient per optimiser step.
 """
 import argparse
 import json
@@ -30,40 +32,41 @@ FLOP_PER_ENV_STEP = 16_772_066            # dense MLP flops, rol
 PEAK_F32_MFMA_TFLOPS = 157.3              # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 
 
-def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of `kernel_name` from the committed PMC pass (profiles/*_traffic.json, written by
-    tools/collect_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same
-    command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The counters cannot be read live
-    from inside the timed run, so the newest committed file for the default workload is reported; None if absent."""
+def _committed(pattern, build_id):
+    """Newest committed measurement file under profiles/ matching `pattern` that was taken ON THIS BUILD: the file's
+    "build_id" (written by tools/collect_*.py from hx_build_id()) must equal the running library's.  A file from another
+    build describes other kernels -- it is refused (None), never reported beside this run's timings."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        k = d["kernels"][kernel_name]
-        return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], {
-            "unit": "bytes per launch (fetch + write)", "fetch_bytes": k["fetch_bytes_per_launch"], "write_bytes": k["write_bytes_per_launch"],
-            "launches_sampled": k["launches_sampled"], "source": "profiles/" + os.path.basename(files[-1])}
-    except Exception:
-        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if d.get("build_id") == build_id:
+            d["source"] = "profiles/" + os.path.basename(path)
+            return d
+    return None
 
 
-def pmc_env_step():
-    """Wave-level VALU instructions per launch of the env-step kernel from the committed PMC pass (profiles/*_env_step_pmc.json,
-    `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` on this command); None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_env_step_pmc.json")))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        d["source"] = "profiles/" + os.path.basename(files[-1])
-        return d
-    except Exception:
-        return None
+def pmc_traffic(kernel_symbol, build_id):
+    """HBM-side bytes per launch of `kernel_symbol` from the committed PMC pass (profiles/*_traffic.json, written by
+    tools/collect_traffic.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The counters cannot be read live from inside the
+    timed run; None unless a file of this very build (hx_build_id) holds this very symbol."""
+    d = _committed("*_traffic.json", build_id)
+    k = (d or {}).get("kernels", {}).get(kernel_symbol)
+    if not k:
+        return None, None
+    return k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"], {
+        "unit": "bytes per launch (fetch + write)", "fetch_bytes": k["fetch_bytes_per_launch"], "write_bytes": k["write_bytes_per_launch"],
+        "launches_sampled": k["launches_sampled"], "source": d["source"], "build_id": d["build_id"]}
+
+
+def pmc_env_step(build_id):
+    """Wave-level VALU instructions per launch of the env-step kernel from the committed PMC pass of this build
+    (profiles/*_env_step_pmc.json, `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` on this command); None otherwise."""
+    return _committed("*_env_step_pmc.json", build_id)
 
 
 def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_rows=16384):
@@ -133,6 +136,49 @@ def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_ro
             "env_only_env_steps_per_s": n / full["s_per_step"], "omp10": {"value": v_ten, "env_only_env_steps_per_s": n / ten["s_per_step"], "cores": 10}}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children of this process, which itself never
+    initialises HIP (no capi / build call has happened yet).  Rank 0's stdout -- the one JSON line -- is relayed to ours,
+    every other stream goes to stderr.  A rank that dies takes the job down: the others are given 20 s to notice (their
+    collectives time out by themselves, include/hx_ppo.h) and are then terminated.  Exit code = the first non-zero one."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)         # no launcher agent here: rank 0 serves the rendezvous store
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad and deadline is None:
+            rc, deadline = bad[0], time.time() + 20.0
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 1e9
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0].decode() if isinstance(out0[0], bytes) else out0[0])
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +201,15 @@ def main():
                          "to see what the distributed orchestration costs before any link time")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))          # launcher mode: nothing below runs in this process
+    if os.environ.get("HX_BENCH_CHILD_PROBE"):            # tests/test_host_logic.py: what a spawned rank sees, without a GPU
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+        if os.environ.get("HX_BENCH_CHILD_PROBE") == "fail" + os.environ.get("RANK", ""):
+            raise SystemExit(3)
+        if os.environ.get("HX_BENCH_CHILD_PROBE", "").startswith("fail"):
+            time.sleep(600)                               # a healthy rank waiting for a peer that died: the launcher must end it
+        raise SystemExit(0)
 
     import contextlib
     # stdout carries exactly one line: the result JSON.  Python-level prints go to stderr, and so does file descriptor 1
@@ -174,9 +229,9 @@ def main():
     from isaac_amd.utils.helpers import set_seed
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus != 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    if world != args.gpus and args.gpus != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus {args.gpus}` (self-spawning) or "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     if args.force_collectives and world == 1:
         from isaac_amd.parallel import HxComm
         comm = HxComm(rank=0, world_size=1, local_rank=0)      # one rank, real RCCL: every collective of the N > 1 path runs
@@ -258,14 +313,15 @@ def main():
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])
             achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            traffic, traffic_detail = pmc_traffic(k["name"]) if (args.envs == 4096 and args.terrain == "trimesh" and args.shards == 1 and not full) else (None, None)
+            build_id = capi.lib().hx_build_id().decode()
+            traffic, traffic_detail = pmc_traffic(k["name"], build_id) if (args.envs == 4096 and args.terrain == "trimesh" and args.shards == 1 and not full) else (None, None)
             # bf16 mode: the same kernel ids run on the bf16 matrix cores (dense peak 2.5 PFLOP/s); with fp32 operands in HBM
             # those products are memory-bound, which is what the small fraction of that peak says
             peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else 2500.0
             out["roofline"] = {"bound": "mfma", "kernel": k["name"] + ("" if args.dtype == "f32" else " [bf16 operands]"), "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic if args.dtype == "f32" else None,
                                "traffic_detail": traffic_detail,
-                               "launches": k["launches"], "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
+                               "build_id": build_id, "launches": k["launches"], "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
                                "flop_per_launch": k["flops"] / max(1, k["launches"]),
                                "all_gemm_kernels": (prof_all or prof)["kernels"],
                                "all_gemm_kernels_from": "warm-up iterations (every launch on the learner's stream bracketed; the deferred critic's background launches overlap the rollout and are not)" if prof_all else "timed region",
@@ -274,7 +330,7 @@ def main():
             # the env-step kernel: top kernel of the rollout, bound by VALU issue (it reads and writes ~1.3 KB per robot).
             # peak = one wave64 VALU instruction per SIMD every 4 cycles at 2.4 GHz on 1024 SIMDs
             us = 1e3 * env_step_ms[0] / env_step_ms[1]
-            pmc = None if full else pmc_env_step()
+            pmc = None if full else pmc_env_step(capi.lib().hx_build_id().decode())
             peak = 1024 * 2.4e9 / 4
             es = {"kernel": "hx_env_step_kernel", "bound": "valu-issue", "launches": int(env_step_ms[1]), "avg_launch_us": us,
                   "measured_in": env_step_from, "waves": (args.envs + 7) // 8, "peak_wave_insts_per_s": peak, "valu_insts_per_launch": None, "achieved_wave_insts_per_s": None, "frac": None}

@@ -1,0 +1,45 @@
+/* hx_lab.h -- measurement and unit-test hooks of libhx.so.  NOT part of the drop-in boundary: a maintainer binding the
+ * library for the reference's VecEnv / PPO seams needs include/hx_sim.h and include/hx_ppo.h only (INTEGRATION.md cites
+ * nothing from this file).  These entry points exist so that every number under profiles/ can be reproduced and so that
+ * the GEMM kernels can be tested in isolation; they change no result of the product path. */
+#ifndef HX_LAB_H
+#define HX_LAB_H
+#include <stdint.h>
+#include "hx_ppo.h"
+#include "hx_sim.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP-event timing of the learner's GEMM launches on the learner's stream, ONE row per kernel symbol, named exactly as
+ * rocprofv3 prints it (e.g. "hx_gemm_kernel<128, 128, 16, false, false, 2, true, false, false>"), so a row here and a row of
+ * `rocprofv3 --kernel-trace --stats` are the same launches.  hx_ppo_prof_begin(p, NULL) brackets every symbol;
+ * (p, symbol) only that one (an event pair costs ~1 us of GPU time per bracketed launch).  The deferred critic's launches
+ * on the background stream are never bracketed (they overlap the rollout's kernels).  hx_ppo_prof_end stops and returns
+ * the rows with at least one launch. */
+typedef struct hx_prof_row { char symbol[128]; double ms; int64_t launches; double flops; } hx_prof_row;
+int hx_ppo_prof_begin(hx_ppo* p, const char* only_symbol /*nullable*/);
+int hx_ppo_prof_end(hx_ppo* p, hx_prof_row* rows_h, int max_rows, int* n_rows);
+
+/* unit-test hook: one GEMM of the given mode (0/3 fwd bias+ELU 128/64-row tile, 1/4 dgrad * elu', 2 wgrad single
+ * split; add 10 for the BK = 32 variant; 5-9: bf16 and persistent-grid variants, tests/test_gpu_gemm.py) */
+int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     const float* bias, float* C, int ldc, const float* H, void* hip_stream);
+/* timing hook: mean ms per launch of one learner GEMM (kind 0 fwd, 1 dgrad, 2 wgrad split-K; bk 16 or 32) */
+int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out);
+/* measurement hook: TFLOP/s of 256-thread workgroups whose waves issue n v_mfma_f32_32x32x2_f32 each with, by mode,
+ * 0 nothing else, 1 + the GEMM's LDS fragment reads, 2 + a barrier per BK=16 tile, 3 + the tile's global loads and LDS
+ * stores -- where between the matrix-pipe peak and the GEMM kernels the throughput goes (tools/mfma_peak.py) */
+int hx_mfma_probe(int mode, int blocks, int n, float* tflops_out);
+
+/* HIP-event time of the env-step kernel launches on the simulator's stream; which = 1 start / clear, 0 stop and read
+ * {total milliseconds, launches} (bench.py: the live duration behind roofline.env_step) */
+int hx_sim_time(hx_sim* s, int which, double* out_h /*[2]*/);
+/* per-phase shader-clock cycles of the env-step kernel, summed over waves and launches; meaningful only in a library
+ * built with -DHX_STEP_PROF (tools/step_prof.py), all zeros otherwise.  which = 1 start / clear, 0 read. */
+int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[15]: 9 phase timers, then shape-visit counts*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -108,7 +108,14 @@ int hx_ppo_adv_normalize(hx_ppo* p);
  * advantage moments on the same stream first, so that the normalisation (rollout_storage.py:135-136) is the one a single
  * process would compute over all ranks' rows.  Nothing synchronises with the host.  Every rank sees the same global KL, so
  * the learning-rate decision (ppo.py:136-148) and with it the parameters stay bit-identical without a broadcast;
- * hx_ppo_broadcast_params makes them identical once at start-up. */
+ * hx_ppo_broadcast_params makes them identical once at start-up.
+ * Binding and failure behaviour: librccl.so.1 is resolved at run time -- the copy the process already maps (PyTorch's) if
+ * there is one (dlopen RTLD_NOLOAD), else the system's -- and must report the NCCL API major version this library was built
+ * against (ncclGetVersion; hx_comm_library_info).  No wait is unbounded: hx_comm_init returns an error if ncclCommInitRank
+ * has not come back after HX_COMM_INIT_TIMEOUT_S (300 s), and every host synchronisation with a stream that carries
+ * collectives goes through hx_comm_wait, which after HX_COMM_TIMEOUT_S (120 s) or on an asynchronous RCCL error aborts the
+ * communicator (ncclCommAbort) and returns an error naming the rank -- the process is expected to exit non-zero then; the
+ * launcher may start a fresh one (a process that has touched the GPU is never re-exec'd). */
 #define HX_COMM_ID_BYTES 128
 enum { HX_COMM_F32 = 0, HX_COMM_F64 = 1 };
 enum { HX_COMM_SUM = 0, HX_COMM_MAX = 1 };
@@ -121,6 +128,13 @@ int hx_comm_world(hx_comm* c);
 /* in-place collectives on device buffers for the host's bookkeeping (barrier, max-over-ranks timing, episode statistics) */
 int hx_comm_all_reduce(hx_comm* c, void* buf, size_t count, int dtype, int op, void* hip_stream);
 int hx_comm_broadcast(hx_comm* c, void* buf, size_t count_f32, int root, void* hip_stream);
+/* wait for everything enqueued on hip_stream with a deadline (timeout_s <= 0: the communicator's HX_COMM_TIMEOUT_S);
+ * c == NULL: plain stream synchronisation */
+int hx_comm_wait(hx_comm* c, void* hip_stream, double timeout_s);
+int hx_comm_library_info(int* nccl_version, int* shared_copy /*1: the process had librccl.so.1 mapped already*/);
+/* ranks that split ONE logical batch pass the global index of their first env row: the action-noise stream is keyed by the
+ * global row then, so the job samples what a single process on the union of the shards would (tests/test_gpu_dp.py) */
+int hx_ppo_set_row_base(hx_ppo* p, uint32_t first_global_row);
 int hx_ppo_set_comm(hx_ppo* p, hx_comm* c /*NULL: back to single process*/);
 int hx_ppo_broadcast_params(hx_ppo* p, int root);
 
@@ -146,23 +160,6 @@ int hx_ppo_buffer(hx_ppo* p, int which, void** dptr);
 int hx_ppo_get_lr(hx_ppo* p, float* lr_h);
 int hx_ppo_set_lr(hx_ppo* p, float lr);
 int hx_ppo_inference(hx_ppo* p, const float* obs, int rows, float* actions_out);
-/* HIP-event timing of the GEMM kernels on the learner's stream (events recorded on that stream around every
- * launch): which=1 starts/clears for all five kernel symbols, which = 0x100 | mask only for the symbols whose bit is
- * set in mask (the event pairs cost ~1 us of GPU time per bracketed launch), which=0 stops and returns, per kernel symbol
- * {fwd 128x128, fwd 64x128, dgrad 128x128, dgrad 64x128, wgrad split-K}: {milliseconds, launches, flops} */
-int hx_ppo_prof(hx_ppo* p, int which, double* out_h /*[15]*/, void* reserved);
-/* unit-test hook: one GEMM of the given mode (0/3 fwd bias+ELU 128/64-row tile, 1/4 dgrad * elu', 2 wgrad single
- * split); add 10 for the BK = 32 variant */
-int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                     const float* bias, float* C, int ldc, const float* H, void* hip_stream);
-
-/* timing hook: mean ms per launch of one learner GEMM (kind 0 fwd, 1 dgrad, 2 wgrad split-K; bk 16 or 32) */
-int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out);
-/* measurement hook: TFLOP/s of 256-thread workgroups whose waves issue n v_mfma_f32_32x32x2_f32 each with, by mode,
- * 0 nothing else, 1 + the GEMM's LDS fragment reads, 2 + a barrier per BK=16 tile, 3 + the tile's global loads and LDS
- * stores -- where between the matrix-pipe peak and the GEMM kernels the throughput goes (tools/mfma_peak.py) */
-int hx_mfma_probe(int mode, int blocks, int n, float* tflops_out);
-
 /* device memory helpers for hosts without a tensor library */
 int hx_malloc(size_t bytes, void** out);
 int hx_free(void* ptr);

@@ -218,13 +218,10 @@ int hx_sim_get_base_velocities(hx_sim* s, float* lin_h, float* ang_h);
  * of the last <= 100 finished episodes (the rewbuffer / lenbuffer deques, on_policy_runner.py:112-113,140-154).
  * count_h: episodes finished since the last call.  The call starts a new iteration's accumulation. */
 int hx_sim_episode_stats(hx_sim* s, float* mean_h /*[HX_NUM_REWARDS + 2]*/, int32_t* count_h);
-/* measurement hook: HIP-event time of the env-step kernel launches on the simulator's stream; which = 1 start / clear,
- * 0 stop and read {total milliseconds, launches} */
-int hx_sim_time(hx_sim* s, int which, double* out_h /*[2]*/);
 void* hx_sim_stream(hx_sim* s);
-/* measurement hook: per-phase shader-clock cycles of the env-step kernel, summed over waves and launches; meaningful only in a
- * library built with -DHX_STEP_PROF (tools/step_prof.py), all zeros otherwise.  which = 1 start / clear, 0 read. */
-int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[15]: 9 phase timers, then shape-visit counts*/);
+/* identity of this build: "<version>-<first 16 hex digits of the SHA-256 over the library's sources>" (isaac_amd/build.py);
+ * measurement files under profiles/ name the build they were taken on with it */
+const char* hx_build_id(void);
 int hx_sync(void* hip_stream);
 
 #ifdef __cplusplus

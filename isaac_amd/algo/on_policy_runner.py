@@ -55,7 +55,13 @@ class OnPolicyRunner:
         # parameters are bit-identical to rank 0's); Episode/* and Train/* scalars are summed over ranks in log()
         self.is_chief = comm is None or comm.rank == 0
         self.log_dir = log_dir if self.is_chief else None
-        self.collect_stats = log_dir is not None
+        # Episode statistics are a COLLECTIVE when data parallel (every rank must take part or none), so the decision cannot
+        # depend on a per-rank argument: the common idiom `log_dir if rank == 0 else None` would leave rank 0 alone inside
+        # an all-reduce.  Decided once, here, from the maximum of the flag over ranks.
+        want = 1.0 if log_dir is not None else 0.0
+        if comm is not None and comm.world_size > 1:
+            want = comm.max_over_ranks(want)
+        self.collect_stats = want > 0.0
         self.writer = None
         self.tot_timesteps = 0
         self.tot_time = 0
@@ -153,15 +159,29 @@ class OnPolicyRunner:
             self.save(os.path.join(self.log_dir, "model_{}.pt".format(self.current_learning_iteration)))
 
     def _episode_stats_all_ranks(self):
-        """Episode/* and Train/* scalars over the envs of ALL ranks (mean of the per-rank values: every rank owns the same
-        number of envs).  A collective when world_size > 1, so every rank calls it."""
+        """Episode/* and Train/* scalars over the envs of ALL ranks.  A collective when world_size > 1, so every rank calls
+        it: ONE all-reduce of a packed vector [n_ep | n_ep * value ...], i.e. the means are weighted by the number of
+        episodes each rank finished in this iteration (a rank without finished episodes contributes nothing instead of a
+        stale value)."""
         info, n_ep = self.env.episode_stats()
         self._train_stats = (self.env.last_episode_return, self.env.last_episode_length)
         if self.comm is not None and self.comm.world_size > 1:
-            w = float(self.comm.world_size)
-            info = {k: self.comm.sum_over_ranks(v) / w for k, v in info.items()}
-            self._train_stats = tuple(self.comm.sum_over_ranks(v) / w for v in self._train_stats)
-            n_ep = int(self.comm.sum_over_ranks(n_ep))
+            keys = sorted(info)
+            w = float(n_ep)
+            vec = np.array([w, 1.0] + [w * float(info[k]) for k in keys] + [float(info[k]) for k in keys]
+                           + [w * float(v) for v in self._train_stats] + [float(v) for v in self._train_stats], np.float64)
+            tot = self.comm.sum_array_over_ranks(vec)
+            n_all, ranks, nk = tot[0], tot[1], len(keys)
+            wsum, usum = tot[2:2 + nk], tot[2 + nk:2 + 2 * nk]
+            tw, tu = tot[2 + 2 * nk:4 + 2 * nk], tot[4 + 2 * nk:6 + 2 * nk]
+            if n_all > 0:
+                # terrain_level is a mean over ALL robots (legged_robot.py:203-204), not over finished episodes
+                info = {k: float(usum[i] / ranks if k == "terrain_level" else wsum[i] / n_all) for i, k in enumerate(keys)}
+                self._train_stats = tuple(float(x / n_all) for x in tw)
+            else:                       # nobody finished an episode: plain mean of the (persisting) per-rank values
+                info = {k: float(usum[i] / ranks) for i, k in enumerate(keys)}
+                self._train_stats = tuple(float(x / ranks) for x in tu)
+            n_ep = int(round(n_all))
         return info, n_ep
 
     def log(self, locs, width=80, pad=35):

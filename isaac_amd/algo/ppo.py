@@ -370,23 +370,18 @@ class PPO:
     def load_rng_state(self, act_counter, perm_counter):
         capi.check(self._L.hx_ppo_set_rng_state(self._h, int(act_counter), int(perm_counter)), "set_rng_state")
 
-    PROF_KERNELS = ["hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)", "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
-                    "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)", "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
-                    "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"]
-
     def prof_begin(self, only=None):
-        """Bracket GEMM launches with HIP events on the learner's stream.  only: a kernel name of PROF_KERNELS to bracket
-        just that symbol (each event pair costs about a microsecond of GPU time, 1.5 % of an iteration when every GEMM
-        launch carries one)."""
-        which = 1 if only is None else (0x100 | (1 << self.PROF_KERNELS.index(only)))
-        capi.check(self._L.hx_ppo_prof(self._h, which, None, None), "prof")
+        """Bracket the learner's GEMM launches with HIP events on its stream (include/hx_lab.h).  only: a kernel symbol as
+        returned by prof_end -- the rocprofv3 name, template arguments included -- to bracket just that symbol (each event
+        pair costs about a microsecond of GPU time, 1.5 % of an iteration when every GEMM launch carries one)."""
+        capi.check(self._L.hx_ppo_prof_begin(self._h, None if only is None else only.encode()), "prof_begin")
 
     def prof_end(self):
-        out = np.zeros(15, np.float64)
-        capi.check(self._L.hx_ppo_prof(self._h, 0, capi.ptr(out), None), "prof")
-        names = self.PROF_KERNELS
-        ks = [dict(name=names[k], ms=float(out[3 * k]), launches=int(out[3 * k + 1]), flops=float(out[3 * k + 2]))
-              for k in range(5) if out[3 * k + 1] > 0]
+        rows = (capi.ProfRow * 64)()
+        n = capi.C.c_int(0)
+        capi.check(self._L.hx_ppo_prof_end(self._h, rows, 64, capi.C.byref(n)), "prof_end")
+        ks = [dict(name=rows[i].symbol.decode(), ms=float(rows[i].ms), launches=int(rows[i].launches), flops=float(rows[i].flops))
+              for i in range(min(n.value, 64))]
         for k in ks:
             k["tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         return dict(kernels=ks)

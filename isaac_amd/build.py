@@ -6,8 +6,21 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("hx_sim.hip", "hx_ppo.hip", "hx_comm.hip")]
 HDR = [os.path.join(HERE, "csrc", f) for f in ("hx_math.h", "hx_dyn.h", "hx_env.h", "hx_gemm.h", "hx_gemm_bf16.h", "hx_common.h", "hx_model_data.h", "hx_model_data_full.h", "hx_model_data_xbot.h")] + \
-      [os.path.join(os.path.dirname(HERE), "include", f) for f in ("hx_sim.h", "hx_ppo.h")]
+      [os.path.join(os.path.dirname(HERE), "include", f) for f in ("hx_sim.h", "hx_ppo.h", "hx_lab.h")]
 OUT = os.path.join(HERE, "libhx.so")
+
+
+def source_hash():
+    """First 16 hex digits of the SHA-256 over every source and header of the library (names and contents, fixed order):
+    the identity of a build.  Compiled into libhx.so (hx_build_id) and written into the measurement files under profiles/,
+    so that bench.py can tell whether a PMC file belongs to the build that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SRC + HDR):
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 # per-file flags chosen by measurement (profiles/): see DESIGN.md "Env-step kernel"
 EXTRA_FLAGS = {
     # env-step kernel: SLP-packing fp32 into v_pk_* costs more register moves and spills than it saves in this
@@ -21,7 +34,13 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in SRC + HDR)
+    if any(os.path.getmtime(f) > t for f in SRC + HDR):
+        return True
+    try:                       # same timestamps but other contents (a checkout, a copied tree): the stamp decides
+        with open(OUT + ".id") as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
@@ -46,12 +65,15 @@ def _build_locked(force, verbose):
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-array-bounds"]
         cmd += EXTRA_FLAGS.get(os.path.basename(src), [])
         cmd += os.environ.get("HX_EXTRA_FLAGS_" + os.path.basename(src).split(".")[0].upper(), "").split()
+        cmd += ['-DHX_BUILD_ID="' + source_hash() + '"']
         cmd += ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", OUT])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-lpthread", "-o", OUT])
+    with open(OUT + ".id", "w") as f:
+        f.write(source_hash() + "\n")
     return OUT
 
 

@@ -73,6 +73,10 @@ class PpoCfg(C.Structure):
     ]
 
 
+class ProfRow(C.Structure):          # include/hx_lab.h hx_prof_row
+    _fields_ = [("symbol", C.c_char * 128), ("ms", C.c_double), ("launches", C.c_int64), ("flops", C.c_double)]
+
+
 _lib = None
 
 
@@ -88,6 +92,7 @@ def lib():
     vp, f32p, i32p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.hx_last_error.restype = C.c_char_p
     L.hx_version.restype = C.c_int
+    L.hx_build_id.restype = C.c_char_p
     L.hx_sync.argtypes = [vp]
     L.hx_sim_create.argtypes = [C.POINTER(SimCfg), vp, vp, vp, vp, C.c_uint64, vp, C.POINTER(vp)]
     L.hx_sim_destroy.argtypes = [vp]
@@ -150,7 +155,10 @@ def lib():
     L.hx_comm_world.argtypes = [vp]
     L.hx_comm_all_reduce.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     L.hx_comm_broadcast.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    L.hx_comm_wait.argtypes = [vp, vp, C.c_double]
+    L.hx_comm_library_info.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hx_ppo_set_comm.argtypes = [vp, vp]
+    L.hx_ppo_set_row_base.argtypes = [vp, C.c_uint32]
     L.hx_ppo_broadcast_params.argtypes = [vp, C.c_int]
     L.hx_ppo_update_begin.argtypes = [vp, vp]
     L.hx_ppo_minibatch_backward.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -165,7 +173,8 @@ def lib():
     L.hx_ppo_get_lr.argtypes = [vp, vp]
     L.hx_ppo_set_lr.argtypes = [vp, C.c_float]
     L.hx_ppo_inference.argtypes = [vp, vp, C.c_int, vp]
-    L.hx_ppo_prof.argtypes = [vp, C.c_int, vp, vp]
+    L.hx_ppo_prof_begin.argtypes = [vp, C.c_char_p]
+    L.hx_ppo_prof_end.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.hx_ppo_gemm_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.hx_ppo_gemm_test.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     _lib = L

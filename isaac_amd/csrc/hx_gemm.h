@@ -57,7 +57,7 @@ template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM> struct GemmLds {
 };
 
 // One output tile (`logical` = tile index, times the split for EPI_SLAB), start to finish, by the whole workgroup.
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL>
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL, bool GA = false, bool GB = false>
 __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logical, float* __restrict__ lds) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
@@ -376,7 +376,7 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
   }
 }
 
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false, bool GA = false, bool GB = false>
 __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
   // XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
@@ -388,18 +388,18 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
-  hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL>(g, logical, lds);
+  hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB>(g, logical, lds);
 }
 
 // The same product with a SMALL fixed grid whose workgroups walk the tiles (tile t, t + grid, ...).  Not faster per se
 // (profiles/README.md "persistent tiles"); its use is the background critic of the rollout: 128 workgroups settle on 128
 // CUs, one wave per SIMD there, and leave the other CUs entirely free -- an env-step wave needs a whole SIMD's registers,
 // and with an ordinary launch every SIMD of the chip soon holds a GEMM wave.
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false, bool GA = false, bool GB = false>
 __global__ void __launch_bounds__(256) hx_gemm_persistent_kernel(GemmArgs g, int total_tiles) {
   __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
   for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL>(g, t, lds);
+    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB>(g, t, lds);
     __syncthreads();          // the next tile's first LDS stores must not overtake this tile's last fragment reads
   }
 }

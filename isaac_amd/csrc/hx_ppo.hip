@@ -17,6 +17,7 @@
 #include <vector>
 #include "../../include/hx_ppo.h"
 #include "../../include/hx_sim.h"
+#include "../../include/hx_lab.h"
 #include "hx_common.h"
 #include "hx_gemm.h"
 #include "hx_gemm_bf16.h"
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restric
                                                           const float* __restrict__ W4, const float* __restrict__ b4,
                                                           const float* __restrict__ W4c, const float* __restrict__ b4c,
                                                           const float* __restrict__ stdp, const float* __restrict__ eps,
-                                                          int n, int A, uint32_t k0, uint32_t k1, uint32_t step,
+                                                          int n, int A, uint32_t k0, uint32_t k1, uint32_t step, uint32_t row_base,
                                                           float* actions, float* mu_out, float* values, float* logp) {
   extern __shared__ float sm[];
   float* sW = sm;                 // [A][hw]
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restric
     if (eps) z = eps[(size_t)e * A + j];
     else {
       uint32_t o[4];
-      philox4p(k0, k1, (uint32_t)e, step, (uint32_t)j, 7u, o);
+      philox4p(k0, k1, (uint32_t)e + row_base, step, (uint32_t)j, 7u, o);
       const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);
       const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
       z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) hx_act_head_kernel(const float* __restric
 __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restrict__ h3a, int hw, const float* __restrict__ W4,
                                                             const float* __restrict__ b4, const float* __restrict__ stdp,
                                                             const float* __restrict__ eps, int n, int A, uint32_t k0, uint32_t k1,
-                                                            uint32_t step, float* actions, float* mu_out, float* logp) {
+                                                            uint32_t step, uint32_t row_base, float* actions, float* mu_out, float* logp) {
   extern __shared__ float sm[];
   float* sW = sm;
   for (int i = threadIdx.x; i < A * hw; i += blockDim.x) sW[i] = W4[i];
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
     if (eps) z = eps[(size_t)e * A + j];
     else {
       uint32_t o[4];
-      philox4p(k0, k1, (uint32_t)e, step, (uint32_t)j, 7u, o);
+      philox4p(k0, k1, (uint32_t)e + row_base, step, (uint32_t)j, 7u, o);
       const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);
       const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
       z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
                                                              const float* __restrict__ W3, const float* __restrict__ b3, int N3,
                                                              const float* __restrict__ W4, const float* __restrict__ b4,
                                                              const float* __restrict__ stdp, const float* __restrict__ eps, int A,
-                                                             uint32_t k0, uint32_t k1, uint32_t step,
+                                                             uint32_t k0, uint32_t k1, uint32_t step, uint32_t row_base,
                                                              float* actions, float* mu_out, float* logp, hx_pending_step pend) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
       if (eps) z = eps[(size_t)e * A + j];
       else {
         uint32_t o[4];
-        philox4p(k0, k1, (uint32_t)e, step, (uint32_t)j, 7u, o);
+        philox4p(k0, k1, (uint32_t)e + row_base, step, (uint32_t)j, 7u, o);
         const float u1 = 1.0f - (float)(o[0] >> 8) * (1.0f / 16777216.0f);
         const float u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
         z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -892,14 +893,15 @@ struct hx_ppo {
   double* sumsq; SchedState* sched;
   int64_t adam_t;
   int mb_done, mb_total;
-  int prof_mask;                 // kernel ids (launch_gemm kid 0..4) whose launches hx_ppo_prof brackets with HIP events
+  int prof_only;                 // -1: every symbol's launches are bracketed with HIP events while profiling; else only this registry id
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
   uint32_t seed_lo, seed_hi, act_counter, perm_counter, perm_key;
+  uint32_t row_base = 0;         // global index of this learner's first env row (hx_ppo_set_row_base): counter word of the action-noise stream
   hx_comm* comm = nullptr;       // RCCL communicator (hx_comm.hip) when data parallel: all-reduce inside hx_ppo_minibatch_step
   // profiling
-  bool prof; std::vector<hipEvent_t> ev; std::vector<int> ev_kid; size_t ev_used; double prof_flops[5]; long prof_launches[5];
+  bool prof; std::vector<hipEvent_t> ev; std::vector<int> ev_kid; size_t ev_used; std::vector<double> prof_flops; std::vector<long> prof_launches;
   std::vector<void*> allocs;
 };
 
@@ -910,53 +912,40 @@ template <typename T> static int palloc(hx_ppo* s, T** ptr, size_t count) {
   return 0;
 }
 
+// ---- launch profiler (include/hx_lab.h): ONE row per kernel symbol, named exactly as rocprofv3 prints the symbol (template
+// arguments included), so that a HIP-event row of bench.py and a rocprofv3 --stats row are the same launches.
+static std::vector<std::string>& prof_names() { static std::vector<std::string> v; return v; }
+static int prof_register(const std::string& n) { prof_names().push_back(n); return (int)prof_names().size() - 1; }
+static const char* tf(bool b) { return b ? "true" : "false"; }
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL, bool GA, bool GB> static int gemm_kid() {
+  static const int id = prof_register("hx_gemm_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(BKT) + ", " + tf(AK) + ", " +
+                                      tf(BK_) + ", " + std::to_string(EPI) + ", " + tf(KFULL) + ", " + tf(GA) + ", " + tf(GB) + ">");
+  return id;
+}
+// brackets one launch with HIP events on its stream when the symbol is selected; returns true if it did
+struct ProfScope {
+  hx_ppo* s; hipStream_t st; bool on;
+  ProfScope(hx_ppo* s_, int kid, hipStream_t st_, double flops);
+  ~ProfScope();
+};
+
 // ---- GEMM dispatch
-template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL = false> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL = false, bool GA = false, bool GB = false> static void launch_gemm(hx_ppo* s, GemmArgs& g, hipStream_t st) {
   g.tiles_m = (g.M + BM - 1) / BM;
   g.tiles_n = (g.N + BN - 1) / BN;
   const int blocks = g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
-  // kernel id for the profiler: 0 fwd128, 1 fwd64, 2 dgrad128, 3 dgrad64, 4 wgrad
-  constexpr int kid = (EPI == EPI_SLAB) ? 4 : ((EPI == EPI_ELU_GRAD) ? (BM == 128 ? 2 : 3) : (BM == 128 ? 0 : 1));
-  // launches of the deferred critic on the background stream are not bracketed: they share the chip with the rollout's
-  // kernels, so an event pair there measures contended time, not the kernel
-  const bool timed = s && s->prof && ((s->prof_mask >> kid) & 1) && st != s->stream2;
-  if (timed) {
-    while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
-  }
-  if (timed && s->ev_used + 2 <= s->ev.size()) {
-    (void)hipEventRecord(s->ev[s->ev_used], st);
-    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(blocks), dim3(256), 0, st, g);
-    (void)hipEventRecord(s->ev[s->ev_used + 1], st);
-    s->ev_kid[s->ev_used] = kid;
-    s->ev_used += 2;
-    s->prof_flops[kid] += 2.0 * g.M * g.N * g.K;
-    s->prof_launches[kid] += 1;
-  } else {
-    hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(blocks), dim3(256), 0, st, g);
-  }
+  ProfScope ps(s, gemm_kid<BM, BN, BKT, AK, BK_, EPI, KFULL, GA, GB>(), st, 2.0 * g.M * g.N * g.K);
+  hipLaunchKernelGGL((hx_gemm_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL, GA, GB>), dim3(blocks), dim3(256), 0, st, g);
 }
 
-// bf16-input variant (hx_gemm_bf16.h); reported to the profiler under the fp32 kernel ids 0 (forward) / 2 (dgrad)
+// bf16-input variant (hx_gemm_bf16.h)
 template <int EPI> static void launch_gemm_bf16(hx_ppo* s, GemmArgs& g, hipStream_t st) {
   g.tiles_m = (g.M + 127) / 128;
   g.tiles_n = (g.N + 127) / 128;
   const int blocks = g.tiles_m * g.tiles_n;
-  constexpr int kid = (EPI == EPI_ELU_GRAD) ? 2 : 0;
-  const bool timed = s && s->prof && ((s->prof_mask >> kid) & 1);
-  if (timed) {
-    while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); }
-  }
-  if (timed && s->ev_used + 2 <= s->ev.size()) {
-    (void)hipEventRecord(s->ev[s->ev_used], st);
-    hipLaunchKernelGGL((hx_gemm_bf16_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
-    (void)hipEventRecord(s->ev[s->ev_used + 1], st);
-    s->ev_kid[s->ev_used] = kid;
-    s->ev_used += 2;
-    s->prof_flops[kid] += 2.0 * g.M * g.N * g.K;
-    s->prof_launches[kid] += 1;
-  } else {
-    hipLaunchKernelGGL((hx_gemm_bf16_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
-  }
+  static const int kid = prof_register("hx_gemm_bf16_kernel<" + std::to_string(EPI) + ">");
+  ProfScope ps(s, kid, st, 2.0 * g.M * g.N * g.K);
+  hipLaunchKernelGGL((hx_gemm_bf16_kernel<EPI>), dim3(blocks), dim3(256), 0, st, g);
 }
 
 // W[out][ld_in] (first `in` columns) -> WT[in][out]
@@ -1062,12 +1051,9 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   if (s->bf16) {
     g.tiles_m = (g.M + 127) / 128; g.tiles_n = (g.N + 127) / 128;
     const int blocks = g.tiles_m * g.tiles_n * g.splits;
-    const bool want = s->prof && ((s->prof_mask >> 4) & 1);
-    if (want) { while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; s->ev.push_back(e); s->ev_kid.push_back(0); } }
-    const bool timed = want && s->ev_used + 2 <= s->ev.size();
-    if (timed) (void)hipEventRecord(s->ev[s->ev_used], st);
+    static const int kid = prof_register("hx_wgrad_bf16_kernel");
+    ProfScope ps(s, kid, st, 2.0 * g.M * g.N * g.K);
     hipLaunchKernelGGL(hx_wgrad_bf16_kernel, dim3(blocks), dim3(256), 0, st, g);
-    if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], st); s->ev_kid[s->ev_used] = 4; s->ev_used += 2; s->prof_flops[4] += 2.0 * g.M * g.N * g.K; s->prof_launches[4] += 1; }
     return splits;
   }
   // kchunk is a multiple of 32; with a row count that is a multiple of the K tile every split is whole tiles
@@ -1459,8 +1445,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   }
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
   s->seed_lo = 0x1234567u; s->seed_hi = 0x89abcdefu; s->act_counter = 0; s->perm_counter = 0; s->perm_key = 0xA511E9B3u;
-  s->prof = false; s->ev_used = 0;
-  for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
+  s->prof = false; s->ev_used = 0; s->prof_only = -1;
   return 0;
 }
 
@@ -1503,6 +1488,13 @@ extern "C" int hx_ppo_set_seed(hx_ppo* s, uint64_t sample_seed, uint64_t perm_se
   s->seed_lo = 0x1234567u ^ mix32(sample_seed); s->seed_hi = 0x89abcdefu ^ mix32(sample_seed + 0x9E3779B97F4A7C15ULL);
   s->perm_key = 0xA511E9B3u ^ mix32(perm_seed ^ 0xD1B54A32D192ED03ULL);
   return 0;
+}
+// Ranks that split ONE logical batch (rank r owns rows [base_r, base_r + num_envs)) pass their first global row: the action
+// noise is then a function of the GLOBAL row, and with equal sample seeds the job samples exactly what a single process on
+// the union of the shards would.  Default 0 (weak scaling: every rank its own robots, keyed by seed + rank instead).
+extern "C" int hx_ppo_set_row_base(hx_ppo* s, uint32_t base) {
+  if (!s) { hx_set_error("hx_ppo_set_row_base: null learner"); return -2; }
+  s->row_base = base; return 0;
 }
 // positions in the two streams (checkpointed so that a resumed run does not replay the noise from counter 0)
 extern "C" int hx_ppo_get_rng_state(hx_ppo* s, uint32_t* act_counter, uint32_t* perm_counter) {
@@ -1658,7 +1650,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
       const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
 #define HX_FA_ARGS so, s->cfg.obs_ld, count, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                        \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
-                   s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, acts,                     \
+                   s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts,        \
                    s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, pend
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
       // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
@@ -1675,7 +1667,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
       mlp_hidden_fwd(s, 0, so, s->cfg.obs_ld, count, aa, st);
       hipLaunchKernelGGL(hx_actor_head_kernel, dim3((count + 15) / 16), dim3(256), A * hw * sizeof(float), st, aa[2], hw,
                          s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi,
-                         s->act_counter, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
+                         s->act_counter, s->row_base, acts, s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0);
     }
     if (flush_now) {
       if (s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));      // the burst starts when the actor has finished, beside the env step
@@ -1686,7 +1678,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, count, ac, st);
     hipLaunchKernelGGL(hx_act_head_kernel, dim3((count + 15) / 16), dim3(256), (size_t)(A * hw + hwc) * sizeof(float), st,
                        aa[2], ac[2], hw, hwc, s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->L[7].w, s->params + s->L[7].b,
-                       s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi + (uint32_t)env0, s->act_counter, acts,
+                       s->params + s->std_off, eps, count, A, s->seed_lo, s->seed_hi + (uint32_t)env0, s->act_counter, s->row_base, acts,
                        s->s_mu + ((size_t)t * N + env0) * A, s->s_values + (size_t)t * N + env0, s->s_logp + (size_t)t * N + env0);
     if (env0 + count == N) s->crit_done = t + 1;             // shard path computes values inline
   }
@@ -1889,7 +1881,9 @@ extern "C" int hx_ppo_minibatch_step(hx_ppo* s, float inv_world) {
 extern "C" int hx_ppo_update_end(hx_ppo* s, float* stats_h) {
   SchedState st;
   HX_CHECK(hipMemcpyAsync(&st, s->sched, sizeof(st), hipMemcpyDeviceToHost, s->stream));
-  HX_CHECK(hipStreamSynchronize(s->stream));
+  // the stream carries this update's all-reduces when data parallel: wait with the communicator's deadline, not forever
+  if (s->comm) { const int rc = hx_comm_wait(s->comm, s->stream, 0.0); if (rc) return rc; }
+  else HX_CHECK(hipStreamSynchronize(s->stream));
   const float n = (float)(s->mb_done > 0 ? s->mb_done : 1);
   if (stats_h) { stats_h[0] = st.vloss_sum / n; stats_h[1] = st.sloss_sum / n; stats_h[2] = st.lr; stats_h[3] = st.last_kl; }
   s->step = 0;       // storage.clear(), ppo.py:182
@@ -1928,7 +1922,8 @@ extern "C" int hx_ppo_buffer(hx_ppo* s, int which, void** d) {
 extern "C" int hx_ppo_get_lr(hx_ppo* s, float* lr) {
   SchedState st;
   HX_CHECK(hipMemcpyAsync(&st, s->sched, sizeof(st), hipMemcpyDeviceToHost, s->stream));
-  HX_CHECK(hipStreamSynchronize(s->stream));
+  if (s->comm) { const int rc = hx_comm_wait(s->comm, s->stream, 0.0); if (rc) return rc; }
+  else HX_CHECK(hipStreamSynchronize(s->stream));
   *lr = st.lr; return 0;
 }
 extern "C" int hx_ppo_set_lr(hx_ppo* s, float lr) {
@@ -1947,19 +1942,50 @@ extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* ou
   return 0;
 }
 
-extern "C" int hx_ppo_prof(hx_ppo* s, int which, double* out, void*) {
-  if (which == 1 || which >= 0x100) {
-    s->prof_mask = (which == 1) ? 31 : (which & 31);      // which = 0x100 | mask: bracket only the kernel ids in mask
-    s->ev_used = 0; s->prof = true;
-    for (int i = 0; i < 5; ++i) { s->prof_flops[i] = 0; s->prof_launches[i] = 0; }
-    return 0;
+// launches of the deferred critic on the background stream are not bracketed: they share the chip with the rollout's
+// kernels, so an event pair there measures contended time, not the kernel
+ProfScope::ProfScope(hx_ppo* s_, int kid, hipStream_t st_, double flops) : s(s_), st(st_), on(false) {
+  if (!s || !s->prof || (s->prof_only >= 0 && s->prof_only != kid) || st == s->stream2) return;
+  while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; s->ev.push_back(e); s->ev_kid.push_back(0); }
+  if ((size_t)kid >= s->prof_flops.size()) { s->prof_flops.resize(kid + 1, 0.0); s->prof_launches.resize(kid + 1, 0); }
+  (void)hipEventRecord(s->ev[s->ev_used], st);
+  s->ev_kid[s->ev_used] = kid;
+  s->prof_flops[kid] += flops; s->prof_launches[kid] += 1;
+  on = true;
+}
+ProfScope::~ProfScope() { if (on) { (void)hipEventRecord(s->ev[s->ev_used + 1], st); s->ev_used += 2; } }
+
+extern "C" int hx_ppo_prof_begin(hx_ppo* s, const char* only_symbol) {
+  if (!s) { hx_set_error("hx_ppo_prof_begin: null learner"); return -2; }
+  s->prof_only = -1;
+  if (only_symbol && *only_symbol) {
+    const auto& names = prof_names();
+    for (size_t i = 0; i < names.size(); ++i) if (names[i] == only_symbol) s->prof_only = (int)i;
+    if (s->prof_only < 0) { hx_set_error(std::string("hx_ppo_prof_begin: no launch of symbol '") + only_symbol + "' has been seen yet"); return -2; }
   }
+  s->ev_used = 0; s->prof = true;
+  s->prof_flops.assign(prof_names().size(), 0.0); s->prof_launches.assign(prof_names().size(), 0);
+  return 0;
+}
+extern "C" int hx_ppo_prof_end(hx_ppo* s, hx_prof_row* rows, int max_rows, int* n_rows) {
+  if (!s || !n_rows) { hx_set_error("hx_ppo_prof_end: null argument"); return -2; }
   s->prof = false;
   HX_CHECK(hipStreamSynchronize(s->stream));
-  double ms[5] = {0, 0, 0, 0, 0};
-  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); ms[s->ev_kid[i]] += t; }
-  // out[15]: per kernel id {milliseconds, launches, flops}
-  if (out) for (int k = 0; k < 5; ++k) { out[3 * k] = ms[k]; out[3 * k + 1] = (double)s->prof_launches[k]; out[3 * k + 2] = s->prof_flops[k]; }
+  std::vector<double> ms(prof_names().size(), 0.0);
+  for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); if ((size_t)s->ev_kid[i] < ms.size()) ms[s->ev_kid[i]] += t; }
+  int n = 0;
+  for (size_t k = 0; k < s->prof_launches.size() && k < ms.size(); ++k) {
+    if (s->prof_launches[k] == 0) continue;
+    if (rows && n < max_rows) {
+      hx_prof_row& r = rows[n];
+      memset(&r, 0, sizeof(r));
+      strncpy(r.symbol, prof_names()[k].c_str(), sizeof(r.symbol) - 1);
+      r.ms = ms[k]; r.launches = s->prof_launches[k]; r.flops = s->prof_flops[k];
+    }
+    ++n;
+  }
+  *n_rows = n;
+  s->ev_used = 0;
   return 0;
 }
 

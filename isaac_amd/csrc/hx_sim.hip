@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include "../../include/hx_sim.h"
+#include "../../include/hx_lab.h"
 #include "hx_env.h"
 #include "hx_common.h"
 
@@ -286,6 +287,10 @@ static thread_local std::string g_err;
 extern "C" const char* hx_last_error(void) { return g_err.c_str(); }
 void hx_set_error(const std::string& s) { g_err = s; }
 extern "C" int hx_version(void) { return 100; }
+#ifndef HX_BUILD_ID
+#define HX_BUILD_ID "unknown"
+#endif
+extern "C" const char* hx_build_id(void) { return "100-" HX_BUILD_ID; }
 extern "C" int hx_sync(void* stream) { HX_CHECK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 
 struct hx_sim {

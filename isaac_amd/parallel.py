@@ -48,6 +48,10 @@ class Comm:
     def sum_over_ranks(self, x):
         return x
 
+    def sum_array_over_ranks(self, values):
+        """Element-wise sum over ranks of a small float64 vector: ONE collective for all of an iteration's statistics."""
+        return np.asarray(values, np.float64).copy()
+
     def close(self):
         pass
 
@@ -62,20 +66,17 @@ class TorchComm(Comm):
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if backend is None:
             backend = os.environ.get("HX_DIST_BACKEND") or "gloo"
-        if backend == "nccl":
-            raise ValueError("the RCCL transport lives in libhx.so now: use isaac_amd.parallel.HxComm (HX_DIST_BACKEND=rccl)")
+        if backend not in ("gloo", "gloo-staged"):
+            raise ValueError("TorchComm carries gloo / gloo-staged only; the RCCL transport lives in libhx.so: "
+                             "isaac_amd.parallel.HxComm (HX_DIST_BACKEND=rccl)")
         # "gloo-staged": gloo collectives on host copies of the library's DEVICE buffers.  A functional rehearsal of the
         # N > 1 path where RCCL cannot run (several ranks sharing one GPU); never the measured configuration.
         self.staged = (backend == "gloo-staged")
         if self.staged:
             backend = "gloo"
         self.backend = backend
-        self.device_ptrs = (backend == "nccl") or self.staged      # do the library's pointers name device memory?
-        if backend == "nccl":
-            torch.cuda.set_device(self.local_rank)
-            self.device = torch.device("cuda", self.local_rank)
-        else:
-            self.device = torch.device("cpu")
+        self.device_ptrs = self.staged      # do the library's pointers name device memory?
+        self.device = torch.device("cpu")
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -98,17 +99,7 @@ class TorchComm(Comm):
         if self.staged:
             return None
         self._grad = self.torch.zeros(int(count), dtype=self.torch.float32, device=self.device)
-        if self.backend == "nccl":
-            self.torch.cuda.current_stream().synchronize()      # the fill ran on torch's stream; the library uses its own
         return self._grad.data_ptr()
-
-    def _sync_streams(self, stream):
-        """The library launches on its own HIP stream; torch's collectives are ordered against torch's current
-        stream.  Make each wait for the other with a full stream sync (two per optimiser step, ~10 us each,
-        against a multi-millisecond minibatch)."""
-        if self.backend == "nccl":
-            from . import capi
-            capi.check(capi.lib().hx_sync(stream), "hx_sync")
 
     def all_reduce_grads(self, ptr, count, stream):
         if self.staged:
@@ -119,10 +110,7 @@ class TorchComm(Comm):
             capi.check(capi.lib().hx_memcpy_h2d(ptr, capi.ptr(np.ascontiguousarray(t.numpy())), int(count) * 4, stream), "h2d")
             return
         assert self._grad is not None and ptr == self._grad.data_ptr() and count == self._grad.numel()
-        self._sync_streams(stream)
         self.dist.all_reduce(self._grad, op=self.dist.ReduceOp.SUM)
-        if self.backend == "nccl":
-            self.torch.cuda.current_stream().synchronize()
 
     def all_reduce_moments(self, ptr, stream):
         """[sum, sum of squares, count] of the raw advantages (3 doubles) -> global moments on every rank."""
@@ -154,8 +142,13 @@ class TorchComm(Comm):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def sum_array_over_ranks(self, values):
+        t = self.torch.tensor(np.asarray(values, np.float64), dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.numpy().copy()
+
     def close(self):
-        """Tear the process group down (the nccl backend warns at exit otherwise)."""
+        """Tear the process group down."""
         if self.dist.is_initialized():
             self.dist.destroy_process_group()
 
@@ -174,43 +167,50 @@ class HxComm(Comm):
         self.world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
         L = capi.lib()
-        ndev = max(1, L.hx_device_count())
-        capi.check(L.hx_set_device(self.local_rank % ndev), "hx_set_device")
+        ndev = L.hx_device_count()
+        if ndev < 1:
+            raise RuntimeError("HxComm: no HIP device (the RCCL transport has no CPU form; HX_DIST_BACKEND=gloo for CPU rehearsals)")
+        if self.local_rank >= ndev:
+            # RCCL needs one GPU per rank: two ranks on one device make ncclCommInitRank fail or hang.  Only the gloo-staged
+            # rehearsal transport may share a GPU.
+            raise RuntimeError(f"HxComm: LOCAL_RANK {self.local_rank} but only {ndev} HIP device(s) visible: one rank per GPU "
+                               "(HX_DIST_BACKEND=gloo-staged rehearses several ranks on one GPU)")
+        capi.check(L.hx_set_device(self.local_rank), "hx_set_device")
+        self._attached = []
         uid = (C.c_uint8 * 128)()
-        if self.world_size > 1:
-            # host-side rendezvous: rank 0's unique id through a TCPStore on MASTER_ADDR:MASTER_PORT (plumbing only)
-            from datetime import timedelta
-            from torch.distributed import TCPStore
-            # under torch.distributed.run the launcher's agent already serves a store on MASTER_PORT: every rank is a client
-            agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
-            store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29511")), self.world_size,
-                             self.rank == 0 and not agent_store, timeout=timedelta(seconds=300))
-            key = "hx_rccl_unique_id_%d" % HxComm._created           # one key per communicator of the job
-            HxComm._created += 1
-            if self.rank == 0:
-                capi.check(L.hx_comm_get_unique_id(uid), "hx_comm_get_unique_id")
-                store.set(key, bytes(uid))
-            else:
-                raw = store.get(key)
-                C.memmove(uid, raw, 128)
-            self._store = store
-        else:
+
+        def make_id():
             capi.check(L.hx_comm_get_unique_id(uid), "hx_comm_get_unique_id")
+            return bytes(uid)
+        raw = exchange_unique_id(self.rank, self.world_size, make_id, "hx_rccl_unique_id_%d" % HxComm._created)
+        HxComm._created += 1           # one key per communicator of the job
+        C.memmove(uid, raw, 128)
         h = C.c_void_p()
         capi.check(L.hx_comm_init(uid, self.rank, self.world_size, C.byref(h)), "hx_comm_init")
         self._h = h
-        self._scratch = capi.DeviceBuffer(64)
+        self._scratch = capi.DeviceBuffer(1024)
 
     def attach(self, alg):
         """Bind the learner: gradients / moments are all-reduced inside the library from now on; rank 0's parameters win."""
+        import weakref
         self.capi.check(self.capi.lib().hx_ppo_set_comm(alg._h, self._h), "hx_ppo_set_comm")
         self.capi.check(self.capi.lib().hx_ppo_broadcast_params(alg._h, 0), "hx_ppo_broadcast_params")
+        self._attached.append(weakref.ref(alg))
+
+    def _reduce(self, values, op):
+        a = np.ascontiguousarray(values, np.float64)
+        assert a.nbytes <= self._scratch.nbytes
+        L = self.capi.lib()
+        self._scratch.upload(a)
+        self.capi.check(L.hx_comm_all_reduce(self._h, self._scratch.ptr, a.size, 1, op, None), "hx_comm_all_reduce")
+        self.capi.check(L.hx_comm_wait(self._h, None, 0.0), "hx_comm_wait")      # deadline, then abort: never an unbounded wait
+        return self._scratch.download(np.float64, a.shape)
 
     def _reduce_scalar(self, x, op):
-        a = np.array([float(x)], np.float64)
-        self._scratch.upload(a)
-        self.capi.check(self.capi.lib().hx_comm_all_reduce(self._h, self._scratch.ptr, 1, 1, op, None), "hx_comm_all_reduce")
-        return float(self._scratch.download(np.float64, (1,))[0])
+        return float(self._reduce([float(x)], op)[0])
+
+    def sum_array_over_ranks(self, values):
+        return self._reduce(values, 0)
 
     def barrier(self):
         self._reduce_scalar(0.0, 0)
@@ -222,9 +222,40 @@ class HxComm(Comm):
         return self._reduce_scalar(x, 0)
 
     def close(self):
+        """Detach every learner that was given this communicator (they hold the raw pointer), then destroy it."""
         if getattr(self, "_h", None):
+            for ref in self._attached:
+                alg = ref()
+                if alg is not None and getattr(alg, "_h", None):
+                    self.capi.lib().hx_ppo_set_comm(alg._h, None)
+            self._attached = []
             self.capi.lib().hx_comm_destroy(self._h)
             self._h = None
+
+
+_stores = []
+
+
+def exchange_unique_id(rank, world_size, make_id, key):
+    """Host-side rendezvous of the RCCL unique id (plumbing only): rank 0 calls make_id() and publishes the bytes under `key`
+    in a TCPStore on MASTER_ADDR:MASTER_PORT, the other ranks read them.  Under torch.distributed.run the launcher's agent
+    already serves a store on MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE=True): every rank is a client then; otherwise
+    (bench.py's own launcher, hand-started ranks) rank 0 serves it.  world_size 1: no store."""
+    if world_size <= 1:
+        return make_id()
+    from datetime import timedelta
+    from torch.distributed import TCPStore
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29511"))
+    store = next((st for a, p_, st in _stores if (a, p_) == (addr, port)), None)
+    if store is None:                  # one store per job: a second communicator reuses it (rank 0 cannot listen on the port twice)
+        store = TCPStore(addr, port, world_size, rank == 0 and not agent_store, timeout=timedelta(seconds=300))
+        _stores.append((addr, port, store))      # and the server side must outlive the clients' reads
+    if rank == 0:
+        raw = make_id()
+        store.set(key, raw)
+        return raw
+    return bytes(store.get(key))
 
 
 def init_comm(backend=None):

@@ -16,9 +16,9 @@ def libpath():
     return capi.LIB_PATH
 
 
-def _declared():
+def _declared(headers=("hx_sim.h", "hx_ppo.h", "hx_lab.h")):
     names = set()
-    for h in ("hx_sim.h", "hx_ppo.h"):
+    for h in headers:
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(hx_[a-z0-9_]+)\s*\(", src))
@@ -31,6 +31,20 @@ def test_every_declared_symbol_is_exported(libpath):
     declared = _declared()
     assert len(declared) >= 40
     assert declared <= exported, sorted(declared - exported)
+
+
+def test_lab_hooks_are_not_in_the_product_headers():
+    """Measurement / unit-test hooks live in include/hx_lab.h; the boundary headers and INTEGRATION.md do not cite them."""
+    product, lab = _declared(("hx_sim.h", "hx_ppo.h")), _declared(("hx_lab.h",))
+    for name in ("hx_ppo_gemm_test", "hx_ppo_gemm_bench", "hx_mfma_probe", "hx_sim_prof", "hx_sim_time", "hx_ppo_prof_begin", "hx_ppo_prof_end"):
+        assert name in lab and name not in product, name
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert not (lab - product) & set(re.findall(r"\b(hx_[a-z0-9_]+)\b", integ))
+
+
+def test_build_id_names_the_sources(libpath):
+    from isaac_amd import build, capi
+    assert capi.lib().hx_build_id().decode() == "100-" + build.source_hash()
 
 
 def test_library_contains_gfx950_code_object(libpath):

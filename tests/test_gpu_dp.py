@@ -31,6 +31,49 @@ def test_two_ranks_stay_bit_identical(hxlib, tmp_path):
     assert np.all(np.isfinite(r0["params"]))
 
 
+def test_two_ranks_equal_single_process_on_the_union(hxlib, tmp_path):
+    """Two ranks on the env_range halves of ONE logical 512-robot batch == a single process on all 512 (tests/dp_gpu_union_worker.py):
+    same robots, same action noise, same minibatches, global advantage moments, summed gradients -- within the tolerance of
+    fp32 sums taken in a different order."""
+    port = 29400 + os.getpid() % 200
+    out = str(tmp_path / "r{rank}.npz")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HX_DIST_BACKEND="gloo-staged", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_gpu_union_worker.py"), "rank", out], env=env))
+    for p in procs:
+        assert p.wait(timeout=500) == 0
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HX_DIST_BACKEND")}
+    uout = str(tmp_path / "union{rank}.npz")
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_gpu_union_worker.py"), "union", uout], env=env, timeout=500).returncode == 0
+    r0, r1, u = np.load(out.format(rank=0)), np.load(out.format(rank=1)), np.load(uout.format(rank=0))
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    # the second rollout ran with parameters that already differ by round-off, so only the first one's samples are bit-equal;
+    # the last iteration's actions / advantages agree to the tolerance of that round-off
+    np.testing.assert_allclose(np.concatenate([r0["actions"], r1["actions"]], axis=1), u["actions"], atol=2e-3)
+    np.testing.assert_allclose(np.concatenate([r0["adv"], r1["adv"]], axis=1), u["adv"], atol=5e-3)
+    np.testing.assert_allclose(r0["hist"], u["hist"], rtol=2e-3, atol=1e-6)          # losses and the learning-rate decisions
+    d = np.abs(r0["params"] - u["params"])
+    print("union vs 2 ranks: max |dparam| %.3g, share above 2e-6: %.4f" % (d.max(), float(np.mean(d > 2e-6))))
+    assert d.max() < 2e-4 and np.mean(d > 2e-6) < 0.02, (d.max(), float(np.mean(d > 2e-6)))
+
+
+def test_bench_self_spawns_two_ranks(hxlib):
+    """`python bench.py --gpus 2` without a launcher (WORLD_SIZE unset): the parent starts both ranks before touching the GPU
+    and relays rank 0's one JSON line.  The ranks share the test box's one GPU, so the transport is the gloo-staged rehearsal."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HX_DIST_BACKEND="gloo-staged", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "256", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=500, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
+
+
 def test_one_rank_rccl_path_equals_single_process(hxlib, tmp_path):
     """The measured N > 1 transport is RCCL inside libhx.so (hx_comm_init / hx_ppo_set_comm), which cannot run with two ranks
     on the one GPU of the test box.  With ONE rank it can: the whole distributed path (unique id, communicator, parameter

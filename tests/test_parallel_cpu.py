@@ -65,3 +65,95 @@ def test_two_ranks_equal_single_process(tmp_path):
     single = np.concatenate([p.reshape(-1) for p in ac.params()])
     d = np.abs(single - r0["params"])
     assert np.mean(d > 2e-6) < 5e-3 and d.max() < 4e-3, (d.max(), float(np.mean(d > 2e-6)))
+
+
+_RDV_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+from isaac_amd.parallel import exchange_unique_id
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+made = []
+def make_id():
+    made.append(1)
+    return bytes(range(128))
+raw = exchange_unique_id(rank, world, make_id, "hx_rccl_unique_id_0")
+assert raw == bytes(range(128)), raw
+assert len(made) == (1 if rank == 0 else 0)          # only rank 0 draws the id
+raw2 = exchange_unique_id(rank, world, lambda: bytes(reversed(range(128))), "hx_rccl_unique_id_1")   # a second communicator of the job
+assert raw2 == bytes(reversed(range(128)))
+# the serving rank must outlive the readers (in the product ncclCommInitRank is that barrier)
+from isaac_amd.parallel import _stores
+st = _stores[-1][2]
+if rank == 0:
+    st.set("done0", b"1"); st.get("done1")
+else:
+    st.get("done0"); st.set("done1", b"1")
+print("rank", rank, "ok", flush=True)
+"""
+
+
+def _run_rendezvous(agent_store):
+    import socket
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    server = None
+    if agent_store:                       # what torch.distributed.run's agent does: it serves the store, every rank is a client
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        server = TCPStore("127.0.0.1", port, 2, True, timeout=timedelta(seconds=60), wait_for_workers=False)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        if agent_store:
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "True"
+        procs.append(subprocess.Popen([sys.executable, "-c", _RDV_WORKER.format(root=ROOT)], env=env, stdout=subprocess.PIPE, text=True))
+        if rank == 0:
+            time.sleep(0.2)
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    del server
+
+
+def test_unique_id_rendezvous_rank0_serves_the_store():
+    _run_rendezvous(agent_store=False)
+
+
+def test_unique_id_rendezvous_through_the_launcher_agent_store():
+    _run_rendezvous(agent_store=True)
+
+
+def test_hxcomm_refuses_a_rank_without_its_own_gpu():
+    """RCCL needs one GPU per rank; LOCAL_RANK >= visible devices must be an error, not a silent modulo (and without any
+    device the transport has no CPU form at all)."""
+    import pytest
+    from isaac_amd import capi
+    from isaac_amd.parallel import HxComm
+    ndev = capi.lib().hx_device_count()
+    with pytest.raises(RuntimeError):
+        HxComm(rank=0, world_size=1, local_rank=max(ndev, 1))
+
+
+def test_bench_self_spawn_relays_rank0_and_propagates_failure():
+    """`python bench.py --gpus N` with WORLD_SIZE unset starts the N ranks itself (before any GPU / library call) and relays
+    rank 0's one line; a rank that dies ends the job with its exit code and the surviving ranks are terminated."""
+    import json
+    import time
+    env = dict(os.environ, HX_BENCH_CHILD_PROBE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["RANK"] == "0" and d["WORLD_SIZE"] == "3" and d["MASTER_ADDR"] == "127.0.0.1" and int(d["MASTER_PORT"]) > 0
+    assert r.stderr.count('"RANK"') == 2          # the other ranks' stdout goes to stderr
+    env["HX_BENCH_CHILD_PROBE"] = "fail1"         # rank 1 exits 3, ranks 0 and 2 would wait ten minutes for it
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 3 and time.time() - t0 < 60

@@ -20,7 +20,9 @@ for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recur
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 assert agg, "no hx_env_step_kernel rows under " + out_dir
 mean = {k: sum(v) / len(v) for k, v in agg.items()}
-res = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof",
+sys.path.insert(0, ROOT)
+from isaac_amd import capi
+res = {"build_id": capi.lib().hx_build_id().decode(), "command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof",
        "kernel": "hx_env_step_kernel<ModelHector>", "terrain": "trimesh", "envs": 4096, "launches_sampled": len(next(iter(agg.values()))),
        "valu_insts_per_launch": mean.get("SQ_INSTS_VALU"), "waves_per_launch": mean.get("SQ_WAVES"),
        "salu_insts_per_launch": mean.get("SQ_INSTS_SALU"), "lds_insts_per_launch": mean.get("SQ_INSTS_LDS")}

@@ -16,17 +16,28 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out_dir = os.path.join(ROOT, "gpurun_out", f"pmc_traffic_{tag}")
-# template-argument prefixes (a trailing KFULL flag follows in the symbol name)
-KEYS = {"<128, 128, 32, true, true, 0,": "hx_gemm_kernel<128,128,KM,KM,bias+elu> (fwd)",
-        "<64, 128, 16, true, true, 0,": "hx_gemm_kernel<64,128,KM,KM,bias+elu> (fwd, K%32!=0 input layers + small batches)",
-        "<128, 128, 32, true, false, 1,": "hx_gemm_kernel<128,128,KM,NM,elu'> (dgrad)",
-        "<64, 128, 32, true, false, 1,": "hx_gemm_kernel<64,128,KM,NM,elu'> (dgrad)",
-        "<128, 128, 16, false, false, 2,": "hx_gemm_kernel<128,128,MM,NM,slab> (wgrad split-K)"}
+sys.path.insert(0, ROOT)
+from isaac_amd import capi
+BUILD_ID = capi.lib().hx_build_id().decode()          # the build this script runs beside = the build the passes ran on
+
+
+def key_of(name):
+    """rocprofv3's Kernel_Name -> the symbol as bench.py / include/hx_lab.h name it: 'void f<...>(Args)' -> 'f<...>'"""
+    n = name[5:] if name.startswith("void ") else name
+    depth = 0
+    for i, ch in enumerate(n):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return n[:i]
+    return n
+
+
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        key = next((v for k, v in KEYS.items() if k in name), name.split("(")[0][:60])
+        key = key_of(name)
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, c in agg.items():
@@ -37,7 +48,7 @@ for k, c in agg.items():
     res[k] = {"launches_sampled": len(c["FETCH_SIZE"]), "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
               "fetch_bytes_per_launch": 2.0 * fetch_kb * 1024.0, "write_bytes_per_launch": write_kb * 1024.0}
 path = os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json")
-json.dump({"command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} (one pass each) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof",
+json.dump({"build_id": BUILD_ID, "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} (one pass each) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof",
            "correction": "fetch = 2 x FETCH_SIZE (gfx950), write = WRITE_SIZE; units: rocprofv3 reports KB", "kernels": res}, open(path, "w"), indent=1)
 print(path)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["fetch_bytes_per_launch"])[:10]:
