@@ -122,6 +122,13 @@ typedef struct hx_sim_cfg {
    * reward ingredient (the arm term of default_joint_pos, hector_w_arm_env.py:371-378).  Random packs then follow the same
    * field order with 18-wide action-noise / reset rows and a 65-wide observation-noise block. */
   int32_t num_dof;
+  /* sim.physx of the reference's config (hector_config.py:108-120), as far as a penalty contact model has a place for them:
+   * max_depenetration_velocity (1.0) caps the speed at which a penetrating point is pushed out, contact_offset (0.01) is the
+   * distance at which a point becomes a contact (its approach speed beyond gap / dt is damped before it touches),
+   * rest_offset (0) the distance at which shapes rest.  0 / 0 / 0 = the plain spring-damper.  solver_type (TGS),
+   * num_position_iterations, num_velocity_iterations and bounce_threshold_velocity (restitution is 0) have no counterpart:
+   * nothing here iterates.  DESIGN.md 4. */
+  float max_depenetration_velocity, contact_offset, rest_offset;
 } hx_sim_cfg;
 
 typedef struct hx_sim hx_sim;
@@ -162,6 +169,9 @@ int hx_sim_create(const hx_sim_cfg* cfg, const float* shape_friction_h, const fl
  * hx_sim_reset_all; heights_h == NULL returns to the ground plane z = 0 (gym.add_ground, legged_robot.py:541-551). */
 int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t rows, int32_t cols, float horizontal_scale,
                        float vertical_scale, float x0, float y0, float wall_height);
+/* ablation switches for the trimesh walls (tools/falls_by_tile.py): flags & 1 = cliff cells keep their ramp, flags & 2 = no
+ * sideways wall contact; 0 (default) = the reference's trimesh semantics */
+int hx_sim_set_terrain_options(hx_sim* s, int32_t flags);
 /* Terrain curriculum, LeggedRobot._update_terrain_curriculum (legged_robot.py:399-419) with the tables of
  * _get_env_origins (legged_robot.py:687-697).  origins_h [rows][cols][3] = terrain.env_origins, levels_h / types_h [N] =
  * terrain_levels / terrain_types, env_length = terrain.env_length, max_episode_length_s as in the config.  Every reset

@@ -58,6 +58,7 @@ class SimCfg(C.Structure):
         ("contact_kn", C.c_float), ("contact_dn", C.c_float), ("friction_veps", C.c_float),
         ("limit_k", C.c_float), ("limit_d", C.c_float), ("terrain_mu", C.c_float),
         ("env_id_offset", C.c_int32), ("num_dof", C.c_int32),
+        ("max_depenetration_velocity", C.c_float), ("contact_offset", C.c_float), ("rest_offset", C.c_float),
     ]
 
 
@@ -108,6 +109,7 @@ def lib():
     L.hx_sim_set_commands.argtypes = [vp, vp]
     L.hx_sim_get_base_velocities.argtypes = [vp, vp, vp]
     L.hx_sim_set_terrain.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.hx_sim_set_terrain_options.argtypes = [vp, C.c_int32]
     L.hx_sim_set_terrain_curriculum.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.c_float, C.c_float]
     L.hx_sim_get_terrain_levels.argtypes = [vp, vp]
     L.hx_sim_episode_stats.argtypes = [vp, vp, vp]

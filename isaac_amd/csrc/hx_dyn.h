@@ -64,7 +64,17 @@ template <class M> struct ModelInfo {
 #define HX_PATCH_LD (HX_PATCH * HX_PATCH + 1)      /* per-robot LDS strides: odd, so that the 32 robots of a wave reading the */
 #define HX_POOL_LD (HX_POOL * HX_POOL + 1)          /* same cell of their own windows hit 32 different banks */
 struct DynParams {
-  float dt, gz, kn, dn, veps, lim_k, lim_d, mu;
+  float dt, inv_dt, gz, kn, dn, veps, lim_k, lim_d, mu;
+  // the contact inputs the reference states for PhysX (hector_config.py:113-117), in this penalty model's terms:
+  float vdep;             // max_depenetration_velocity: the spring part of a point's normal force is capped at c_n * vdep, the force
+                          // at which a point pushes itself out at vdep -- a deep penetration (a toe driven into a riser) is
+                          // corrected at that speed instead of being thrown out by k * depth; <= 0: no cap
+  float coff;             // contact_offset: a point closer than this to the surface is a contact already; while it is still
+                          // outside, the damper acts on the part of its approach speed that would carry it through the surface
+                          // within this substep (vn + gap / dt < 0) -- the penalty form of PhysX's speculative contact
+  float roff;             // rest_offset: distance at which shapes come to rest (added to the penetration)
+  int tflags;             // ablation switches of the trimesh walls (hx_sim_set_terrain_options): 1 = cliff cells keep their
+                          // ramp (no flattening), 2 = no sideways wall contact
   const float* patch;     // LDS, [HX_PATCH][HX_PATCH] row-major (row = x index), or nullptr
   float px0, py0;         // world x / y of patch node (0, 0)
   float inv_hs;           // 1 / horizontal_scale
@@ -170,7 +180,7 @@ HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls
   const float fu = fminf(fmaxf(u - (float)i, 0.f), 1.f), fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
   const float* c = P.patch + i * HX_PATCH + j;
   float h00 = c[0], h01 = c[1], h10 = c[HX_PATCH], h11 = c[HX_PATCH + 1];
-  if (hx_any(walls)) {
+  if (hx_any(walls) && !(P.tflags & 1)) {
     const float lo = fminf(fminf(h00, h01), fminf(h10, h11));
     if (fmaxf(fmaxf(h00, h01), fmaxf(h10, h11)) - lo > P.wall) {
       // vertices standing more than a wall height above the cell's lowest one are "high": the mesh has no surface of
@@ -284,7 +294,7 @@ HXD float shape_gap(const DynParams& P, const float* shp, const M3& Rb, V3 pb) {
         for (int b = hx_imax(j - 1, 0); b <= hx_imin(j + 1, HX_POOL - 1); ++b) bound = fmaxf(bound, P.pool[a * HX_POOL + b]);
     }
   }
-  return zlow - bound;
+  return zlow - bound - P.coff;
 }
 
 // Contact terms of one shape (`shp`: bounding sphere centre xyz + radius, then npts xyz triples; LDS): the body state
@@ -311,21 +321,25 @@ HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const Con
     if (P.patch != nullptr) {
       const float u = (pb.x + dot(row(Rb, 0), r) - P.px0) * P.inv_hs, w = (pb.y + dot(row(Rb, 1), r) - P.py0) * P.inv_hs;
       const int pi = terrain_pool_index(u, w);
-      if (!hx_any(z < P.pool[pi])) continue;
+      if (!hx_any(z < P.pool[pi] + P.coff)) continue;
       const bool walls = P.poolw[pi] != 0.f;         // never set without walls (P.wall = 0)
       V3 nw;
       const float h = terrain_query(P, u, w, nw, walls);
       pen = (h - z) * nw.z;
-      if (hx_any(walls && pen > 0.f)) {
+      if (hx_any(walls && pen > 0.f) && !(P.tflags & 2)) {
         float wp = pen; V3 wn = nw;
         if (walls && pen > 0.f && wall_push(P, u, w, z, wp, wn)) { pen = wp; nw = wn; }
       }
       nb = mulT(Rb, nw);
-    } else if (!hx_any(z < 0.f)) continue;
+    } else if (!hx_any(z < P.coff)) continue;
     const V3 vp = v.v + cross(v.w, r);
     const float vn = dot(vp, nb);
-    const float fn0 = P.kn * pen - c_n * vn;
-    const bool act = (pen > 0.f) && (fn0 > 0.f);
+    // normal force = capped spring on the penetration - damper on the closing speed; outside the surface but inside the
+    // contact offset only the speed in excess of gap / dt is damped (DynParams::coff, ::vdep)
+    pen += P.roff;
+    const float spring = P.kn * fmaxf(pen, 0.f);
+    const float fn0 = ((P.vdep > 0.f) ? fminf(spring, c_n * P.vdep) : spring) - c_n * (vn + fmaxf(-pen, 0.f) * P.inv_dt);
+    const bool act = (pen > -P.coff) && (fn0 > 0.f);
     if (!hx_any(act)) continue;
     const V3 vt = vp - vn * nb;
     const float vtn = sqrtf(dot(vt, vt));

@@ -49,6 +49,7 @@ struct SimPtrs {
   const float* terrain;
   int t_rows, t_cols;
   float t_inv_hs, t_hs, t_x0, t_y0;
+  int t_flags;                // hx_sim_set_terrain_options (ablation switches, DynParams::tflags)
   float t_wall;               // slope_treshold * horizontal_scale for mesh_type 'trimesh', 0 for 'heightfield' (no walls)
   // pooled bounds of the grid (terrain_pool_build), [t_prows][t_pcols] each: highest node / cliff flag of the 7 x 7 nodes
   // around every second node -- what DynParams::pool / poolw window into
@@ -706,7 +707,8 @@ inline void terrain_pool_build(const float* h, int rows, int cols, float wall, f
 }
 HXD DynParams dyn_params(const hx_sim_cfg& cfg, float friction) {
   DynParams P;
-  P.dt = cfg.sim_dt; P.gz = cfg.gravity_z; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
+  P.dt = cfg.sim_dt; P.inv_dt = 1.0f / cfg.sim_dt; P.gz = cfg.gravity_z;
+  P.vdep = cfg.max_depenetration_velocity; P.coff = cfg.contact_offset; P.roff = cfg.rest_offset; P.tflags = 0; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
   P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
   P.patch = nullptr; P.pool = nullptr; P.poolw = nullptr; P.prof = nullptr; P.pt0 = 0; P.ptstep = 1; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.wall = 0.f;
   return P;

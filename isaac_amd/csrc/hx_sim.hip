@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
       P.patch = lds_patch + r * HX_PATCH_LD;
       P.px0 = p.t_x0 + (float)lds_patch_org[r][0] * p.t_hs;
       P.py0 = p.t_y0 + (float)lds_patch_org[r][1] * p.t_hs;
-      P.inv_hs = p.t_inv_hs; P.wall = p.t_wall;
+      P.inv_hs = p.t_inv_hs; P.wall = p.t_wall; P.tflags = p.t_flags;
       P.pool = lds_pool + r * HX_POOL_LD; P.poolw = lds_poolw + r * HX_POOL_LD;
     }
     // one buffer column per body side: the four lanes of a side hold the same body states and (after the quad sums) write the
@@ -443,6 +443,12 @@ extern "C" int hx_sim_set_terrain(hx_sim* s, const int16_t* heights_h, int32_t r
   s->p.terrain = d; s->p.t_rows = rows; s->p.t_cols = cols;
   s->p.t_hs = horizontal_scale; s->p.t_inv_hs = 1.0f / horizontal_scale; s->p.t_x0 = x0; s->p.t_y0 = y0;
   s->p.t_wall = wall_height > 0.f ? wall_height : 0.f;
+  return 0;
+}
+
+extern "C" int hx_sim_set_terrain_options(hx_sim* s, int32_t flags) {
+  if (!s) { hx_set_error("hx_sim_set_terrain_options: null sim"); return -2; }
+  s->p.t_flags = flags;
   return 0;
 }
 

@@ -220,7 +220,10 @@ class HectorFreeEnv(VecEnv):
         c.base_height_target, c.min_dist, c.max_dist = rw.base_height_target, rw.min_dist, rw.max_dist
         c.target_joint_pos_scale, c.target_feet_height = rw.target_joint_pos_scale, rw.target_feet_height
         c.cycle_time, c.tracking_sigma, c.max_contact_force = rw.cycle_time, rw.tracking_sigma, rw.max_contact_force
-        for k, v in PHYS.items():
+        # sim.physx of the config as far as the contact model has a place for it (include/hx_sim.h): hector_config.py:113-117
+        px = cfg.sim.physx
+        c.max_depenetration_velocity, c.contact_offset, c.rest_offset = float(px.max_depenetration_velocity), float(px.contact_offset), float(px.rest_offset)
+        for k, v in PHYS.items():      # model constants without a config counterpart; studies may also override the three above
             setattr(c, k, v)
         c.terrain_mu = cfg.terrain.static_friction
         c.env_id_offset = self.env_lo

@@ -42,6 +42,12 @@ FRICTION_VEPS = 2.0e-2    # m/s, width of the viscous zone of the regularised Co
 LIMIT_K = 2.0e3           # Nm/rad soft joint limit
 LIMIT_D = 2.0e1           # Nm s/rad
 TERRAIN_MU = 0.6          # reference hector_config.py:50-51
+# the contact inputs the reference states for PhysX (hector_config.py:113-117; include/hx_sim.h hx_sim_cfg): the spring part of a
+# point's normal force is capped at the force that pushes it out at MAX_DEPEN_VEL; a point within CONTACT_OFFSET of the
+# surface is a contact whose approach speed beyond gap / dt is damped; shapes rest at REST_OFFSET
+MAX_DEPEN_VEL = 1.0       # max_depenetration_velocity
+CONTACT_OFFSET = 0.01     # contact_offset
+REST_OFFSET = 0.0         # rest_offset
 
 
 def load_model(path=MODEL_JSON):
@@ -264,8 +270,12 @@ class HectorPhysics:
                     pen = pen.astype(dtp)
                 vb = v[body][:, 3:] + np.cross(v[body][:, :3], r)     # point velocity, body coords
                 vn = np.einsum("ni,ni->n", vb, nrm_b)
-                fn0 = CONTACT_KN * pen - c_n * vn
-                act = (pen > 0) & (fn0 > 0)
+                pen = pen + REST_OFFSET
+                spring = CONTACT_KN * np.maximum(pen, 0.0)
+                if MAX_DEPEN_VEL > 0:
+                    spring = np.minimum(spring, c_n * MAX_DEPEN_VEL)
+                fn0 = spring - c_n * (vn + np.maximum(-pen, 0.0) / dt)
+                act = (pen > -CONTACT_OFFSET) & (fn0 > 0)
                 vt = vb - vn[:, None] * nrm_b
                 vt_norm = np.sqrt(np.einsum("ni,ni->n", vt, vt))
                 c_t = mu * fn0 / np.maximum(vt_norm, FRICTION_VEPS)

@@ -2,20 +2,39 @@
 import numpy as np
 
 # Tolerances of one teacher-forced env step (10 substeps of the fp32 articulated-body algorithm against the float64
-# joint-space oracle), per (step, robot) pair: `tight` must hold for at least 99 % of the pairs, `loose` for all.  The pairs
-# in between are steps in which a contact point crossed its activation threshold (penetration > 0 and force > 0) one substep
-# earlier or later in fp32 than in float64 -- a discontinuity of the contact model, not round-off; their count is printed.
-STEP_TOL = dict(obs=(2e-4, 0.1), priv=(1e-3, 0.3), rew=(2e-5, 5e-3), tau=(0.05, 8.0), contact=(1.0, 150.0))
+# joint-space oracle), per (step, robot) pair.
+#   tight  : holds for every pair except a COUNTED handful per fixture (OVER_TIGHT below: the measured count + a margin of 3);
+#   loose  : holds for every pair, set just above the worst value measured on any fixture.
+# Since round 3 the contact model has no activation jump (a point inside the contact offset is damped on the part of its
+# approach speed that would carry it through the surface: force and its onset are continuous in the state), so the former
+# "a contact switched one substep earlier in fp32" pairs -- up to 1 % of all pairs, with errors of 0.1-0.3 in observations,
+# 8 N m in torques and 150 N in contact forces -- are gone.  What is left are the model's remaining switches: the PD
+# torque crossing its clip (its implicit damping term goes on / off: robot 9 of fixture A at step 24, airborne, joints at their
+# velocity limits: 0.19 rad/s on one base rate, 2.3 N m on a torque), and threshold rewards (contact > 5 N) in fixtures C / H.
+STEP_TOL = dict(obs=(2e-4, 0.4), priv=(1e-3, 0.4), rew=(2e-5, 5e-3), tau=(0.05, 5.0), contact=(1.0, 5.0))
+
+# pairs over the tight bound, measured: {fixture label: {quantity: count}}; everything not listed is 0.  Host build (g++,
+# IEEE fp32) and HIP kernel (hipcc -ffast-math) are listed separately.
+OVER_TIGHT = {
+    "env_rollout_a host build": dict(obs=3, priv=2, tau=2),
+    "env_rollout_c host build": dict(obs=3, rew=5),
+    "env_rollout_h host build": dict(rew=4),
+}
+MARGIN = 3
 
 
-def check_step_errors(label, errs, tol=STEP_TOL, frac=0.99):
+def check_step_errors(label, errs, tol=STEP_TOL, over_tight=None):
+    """errs[k]: list over steps of per-robot errors.  Asserts the COUNT of (step, robot) pairs over the tight bound against
+    the measured count + MARGIN, and the worst pair against the loose bound."""
+    allowed = OVER_TIGHT.get(label, {}) if over_tight is None else over_tight
     report = {}
     for k, (tight, loose) in tol.items():
         e = np.concatenate([np.asarray(x, np.float64).reshape(-1) for x in errs[k]])
         over = int((e > tight).sum())
         report[k] = "median %.1e worst %.1e, %d of %d pairs over %.0e" % (np.median(e), e.max(), over, e.size, tight)
-        assert np.quantile(e, frac) <= tight, f"{label}: {k}: {report[k]}"
-        assert e.max() <= loose, f"{label}: {k}: {report[k]}"
     print(label, "teacher-forced step errors:", report)
-
-
+    for k, (tight, loose) in tol.items():
+        e = np.concatenate([np.asarray(x, np.float64).reshape(-1) for x in errs[k]])
+        over = int((e > tight).sum())
+        assert over <= allowed.get(k, 0) + MARGIN, f"{label}: {k}: {report[k]} (allowed {allowed.get(k, 0)} + {MARGIN})"
+        assert e.max() <= loose, f"{label}: {k}: {report[k]}"

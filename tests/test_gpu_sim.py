@@ -98,8 +98,8 @@ def test_teacher_forced_steps(hxlib, name):
         np.testing.assert_array_equal(env.episode_length_buf.numpy(), fx["ep_len"][t])
         if "levels" in fx:       # terrain curriculum: the row every robot is on after this step's resets
             np.testing.assert_array_equal(env.terrain_levels, fx["levels"][t], err_msg=f"terrain levels differ at step {t}")
-    # observations, rewards, torques AND contact forces: tight for 99 % of the (step, robot) pairs, bounded for the steps in
-    # which a contact point crosses its activation threshold at a different substep (tests/step_errors.py)
+    # observations, rewards, torques AND contact forces: the tight tier for every (step, robot) pair but a counted handful per
+    # fixture, the loose one for all (tests/step_errors.py)
     check_step_errors(name + " HIP kernel", errs)
     env.close()
 
@@ -225,7 +225,7 @@ def test_terrain_contact_matches_oracle(hxlib):
         loaded += int((cf[:, [5, 10], 2] > 20.0).sum())
         tilted += int((np.abs(cf[:, [5, 10], :2]).max(-1) > 0.3 * np.abs(cf[:, [5, 10], 2]) + 1.0).sum())
     # 64 robots that start 5 cm inside the ground (violent first steps) on every tile kind, walls included
-    check_step_errors("terrain contact, HIP kernel vs oracle", errs, frac=0.98)
+    check_step_errors("terrain contact, HIP kernel vs oracle", errs)
     print("loaded feet %d, on inclines %d" % (loaded, tilted))
     assert loaded > 500 and tilted > 20
     env.close()

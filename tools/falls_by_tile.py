@@ -1,48 +1,66 @@
 #!/usr/bin/env python3
-"""Diagnostic (GPU box): train `iters` iterations on the default tile map, then roll the policy for `steps` steps and
-report falls per robot-second by tile kind / difficulty of the tile each robot is assigned to."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-from isaac_amd.envs import *  # noqa
-from isaac_amd.utils import get_args, task_registry
+"""Where do robots fall on the default tile map (mesh_type 'trimesh', 20 x 20 tiles, random difficulty rows as in the
+reference's own training)?  Rolls a policy -- the PhysX-trained actor the reference ships, or a checkpoint trained here --
+with the play protocol (fixed command vx = 0.5 m/s, 10 s, 4096 robots) and prints survival and falls per robot per 10 s by
+tile kind x difficulty tercile, for the build's default and for ablations of the terrain / contact model:
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-args = get_args(["--task=hector", "--headless", "--run_name", "falls", "--max_iterations", str(iters)])
-env_cfg, train_cfg = task_registry.get_cfgs("hector")
-for kv in sys.argv[3:]:
-    k, v = kv.split("=")
-    obj = env_cfg
-    parts = k.split(".")
-    for p in parts[:-1]:
-        obj = getattr(obj, p)
-    setattr(obj, parts[-1], eval(v))
-env, _ = task_registry.make_env(name="hector", args=args, env_cfg=env_cfg)
-runner, _ = task_registry.make_alg_runner(env=env, name="hector", args=args, log_root=None)
-runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)
-policy = runner.get_inference_policy()
-n = env.num_envs
-log = np.array(env.terrain.tile_log).reshape(env_cfg.terrain.num_rows, env_cfg.terrain.num_cols, 2)
-kind = log[env.terrain_levels, env.terrain_types, 0].astype(int)
-diff = log[env.terrain_levels, env.terrain_types, 1]
-obs = env.get_observations()
-falls = np.zeros(n)
-touts = np.zeros(n)
-for t in range(steps):
-    obs, _, _, dones, infos = env.step(policy(obs))
-    d = dones.numpy().astype(bool)
-    to = env.time_out_buf.numpy().astype(bool)
-    falls += d & ~to
-    touts += to
-names = ["flat", "obstacles", "rough", "slope up", "slope down", "stairs up", "stairs down"]
-print(f"after {iters} iterations, {steps} evaluation steps ({steps * env.dt:.0f} s per robot)")
-print("kind          robots  falls/robot/10s   by difficulty tercile (easy, mid, hard)")
-for k in range(7):
-    m = kind == k
-    if not m.any():
-        continue
-    rate = lambda mm: falls[mm].sum() / max(mm.sum(), 1) / (steps * env.dt) * 10.0
-    terc = [rate(m & (diff < 1 / 3)), rate(m & (diff >= 1 / 3) & (diff < 2 / 3)), rate(m & (diff >= 2 / 3))]
-    print(f"{names[k]:12s} {m.sum():6d}  {rate(m):8.2f}          " + "  ".join(f"{x:6.2f}" for x in terc))
-print("overall falls/robot/10s: %.2f" % (falls.sum() / n / (steps * env.dt) * 10))
+  default        trimesh semantics of the reference (walls from slope_treshold, cliff cells flattened), PhysX contact inputs
+  ramps          no walls at all (mesh_type 'heightfield' semantics: wall_height = 0)
+  no_flatten     walls push sideways, but cliff cells keep their ramp surface
+  no_wallpush    cliff cells flattened, but no sideways wall contact
+  plain_contact  max_depenetration_velocity = 0, contact_offset = 0 (the round-2 spring-damper)
+  no_depen_cap / no_offset   one of the two at a time
+
+usage: python tools/falls_by_tile.py [--policy physx|<model_N.pt>] [--variants default,ramps,...] [--push on|off] [--steps 1000]
+GPU box only."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from isaac_amd.utils.actor_eval import load_actor_checkpoint, load_actor_npz, roll_actor  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--policy", default="physx")
+ap.add_argument("--variants", default="default,ramps,no_flatten,no_wallpush,plain_contact")
+ap.add_argument("--push", default="off", choices=["on", "off"])
+ap.add_argument("--steps", type=int, default=1000)
+ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--json", default=None, help="also append one JSON line per variant to this file")
+args = ap.parse_args()
+sd = load_actor_npz(os.path.join(ROOT, "tests", "golden", "actors", "locomotion_net.npz")) if args.policy == "physx" else load_actor_checkpoint(args.policy)
+
+VARIANTS = {
+    "default": dict(),
+    "ramps": dict(edit=lambda c: setattr(c.terrain, "slope_treshold", None)),
+    "no_flatten": dict(flags=1),
+    "no_wallpush": dict(flags=2),
+    "plain_contact": dict(phys=dict(max_depenetration_velocity=0.0, contact_offset=0.0)),
+    "no_depen_cap": dict(phys=dict(max_depenetration_velocity=0.0)),
+    "no_offset": dict(phys=dict(contact_offset=0.0)),
+}
+for name in args.variants.split(","):
+    v = VARIANTS[name]
+
+    def edit(cfg, v=v):
+        cfg.domain_rand.push_robots = args.push == "on"
+        if "edit" in v:
+            v["edit"](cfg)
+    r = roll_actor(sd, num_envs=args.envs, steps=args.steps, mesh_type="trimesh", cfg_edit=edit, phys=v.get("phys"),
+                   terrain_flags=v.get("flags", 0), by_tile=True)
+    print(f"== policy {os.path.basename(args.policy)}  variant {name}  pushes {args.push}: survival {r['survival']:.3f}  "
+          f"falls/robot/10s {r['falls_per_robot_10s']:.2f}  median first fall {r['median_first_fall']:.0f} steps  vx of robots still up {r['mean_vx']:.3f}")
+    print("kind          robots  survival  falls/robot/10s |  survival by difficulty tercile (easy, mid, hard) | falls/robot/10s by tercile")
+    tiles = r["tiles"]
+    for kind in dict.fromkeys(t["kind"] for t in tiles):
+        rows = {t["tercile"]: t for t in tiles if t["kind"] == kind}
+        a = rows["all"]
+        g = lambda k, f: ("%6.2f" % rows[k][f]) if k in rows else "     -"
+        print(f"{kind:12s} {a['robots']:6d}   {a['survival']:6.3f}   {a['falls_per_robot_10s']:8.2f}       |   "
+              + "  ".join(g(k, "survival") for k in ("easy", "mid", "hard")) + "        |   " + "  ".join(g(k, "falls_per_robot_10s") for k in ("easy", "mid", "hard")))
+    sys.stdout.flush()
+    if args.json:
+        with open(args.json, "a") as f:
+            f.write(json.dumps(dict(policy=os.path.basename(args.policy), variant=name, push=args.push, **r)) + "\n")
