@@ -195,6 +195,9 @@ def main():
                     help="learner precision: f32 = the metric's configuration (BASELINE config 2); bf16 = BASELINE config 4 "
                          "(forward/dgrad products on the bf16 matrix cores, fp32 master weights and wgrads) -- a different "
                          "configuration, reported with dtype 'bf16' and never as the headline")
+    ap.add_argument("--storage", default="frames", choices=["frames", "rows"],
+                    help="rollout storage of the observations: frames = every robot's 41 / 70-wide frames once (the build's default), "
+                         "rows = the reference's stacked 615 / 1050-wide rows (stacking and gather launches; for A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic, one rank only: walk the N > 1 code path (RCCL all-reduce per optimiser step, as identity) "
@@ -258,6 +261,7 @@ def main():
     tcfg = class_to_dict(train_cfg)
     if args.dtype != "f32":
         tcfg["algorithm"]["mlp_dtype"] = args.dtype          # extra PPO keyword of this build (hx_ppo_set_compute_dtype)
+    tcfg["runner"]["observation_storage"] = args.storage
     runner = OnPolicyRunner(env, tcfg, log_dir=None, device=f"cuda:{local}", comm=comm)
     T = runner.num_steps_per_env
 
@@ -308,7 +312,7 @@ def main():
                                       f"critic {dims(train_cfg.policy.critic_hidden_dims)}"
                                       + ("" if args.dtype == "f32" else " (bf16 forward/dgrad MFMA, fp32 master weights)"),
                           "num_envs_per_gpu": args.envs, "num_steps_per_env": T, "parallelism": f"dp{world}",
-                          "terrain": args.terrain, "env_shards": args.shards, **({"forced_collectives": True} if args.force_collectives else {}), "collection_s": runner.last_perf.get("collection_time"),
+                          "terrain": args.terrain, "env_shards": args.shards, "observation_storage": ("frames" if getattr(runner.alg, "frames", None) else "rows"), **({"forced_collectives": True} if args.force_collectives else {}), "collection_s": runner.last_perf.get("collection_time"),
                           "learn_s": runner.last_perf.get("learn_time")}}
         if prof is not None and prof["kernels"]:
             k = max(prof["kernels"], key=lambda r: r["ms"])

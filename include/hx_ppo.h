@@ -40,6 +40,14 @@ typedef struct hx_ppo_cfg {
   float desired_kl;
   float init_noise_std;
   int32_t obs_ld, priv_ld;                /* row strides of the obs / privileged-obs buffers given to hx_ppo_act */
+  /* Single-frame observation storage (include/hx_sim.h hx_sim_step_frames; 0 / 0 / 0 / 0 = rows are stored as given, the
+   * reference's layout).  With obs_frame * obs_stack == num_obs and priv_frame * priv_stack == num_priv the rollout storage
+   * keeps every robot's frames once -- [N][T + stack][frame] instead of [T][N][stack * frame]: 135 MB instead of 1.64 GB at
+   * 4096 robots -- and the first-layer products of both networks (forward and weight gradient), the fused rollout actor and
+   * the deferred critic read their rows through (row start, first valid element) tables straight from it; no stacking
+   * launch, no minibatch gather, bit-identical results.  Such a learner is driven by hx_rollout (one simulator, fp32 mode);
+   * hx_ppo_act / hx_ppo_process_step, which take ready-made rows, are refused. */
+  int32_t obs_frame, priv_frame, obs_stack, priv_stack;
 } hx_ppo_cfg;
 
 typedef struct hx_ppo hx_ppo;
@@ -54,7 +62,8 @@ enum hx_ppo_buffer_id {
   HX_PPO_BUF_ADVANTAGES,    /* float [T][N] */
   HX_PPO_BUF_GRADS,         /* float [padded params + 4] flat gradient + statistics buffer */
   HX_PPO_BUF_PERM,          /* int32 [T*N] minibatch permutation in use */
-  HX_PPO_BUF_OBS,           /* float [T][N][obs_ld]   RolloutStorage.observations (rollout_storage.py:60) */
+  HX_PPO_BUF_OBS,           /* float [T][N][obs_ld]   RolloutStorage.observations (rollout_storage.py:60); with frame storage
+                               the rows do not exist in memory: hx_ppo_storage_rows expands them on request */
   HX_PPO_BUF_PRIV,          /* float [T][N][priv_ld]  RolloutStorage.privileged_observations */
   HX_PPO_BUF_DONES,         /* uint8 [T][N] */
   HX_PPO_BUF_TIMEOUTS       /* uint8 [T][N]  infos["time_outs"] as the step saw them (stale on steps without a reset) */
@@ -148,13 +157,10 @@ int hx_ppo_update(hx_ppo* p, const int32_t* perm, float* stats_h);
  * to the host language; sims[h] simulates env rows [env0[h], env0[h]+count[h]).  hx_sim is declared in hx_sim.h. */
 struct hx_sim;
 int hx_rollout(hx_ppo* p, struct hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps);
-/* PPO.act (ppo.py:91-101) on observation rows that a deferred env step left for the consumer to assemble
- * (include/hx_sim.h hx_sim_step_deferred): the fused rollout actor builds the rows of the current slot from `pending`
- * while staging them, stores them to the slot and does the step's bookkeeping.  Whole batch only; what hx_rollout uses
- * on every step but the first and the last of a rollout.  `priv` = the slot's privileged rows (assembled by the next
- * env-step launch; not read here). */
-struct hx_pending_step;
-int hx_ppo_act_pending(hx_ppo* p, const struct hx_pending_step* pending, const float* priv, float** actions_out);
+/* RolloutStorage.observations / .privileged_observations of slots [t0, t1) as rows [t1 - t0][N][ld], whatever the storage
+ * layout (frame storage: expanded from the frames with the zeroed history of reset robots; t1 may be num_steps + 1 to
+ * include the rows after the last step).  which = HX_PPO_BUF_OBS or HX_PPO_BUF_PRIV; dst = device memory of the caller. */
+int hx_ppo_storage_rows(hx_ppo* p, int which, int t0, int t1, float* dst);
 
 int hx_ppo_buffer(hx_ppo* p, int which, void** dptr);
 int hx_ppo_get_lr(hx_ppo* p, float* lr_h);

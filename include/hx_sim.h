@@ -189,17 +189,26 @@ int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const flo
  * HX_BUF_OBS / HX_BUF_PRIV then point at obs_dst / priv_dst until the next step. */
 int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
                    float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst);
-/* Deferred frame stacking (the rollout fast path of hx_rollout; no reference counterpart: it moves WHERE the rows of
- * hector_env.py:246-254 are assembled, not what they are).  hx_sim_step_deferred is hx_sim_step_ex without the stacking
- * launch: the observation rows of the step and its per-step bookkeeping (extras["time_outs"], reward / done hand-over,
- * episode statistics) are described in *pending for the consumer that reads the rows next -- the fused rollout actor
- * builds them while staging its input -- and the privileged rows are assembled by spare workgroups of the NEXT env-step
- * launch.  The caller must either consume *pending (then call hx_sim_pending_consumed) or take another hx_sim_* step, which
- * flushes whatever is still pending before it does anything else.  Plain device pointers, valid until the next step. */
-typedef struct hx_row_stack {      /* dst[e] = [ reset[e] ? 0 : src[e][f:] | clip(frame[:, e]) ], `stack` frames of width f, row stride ld */
-  const float* src; float* dst; const float* frame; const uint8_t* reset;
-  int32_t n, f, ld, stack; float clip;
-} hx_row_stack;
+/* Single-frame observation storage (the rollout fast path of hx_rollout; no reference counterpart: it changes WHERE the
+ * 15-frame rows of hector_env.py:246-254 live, not what they are).  The reference re-materialises every robot's
+ * [15 x 41] / [15 x 70] stack each step and stores all of them (rollout_storage.py:60-61: 1.64 GB per 60-step rollout at 4096
+ * robots).  Consecutive rows of one robot share 14 of their 15 frames, so here the consumer keeps each robot's frames ONCE, in
+ * time order and contiguous --  frame p of env e at  base + e * env_stride + p * width  -- and row t is the window of
+ * `stack` frames that ends at the frame the step before t produced; `age` = how many frames of that window are real (1..stack):
+ * the reference zeroes a robot's whole history on reset (hector_env.py:256-261), so the first stack - age frames of the row
+ * read as zero.  hx_sim_step_frames is hx_sim_step_ex without the stacking launch: the new (clipped) frames, the row's age and
+ * the first valid element index (kz = (stack - age) * width, what the learner's loaders compare against) go straight to the
+ * consumer's slots.  Reward / done / extras["time_outs"] of the step and the episode statistics are handed over by the NEXT
+ * reader of the rows (they depend on this launch's total reset count): hx_sim_take_book returns the pointers and the consumer
+ * runs hx_step_book_row / _global (hx_common.h) for every robot once -- the fused rollout actor does it while staging its
+ * rows -- or calls hx_sim_flush_book.  hx_sim_export_stack writes the simulator's CURRENT rows as frames 0..stack-1 of every
+ * robot (start of a rollout), hx_sim_import_stack rebuilds the simulator's own row buffers (HX_BUF_OBS / HX_BUF_PRIV) from
+ * the consumer's frames (end of a rollout), so the row API stays valid around a frame-mode rollout. */
+typedef struct hx_frame_slot {     /* where one step's outputs go */
+  float* obs; int64_t obs_env_stride;     /* frame slot of env 0 and the distance between envs, in floats */
+  float* priv; int64_t priv_env_stride;
+  int32_t* obs_kz; int32_t* priv_kz;      /* [N] first valid element of the row this frame completes */
+} hx_frame_slot;
 typedef struct hx_step_book {      /* what the stacking launch does besides the rows */
   const uint8_t* reset; const uint8_t* timeout; uint8_t* timeout_visible;
   const int32_t* num_reset; int32_t* num_reset_next;
@@ -207,15 +216,18 @@ typedef struct hx_step_book {      /* what the stacking launch does besides the 
   const float* rew; float* rew_out; uint8_t* done_out; uint8_t* timeout_out;
   int32_t n;
 } hx_step_book;
-typedef struct hx_pending_step { int32_t valid; hx_row_stack obs; hx_step_book book; } hx_pending_step;
-int hx_sim_step_deferred(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
-                         float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst, hx_pending_step* pending);
-int hx_sim_pending_consumed(hx_sim* s);
+int hx_sim_step_frames(hx_sim* s, const float* actions, const float* pack, const hx_frame_slot* dst,
+                       float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst);
+int hx_sim_take_book(hx_sim* s, hx_step_book* book /*out*/, int32_t* valid /*out: 1 if a step's bookkeeping is still owed*/);
+int hx_sim_flush_book(hx_sim* s);
+int hx_sim_export_stack(hx_sim* s, const hx_frame_slot* first /* slot of frame 0; kz arrays = those of row 0 */);
+int hx_sim_import_stack(hx_sim* s, const hx_frame_slot* first /* slot of the row's oldest frame; kz arrays = the row's */);
 int hx_sim_buffer(hx_sim* s, int which, void** dptr);
 int hx_sim_get_state(hx_sim* s, float* root13_h /*[N][13]*/, float* q_h /*[N][10]*/, float* qd_h /*[N][10]*/);
 int hx_sim_set_state(hx_sim* s, const float* root13_h, const float* q_h, const float* qd_h);
 int hx_sim_set_episode_length(hx_sim* s, const int32_t* ep_len_h);
 int hx_sim_set_step_counter(hx_sim* s, int64_t common_step_counter);
+int64_t hx_sim_step_counter(hx_sim* s);      /* common_step_counter (legged_robot.py:128): env steps taken so far */
 /* play-style access (reference humanoid/scripts/play.py:136-140,160-175): overwrite `env.commands` [N][4]
  * (vx, vy, yaw rate, heading) before a step, and read `env.base_lin_vel` / `env.base_ang_vel` [N][3] (base frame,
  * legged_robot.py:132-133) after it.  Host pointers; both synchronise the simulator's stream. */

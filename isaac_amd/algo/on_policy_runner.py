@@ -49,8 +49,14 @@ class OnPolicyRunner:
                                                               comm=comm, **alg_kw)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
+        # an env served by one simulator object reports its frame dimensions: the learner then keeps single-frame observation
+        # storage and the rollout runs without stacking / gather launches (a sharded env keeps the row layout)
+        # runner.observation_storage = "rows" (not a reference key) keeps the reference's stacked-row layout for A/B runs
+        frames = getattr(env, "frame_dims", None) if (hasattr(env, "_h") and hasattr(self.alg, "rollout")) else None
+        if self.cfg.get("observation_storage", "frames") == "rows":
+            frames = None
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions],
-                              obs_ld=getattr(env, "obs_ld", None), priv_ld=getattr(env, "priv_ld", None))
+                              obs_ld=getattr(env, "obs_ld", None), priv_ld=getattr(env, "priv_ld", None), frames=frames)
         # one writer per job: ranks other than 0 neither create directories nor write scalars or checkpoints (their
         # parameters are bit-identical to rank 0's); Episode/* and Train/* scalars are summed over ranks in log()
         self.is_chief = comm is None or comm.rank == 0

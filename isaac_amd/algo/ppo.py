@@ -160,7 +160,11 @@ class PPO:
 
     # ------------------------------------------------------------------ construction
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape,
-                     obs_ld=None, priv_ld=None):
+                     obs_ld=None, priv_ld=None, frames=None):
+        """frames = (obs_frame, priv_frame, obs_stack, priv_stack) -- what an env reports as `frame_dims` -- selects single-frame
+        observation storage (include/hx_ppo.h hx_ppo_cfg.obs_frame): the rollout storage keeps every robot's frames once and
+        the learner's first layers read their rows in place; such a learner is driven by rollout() (hx_rollout), act() and
+        process_env_step() with ready-made rows are refused.  None: rows are stored as given (the reference's layout)."""
         ac = self.actor_critic
         c = capi.PpoCfg()
         c.num_envs, c.num_steps = num_envs, num_transitions_per_env
@@ -177,6 +181,10 @@ class PPO:
         c.init_noise_std = ac.init_noise_std
         c.obs_ld = obs_ld if obs_ld is not None else (c.num_obs + 3) // 4 * 4
         c.priv_ld = priv_ld if priv_ld is not None else (c.num_priv + 3) // 4 * 4
+        self.frames = None
+        if frames is not None and self.mlp_dtype == "f32":      # the bf16 kernels read ready-made rows
+            c.obs_frame, c.priv_frame, c.obs_stack, c.priv_stack = (int(x) for x in frames)
+            self.frames = tuple(int(x) for x in frames)
         if (num_envs * num_transitions_per_env) % self.num_mini_batches:
             raise ValueError("num_envs * num_steps_per_env must be divisible by num_mini_batches")
         self._cfg = c
@@ -340,6 +348,15 @@ class PPO:
         out = capi.DeviceBuffer(rows * self.A * 4)
         capi.check(self._L.hx_ppo_inference(self._h, po, rows, out.ptr), "inference")
         return DeviceArray(out.ptr, (rows, self.A), np.float32, None, self.stream, owner=out)
+
+    def storage_rows(self, which, t0=0, t1=None):
+        """RolloutStorage.observations / .privileged_observations of slots [t0, t1) as a [t1 - t0, N, ld] device array, whatever
+        the storage layout (hx_ppo_storage_rows; with frame storage t1 may be T + 1)."""
+        t1 = self.T if t1 is None else t1
+        ld = self.obs_ld if which == capi.PPO_BUF_OBS else self.priv_ld
+        out = capi.DeviceBuffer((t1 - t0) * self.N * ld * 4)
+        capi.check(self._L.hx_ppo_storage_rows(self._h, which, t0, t1, out.ptr), "hx_ppo_storage_rows")
+        return DeviceArray(out.ptr, (t1 - t0, self.N, ld), np.float32, None, self.stream, owner=out)
 
     def buffer(self, which, shape, dtype=np.float32):
         p = capi.C.c_void_p()

@@ -71,6 +71,7 @@ class PpoCfg(C.Structure):
         ("entropy_coef", C.c_float), ("learning_rate", C.c_float), ("max_grad_norm", C.c_float),
         ("use_clipped_value_loss", C.c_int32), ("adaptive_schedule", C.c_int32), ("desired_kl", C.c_float),
         ("init_noise_std", C.c_float), ("obs_ld", C.c_int32), ("priv_ld", C.c_int32),
+        ("obs_frame", C.c_int32), ("priv_frame", C.c_int32), ("obs_stack", C.c_int32), ("priv_stack", C.c_int32),
     ]
 
 
@@ -168,9 +169,7 @@ def lib():
     L.hx_ppo_update_end.argtypes = [vp, vp]
     L.hx_ppo_update.argtypes = [vp, vp, vp]
     L.hx_rollout.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int]
-    L.hx_sim_step_deferred.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]        # last: hx_pending_step* (include/hx_sim.h)
-    L.hx_sim_pending_consumed.argtypes = [vp]
-    L.hx_ppo_act_pending.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    L.hx_ppo_storage_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     L.hx_ppo_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hx_ppo_get_lr.argtypes = [vp, vp]
     L.hx_ppo_set_lr.argtypes = [vp, C.c_float]

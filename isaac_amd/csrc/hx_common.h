@@ -15,30 +15,11 @@ void hx_set_error(const std::string& s);
     }                                                                                          \
   } while (0)
 
-// ---- device side of the deferred frame stacking (include/hx_sim.h hx_pending_step): shared by the env-step launch
-// (privileged rows, hx_sim.hip) and the fused rollout actor (observation rows + bookkeeping, hx_ppo.hip), and equal to what
-// hx_stack_kernel does for the same step.
+// ---- per-step bookkeeping that depends on the env-step launch's TOTAL reset count and therefore runs in the launch that
+// follows it: the stacking kernel (row API), or the consumer of a frame-mode step (include/hx_sim.h hx_sim_take_book) -- the
+// fused rollout actor while it stages its rows, or hx_book_kernel.
 #if defined(__HIPCC__)
 #include "../../include/hx_sim.h"
-__device__ __forceinline__ float hx_row_stack_value(const hx_row_stack& a, int e, bool rst, int k) {
-  const int keep = (a.stack - 1) * a.f;
-  if (k < keep) return rst ? 0.f : a.src[(size_t)e * a.ld + k + a.f];
-  if (k < keep + a.f) return fminf(fmaxf(a.frame[(size_t)(k - keep) * a.n + e], -a.clip), a.clip);
-  return 0.f;
-}
-// The same value without divergent control flow around the load (the address is selected, the load is unconditional), so
-// that a caller can keep a batch of them in flight: hipcc drains the VM counter at every guarded load otherwise.
-__device__ __forceinline__ const float* hx_row_stack_addr(const hx_row_stack& a, int e, int k) {
-  const int keep = (a.stack - 1) * a.f;
-  const int kf = min(max(k - keep, 0), a.f - 1);
-  return (k < keep) ? a.src + (size_t)e * a.ld + k + a.f : a.frame + (size_t)kf * a.n + e;
-}
-__device__ __forceinline__ float hx_row_stack_finish(const hx_row_stack& a, bool rst, int k, float loaded) {
-  const int keep = (a.stack - 1) * a.f;
-  const float hist = rst ? 0.f : loaded;
-  const float fresh = fminf(fmaxf(loaded, -a.clip), a.clip);
-  return (k < keep) ? hist : ((k < keep + a.f) ? fresh : 0.f);
-}
 // per-env part: extras["time_outs"] is rebound only inside reset_idx, i.e. when at least one env reset this step
 // (legged_robot.py:172-173,208-209); reward / done / time-out go to the learner's slot
 __device__ __forceinline__ void hx_step_book_row(const hx_step_book& b, int e) {

@@ -35,6 +35,7 @@ struct SimPtrs {
   float* priv_frame;  // [PRIVF][N]
   float* rew;         // [N]
   unsigned char* reset;    // [N]
+  unsigned char* age;      // [N] real frames in the robot's observation history (1 .. frame_stack)
   unsigned char* timeout;  // [N]
   int* num_reset;     // [1]
   // episode statistics as the runner logs them (legged_robot.py:198-201 + on_policy_runner.py:140-154,181-195):
@@ -70,10 +71,12 @@ struct StepArgs {
   int mode;                  // 0: step, 1: constructor reset (reset all + first observation)
   long long step_counter;    // common_step_counter AFTER the increment of this step
   uint32_t k0, k1, rng_step;
-  // device launches only: workgroups [env_blocks, env_blocks + stack_blocks) assemble the privileged rows of the PREVIOUS
-  // step (deferred frame stacking, include/hx_sim.h) on SIMDs the env-step waves leave idle
-  int env_blocks, stack_blocks;
-  hx_row_stack pstack;
+  // single-frame observation storage (include/hx_sim.h hx_sim_step_frames): frames != 0 -> the new frames go, clipped, to the
+  // consumer's slots in env-major layout together with the first valid element of the row they complete; else to the
+  // [frame][env] buffers the stacking kernel reads
+  int frames, obs_stack, priv_stack;
+  float clip;
+  hx_frame_slot fs;
 };
 
 // ---------------------------------------------------------------- counter-based RNG (Philox4x32-10)
@@ -573,7 +576,10 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
         if (sv != 0.f) o[k] = o[k] + eps[k] * sv * cfg.noise_level;
       }
     }
-    if (writer) for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
+    if (writer) {
+      if (A.frames) { float* d = A.fs.obs + (size_t)e * A.fs.obs_env_stride; for (int k = 0; k < OBSF; ++k) d[k] = fminf(fmaxf(o[k], -A.clip), A.clip); }
+      else for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
+    }
     if constexpr (M::XBOT) {
       // humanoid_env.py:218-236: [cmd 5, q, dq, a, q - ref_dof_pos, lin vel 3, ang vel 3, euler 3, push 2 + 3, friction, mass / 30,
       // stance 2, contact 2]; ref_dof_pos of THIS call (compute_ref_state :121-143 runs first)
@@ -601,7 +607,10 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
       f[PB + 29] = R.friction; f[PB + 30] = R.base_mass / 30.f;
       f[PB + 31] = sm[0]; f[PB + 32] = sm[1]; f[PB + 33] = contact[0] ? 1.f : 0.f; f[PB + 34] = contact[1] ? 1.f : 0.f;
     }
-    if (writer) for (int k = 0; k < PRIVF; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+    if (writer) {
+      if (A.frames) { float* d = A.fs.priv + (size_t)e * A.fs.priv_env_stride; for (int k = 0; k < PRIVF; ++k) d[k] = fminf(fmaxf(f[k], -A.clip), A.clip); }
+      else for (int k = 0; k < PRIVF; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+    }
   }
 
   // ---- bookkeeping (legged_robot.py:146-150) and store
@@ -633,6 +642,13 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   p.rew[e] = rew_total;
   p.reset[e] = reset ? 1 : 0;
   p.timeout[e] = time_out ? 1 : 0;
+  {
+    // frames of the robot's history that are real: a reset zeroes the whole history before the new frame is appended
+    // (hector_env.py:256-261 then :246-247), so the row a reset step completes holds one frame
+    const int age = reset ? 1 : hx_imin((int)p.age[e] + 1, A.obs_stack);
+    p.age[e] = (unsigned char)age;
+    if (A.frames) { A.fs.obs_kz[e] = (A.obs_stack - age) * OBSF; A.fs.priv_kz[e] = hx_imax(A.priv_stack - age, 0) * PRIVF; }
+  }
   // diagnostic tensors (contact_forces / rigid_state views of the reference)
   {
     p.contact[(size_t)0 * n + e] = R.f_base.x; p.contact[(size_t)1 * n + e] = R.f_base.y; p.contact[(size_t)2 * n + e] = R.f_base.z;

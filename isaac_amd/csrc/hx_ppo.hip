@@ -173,6 +173,9 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
 // hx_gemm.h a float4 per lane (k = 4*(l>>4) .. +3 of a 16-deep block) feeds 4 MFMAs.  C/D: col = l&15, row = 4*(l>>4)+reg.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define FA_ROWS 16
+// rows that live as windows of per-robot frame rings (single-frame observation storage): row r = base + off[r], elements
+// [0, kz[r]) and [klim, ..) read as zero.  base == nullptr: ordinary rows.
+struct FrameSrc { const float* base; const int* off; const int* kz; int klim; };
 // operand rounding of the mixed-precision mode: fp32 -> bf16 (RNE) -> fp32, so that an fp32 MFMA on the rounded values
 // reproduces what the bf16 matrix cores compute in the update (up to summation order)
 __device__ __forceinline__ float hx_bf16r(float x) { return (float)(__bf16)x; }
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
                                                              const float* __restrict__ W4, const float* __restrict__ b4,
                                                              const float* __restrict__ stdp, const float* __restrict__ eps, int A,
                                                              uint32_t k0, uint32_t k1, uint32_t step, uint32_t row_base,
-                                                             float* actions, float* mu_out, float* logp, hx_pending_step pend) {
+                                                             float* actions, float* mu_out, float* logp, FrameSrc fsrc, hx_step_book book, int book_valid) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
   float* Xs = fsm;
@@ -285,36 +288,22 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   const int row0 = blockIdx.x * FA_ROWS;
   f32x4v p1a[32 / NW], p1b[32 / NW], p2a[16 / NW], p2b[16 / NW], p3a[8 / NW], p3b[8 / NW];
   fa_prefetch<32 / NW>(W1, K1, wave * (512 / NW), lane, p1a, p1b);
-  if (pend.valid) {
-    // Deferred frame stacking (include/hx_sim.h): the rows this workgroup is about to read do not exist yet -- they are the
-    // previous rows shifted by one frame plus the frame the env step just produced.  Assemble them into LDS, store them to
-    // their slot (`obs`, = pend.obs.dst) for the update, and do the step's bookkeeping for these 16 robots.
-    // all of a thread's loads in flight together (the stores may alias later loads as far as the compiler knows, so the
-    // batching is written out)
+  if (fsrc.base != nullptr) {
+    // Single-frame storage (include/hx_sim.h): the 16 rows are windows of the robots' frame rings.  Row start and first valid
+    // element come from the tables; elements before it (frames older than the robot's last reset) and the padding read as
+    // zero.  Row starts are only float-aligned (41-wide frames), so the loads are scalar, coalesced along the row.
     const int total = FA_ROWS * K1;
-    constexpr int NB = 96 / NW;              // 16 rows x <= 768 values = all of a thread's share in one batch
-    for (int i0 = tid; i0 < total; i0 += 64 * NW * NB) {
-      float v[NB]; unsigned char rs[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int i = min(i0 + 64 * NW * u, total - 1);
-        const int r = i / K1, k = i - r * K1, gr = min(row0 + r, n - 1);
-        v[u] = *hx_row_stack_addr(pend.obs, gr, k);
-        rs[u] = pend.obs.reset[gr];
-      }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int i = i0 + 64 * NW * u;
-        if (i < total) {
-          const int r = i / K1, k = i - r * K1, gr = min(row0 + r, n - 1);
-          const float o = hx_row_stack_finish(pend.obs, rs[u] != 0, k, v[u]);
-          Xs[r * ldx + k] = BF ? hx_bf16r(o) : o;
-          if (row0 + r < n) pend.obs.dst[(size_t)gr * obs_ld + k] = o;
-        }
-      }
+    for (int i = tid; i < total; i += 64 * NW) {
+      const int r = i / K1, k = i - r * K1, gr = min(row0 + r, n - 1);
+      const float v = fsrc.base[(size_t)fsrc.off[gr] + k];          // always inside the ring (+ slack): no guard around the load
+      const float o = (k >= fsrc.kz[gr] && k < fsrc.klim) ? v : 0.f;
+      Xs[r * ldx + k] = BF ? hx_bf16r(o) : o;
     }
-    if (tid < FA_ROWS && row0 + tid < n) hx_step_book_row(pend.book, row0 + tid);
-    if (blockIdx.x == 0 && tid == 64) hx_step_book_global(pend.book);
+    // bookkeeping of the env step that produced these rows (it needs that launch's total reset count, hx_common.h)
+    if (book_valid) {
+      if (tid < FA_ROWS && row0 + tid < n) hx_step_book_row(book, row0 + tid);
+      if (blockIdx.x == 0 && tid == 64) hx_step_book_global(book);
+    }
   } else {
     // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
     for (int i = tid; i < FA_ROWS * (K1 / 4); i += 64 * NW) {
@@ -501,6 +490,33 @@ __global__ void __launch_bounds__(256) hx_gather_kernel(GatherArgs g) {
   float* r = g.row_mb + (size_t)m * W;
   if (threadIdx.x < g.A) { r[threadIdx.x] = g.actions[(size_t)src * g.A + threadIdx.x]; r[g.A + threadIdx.x] = g.mu[(size_t)src * g.A + threadIdx.x]; }
   if (threadIdx.x == 32) { r[2 * g.A] = g.values[src]; r[2 * g.A + 1] = g.returns[src]; r[2 * g.A + 2] = g.logp[src]; r[2 * g.A + 3] = g.adv[src]; }
+}
+
+// Single-frame storage: what the gather becomes.  For every position i of the permutation the row start / first valid element
+// of both streams and the per-row scalars, in minibatch order -- 4 ints + 24 floats per row instead of 1668 floats.
+struct MbTableArgs {
+  const int* perm; int TN;
+  const int* off_obs; const int* off_priv; const int* kz_obs; const int* kz_priv;
+  int* mb_off_obs; int* mb_off_priv; int* mb_kz_obs; int* mb_kz_priv;
+  const float* actions; const float* mu; const float* values; const float* returns; const float* logp; const float* adv;
+  int A; float* row_mb;
+};
+__global__ void __launch_bounds__(256) hx_mb_tables_kernel(MbTableArgs g) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.TN) return;
+  const int src = g.perm[i];
+  g.mb_off_obs[i] = g.off_obs[src]; g.mb_off_priv[i] = g.off_priv[src]; g.mb_kz_obs[i] = g.kz_obs[src]; g.mb_kz_priv[i] = g.kz_priv[src];
+  float* r = g.row_mb + (size_t)i * (2 * g.A + 4);
+  for (int j = 0; j < g.A; ++j) { r[j] = g.actions[(size_t)src * g.A + j]; r[g.A + j] = g.mu[(size_t)src * g.A + j]; }
+  r[2 * g.A] = g.values[src]; r[2 * g.A + 1] = g.returns[src]; r[2 * g.A + 2] = g.logp[src]; r[2 * g.A + 3] = g.adv[src];
+}
+// rows [count][ld] of a frame-stored stream, expanded (hx_ppo_storage_rows): one workgroup per row
+__global__ void __launch_bounds__(256) hx_expand_rows_kernel(const float* __restrict__ base, const int* __restrict__ off, const int* __restrict__ kz, int klim, int ld,
+                                                             float* __restrict__ dst) {
+  const int r = blockIdx.x;
+  const float* src = base + off[r];
+  const int z = kz[r];
+  for (int k = threadIdx.x; k < ld; k += blockDim.x) dst[(size_t)r * ld + k] = (k >= z && k < klim) ? src[k] : 0.f;
 }
 
 // Loss head (ppo.py:128-166 forward of the last layers, all loss terms, and their backward down to the
@@ -870,6 +886,14 @@ struct hx_ppo {
   // storage
   float *s_obs, *s_priv, *s_actions, *s_mu, *s_values, *s_logp, *s_rewards, *s_returns, *s_adv_raw, *s_adv, *sigma_old;
   unsigned char* s_dones; unsigned char* s_timeouts;
+  // single-frame observation storage (hx_ppo_cfg.obs_frame ...; include/hx_sim.h): s_obs / s_priv are per-robot frame rings
+  // [N][Po][fo] / [N][Pp][fp] then; row (t, e) starts at off_*[t * N + e] and its first kz_*[t * N + e] elements read as zero
+  bool frames = false;
+  int fo = 0, fp = 0, So = 0, Sp = 0, Po = 0, Pp = 0;
+  int *off_obs = nullptr, *off_priv = nullptr;          // [(T + 1) * N] row starts (float offsets), fixed at creation
+  int *kz_obs = nullptr, *kz_priv = nullptr;            // [(T + 1) * N] first valid element of every stored row, written by the env step
+  int *mb_off_obs = nullptr, *mb_off_priv = nullptr, *mb_kz_obs = nullptr, *mb_kz_priv = nullptr;   // [T * N] the same in minibatch (permutation) order
+  long long frames_sim_step = -1;                        // simulator step counter right after the last frame-mode rollout step
   int crit_done;                 // rollout slots [0, crit_done) already have their critic values
   hipEvent_t ev_priv, ev_crit;   // priv rows of a slot copied (main stream) / deferred critic finished (stream2)
   int critic_chunk;              // rollout slots per deferred critic batch (HX_CRITIC_CHUNK, default 2)
@@ -976,10 +1000,24 @@ static void refresh_transposes(hx_ppo* s, hipStream_t st) {
 // Variant choice is from measurement (tools/gemm_bench.py, profiles/r01_gemm_variants*.txt): after the branch-free
 // epilogue all variants are within ~5 %; BK = 32 is best for the forward layers and 64-row BK = 32 tiles for dgrad
 // (short K = 128..256, where a shorter launch tail matters most).
+// rows given as windows of the frame rings (first layer of a network with single-frame storage): table slices for the M rows
+struct RowTable { const int* off; const int* kz; int klim; };
 static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K,
-                     bool background = false, bool fp32_only = false) {
+                     bool background = false, bool fp32_only = false, const RowTable* rt = nullptr) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
+  if (rt) {
+    // gathered A rows: BK16 tiles (K = 616 / 1052 are not multiples of 32), 128-row tiles at update size, 64-row below, the
+    // persistent half-chip grid for the rollout's background critic
+    g.a_off = rt->off; g.a_kz = rt->kz; g.a_klim = rt->klim;
+    if (background && s->bg_persist > 0) {
+      g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 127) / 128;
+      hipLaunchKernelGGL((hx_gemm_persistent_kernel<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU, false, true, false>), dim3(s->bg_persist), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
+    }
+    else if (M >= 8192) launch_gemm<128, 128, 16, true, true, EPI_BIAS_ELU, false, true, false>(s, g, st);
+    else launch_gemm<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU, false, true, false>(s, g, st);
+    return;
+  }
   // K a multiple of 32: 128x128 tiles, BK 32.  The two input layers (K = 616 / 1052) would pad 24 / 4 k-steps per tile
   // at BK 32; 64-row BK 16 tiles waste less and measured 3-6 % faster there (profiles/r01_e_gemm_loops.txt).
   // Background launches (the deferred critic beside the rollout) take the 128x128 BK16 kernel: 37 KB of LDS per
@@ -1017,8 +1055,9 @@ static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, cons
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab; *bias_parts = number of
 // partial rows written to bias_slab (splits x the tile_n blocks that share the column-sum work)
 static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab,
-                      int* bias_parts, int alloc_splits) {
+                      int* bias_parts, int alloc_splits, const RowTable* rt = nullptr) {
   GemmArgs g{};
+  if (rt) { g.b_off = rt->off; g.b_kz = rt->kz; g.b_klim = rt->klim; }
   g.A = dZ; g.lda = out; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = Mrows;
   const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
   // Split-K grid = ONE full wave of workgroups: 3 resident per CU (144 VGPRs -> 3 waves per SIMD; 32 KB LDS), never
@@ -1057,6 +1096,11 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
     return splits;
   }
   // kchunk is a multiple of 32; with a row count that is a multiple of the K tile every split is whole tiles
+  if (rt) {        // X rows gathered from the frame rings
+    if (Mrows % HX_BK_UPD == 0) launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true, false, true>(s, g, st);
+    else launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, false, false, true>(s, g, st);
+    return splits;
+  }
   if (Mrows % HX_BK_UPD == 0) launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true>(s, g, st);
   else launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
   return splits;
@@ -1361,8 +1405,32 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   rc |= palloc(s, &s->v, s->padded);
   // ---- storage
   const size_t TN = (size_t)T * N;
-  rc |= palloc(s, &s->s_obs, TN * cfg->obs_ld);
-  rc |= palloc(s, &s->s_priv, TN * cfg->priv_ld);
+  s->frames = cfg->obs_frame > 0 || cfg->priv_frame > 0 || cfg->obs_stack > 0 || cfg->priv_stack > 0;
+  if (s->frames) {
+    if (cfg->obs_frame * cfg->obs_stack != cfg->num_obs || cfg->priv_frame * cfg->priv_stack != cfg->num_priv || cfg->obs_frame < 1 || cfg->priv_frame < 1) {
+      hx_set_error("hx_ppo_create: frame storage needs obs_frame * obs_stack == num_obs and priv_frame * priv_stack == num_priv"); return -2;
+    }
+    s->fo = cfg->obs_frame; s->fp = cfg->priv_frame; s->So = cfg->obs_stack; s->Sp = cfg->priv_stack; s->Po = T + s->So; s->Pp = T + s->Sp;
+    const size_t no = (size_t)N * s->Po * s->fo, np = (size_t)N * s->Pp * s->fp;
+    if (no + 64 >= (1ull << 31) || np + 64 >= (1ull << 31)) { hx_set_error("hx_ppo_create: frame rings beyond 2^31 floats (row starts are 32-bit offsets)"); return -2; }
+    // + slack: the 16-byte loads of a row's last tile and the padding columns reach a few floats past the last ring; those
+    // elements are masked but must be readable and finite (the buffers are zero-filled)
+    rc |= palloc(s, &s->s_obs, no + 64);
+    rc |= palloc(s, &s->s_priv, np + 64);
+    rc |= palloc(s, &s->off_obs, (TN + N)); rc |= palloc(s, &s->off_priv, (TN + N));
+    rc |= palloc(s, &s->kz_obs, (TN + N)); rc |= palloc(s, &s->kz_priv, (TN + N));
+    rc |= palloc(s, &s->mb_off_obs, TN); rc |= palloc(s, &s->mb_off_priv, TN); rc |= palloc(s, &s->mb_kz_obs, TN); rc |= palloc(s, &s->mb_kz_priv, TN);
+    if (rc) return -3;
+    std::vector<int> oo(TN + N), op(TN + N);
+    for (int t = 0; t <= T; ++t)
+      for (int e = 0; e < N; ++e) { oo[(size_t)t * N + e] = (int)(((size_t)e * s->Po + t) * s->fo); op[(size_t)t * N + e] = (int)(((size_t)e * s->Pp + t) * s->fp); }
+    HX_CHECK(hipMemcpyAsync(s->off_obs, oo.data(), oo.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    HX_CHECK(hipMemcpyAsync(s->off_priv, op.data(), op.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    HX_CHECK(hipStreamSynchronize(s->stream));
+  } else {
+    rc |= palloc(s, &s->s_obs, TN * cfg->obs_ld);
+    rc |= palloc(s, &s->s_priv, TN * cfg->priv_ld);
+  }
   rc |= palloc(s, &s->s_actions, TN * A); rc |= palloc(s, &s->s_mu, TN * A);
   rc |= palloc(s, &s->s_values, TN); rc |= palloc(s, &s->s_logp, TN); rc |= palloc(s, &s->s_rewards, TN);
   rc |= palloc(s, &s->s_returns, TN); rc |= palloc(s, &s->s_adv_raw, TN); rc |= palloc(s, &s->s_adv, TN);
@@ -1376,8 +1444,13 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   // minibatch i holds the same rows in each epoch: with more than one epoch the gathered rows are kept per minibatch
   // (a permuted copy of the rollout, 1.6 GB at 4096 envs) and gathered once per update instead of once per epoch.
   s->mb_slots = (cfg->num_learning_epochs > 1 && cfg->num_mini_batches <= 64 && mbs >= N) ? cfg->num_mini_batches : 1;
-  rc |= palloc(s, &s->obs_mb_all, (size_t)s->mb_slots * Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, (size_t)s->mb_slots * Mm * cfg->priv_ld);
-  rc |= palloc(s, &s->row_mb_all, (size_t)s->mb_slots * Mm * (2 * A + 4));
+  if (s->frames) {        // no gathered copies of the rows: tables in permutation order instead (hx_mb_tables_kernel)
+    s->obs_mb_all = nullptr; s->priv_mb_all = nullptr;
+    rc |= palloc(s, &s->row_mb_all, TN * (2 * A + 4));
+  } else {
+    rc |= palloc(s, &s->obs_mb_all, (size_t)s->mb_slots * Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, (size_t)s->mb_slots * Mm * cfg->priv_ld);
+    rc |= palloc(s, &s->row_mb_all, (size_t)s->mb_slots * Mm * (2 * A + 4));
+  }
   s->obs_mb = s->obs_mb_all; s->priv_mb = s->priv_mb_all; s->row_mb = s->row_mb_all;
   for (int l = 0; l < 3; ++l) {
     rc |= palloc(s, &s->act_a[l], Mm * cfg->actor_hidden[l]); rc |= palloc(s, &s->dz_a[l], Mm * cfg->actor_hidden[l]);
@@ -1550,6 +1623,7 @@ extern "C" int hx_ppo_set_params_h(hx_ppo* s, const float* flat) {
 
 extern "C" int hx_ppo_set_compute_dtype(hx_ppo* s, int dtype) {
   if (dtype != 0 && dtype != 1) { hx_set_error("hx_ppo_set_compute_dtype: 0 = f32, 1 = bf16 forward/dgrad"); return -2; }
+  if (dtype == 1 && s->frames) { hx_set_error("hx_ppo_set_compute_dtype: the bf16 kernels read ready-made rows; create the learner without frame storage for dtype 1"); return -2; }
   if (dtype == 1 && s->wT[1] == nullptr) {
     for (int net = 0; net < 2; ++net)
       for (int l = 1; l <= 2; ++l) {
@@ -1576,11 +1650,12 @@ extern "C" int hx_ppo_get_opt_state_h(hx_ppo* s, float* m, float* v, int64_t* st
 }
 
 // hidden layers of one network: X[M][ld] -> act[0..2]
-static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr, bool fp32_only = false) {
+static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr, bool fp32_only = false,
+                           const RowTable* rt = nullptr) {
   const Layer* L = s->L + net * 4;
   const bool bg = (st != nullptr && st == s->stream2);
   if (!st) st = s->stream;
-  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld, bg, fp32_only);
+  gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld, bg, fp32_only, rt);
   gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld, bg, fp32_only);
   gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld, bg, fp32_only);
 }
@@ -1594,8 +1669,13 @@ static int critic_flush(hx_ppo* s, int upto) {
     if (slots > max_slots) slots = max_slots;
     const int rows = slots * N;
     HX_CHECK(hipStreamWaitEvent(s->stream2, s->ev_priv, 0));   // the newest slot's rows have been copied
-    const float* sp = s->s_priv + (size_t)s->crit_done * N * s->cfg.priv_ld;
-    mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, rows, s->act_c, s->stream2);
+    if (s->frames) {
+      const RowTable rt{s->off_priv + (size_t)s->crit_done * N, s->kz_priv + (size_t)s->crit_done * N, s->cfg.num_priv};
+      mlp_hidden_fwd(s, 1, s->s_priv, 0, rows, s->act_c, s->stream2, false, &rt);
+    } else {
+      const float* sp = s->s_priv + (size_t)s->crit_done * N * s->cfg.priv_ld;
+      mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, rows, s->act_c, s->stream2);
+    }
     hipLaunchKernelGGL(hx_value_head_kernel, dim3((rows + 15) / 16), dim3(256), 0, s->stream2, s->act_c[2], s->cfg.critic_hidden[2],
                        s->params + s->L[7].w, s->params + s->L[7].b, rows, s->s_values + (size_t)s->crit_done * N);
     HX_CHECK(hipGetLastError());
@@ -1609,15 +1689,15 @@ static int critic_flush(hx_ppo* s, int upto) {
 // with `dual` the critic chain is forked onto the learner's second stream (whole-batch call), otherwise both
 // chains run back to back on `st` and the overlap comes from the other shard's stream.
 static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float* eps, int env0, int count, hipStream_t st,
-                    bool dual, float** actions_out, const hx_pending_step* pending = nullptr) {
+                    bool dual, float** actions_out) {
   const int N = s->cfg.num_envs, A = s->cfg.num_actions, t = s->step;
+  if (s->frames) { hx_set_error("hx_ppo_act: this learner keeps single-frame observation storage and is driven by hx_rollout; ready-made rows cannot be stored"); return -2; }
   if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }   // rollout_storage.py:88-89
   if (env0 < 0 || count <= 0 || env0 + count > N) { hx_set_error("hx_ppo_act: env range out of bounds"); return -2; }
   float* so = s->s_obs + ((size_t)t * N + env0) * s->cfg.obs_ld;
   float* sp = s->s_priv + ((size_t)t * N + env0) * s->cfg.priv_ld;
   // rows already in place when the env step wrote them straight into the storage (hx_sim_step_ex)
-  if (pending && (pending->obs.dst != so || !dual || env0 != 0 || count != N)) { hx_set_error("hx_ppo_act_pending: the pending rows are not this slot's"); return -2; }
-  if (obs != so && !pending) HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (obs != so) HX_CHECK(hipMemcpyAsync(so, obs, (size_t)count * s->cfg.obs_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (priv != sp) HX_CHECK(hipMemcpyAsync(sp, priv, (size_t)count * s->cfg.priv_ld * sizeof(float), hipMemcpyDeviceToDevice, st));
   float* aa[3]; float* ac[3];
   for (int l = 0; l < 3; ++l) { aa[l] = s->act_a[l] + (size_t)env0 * s->cfg.actor_hidden[l]; ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l]; }
@@ -1631,15 +1711,12 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
     // step, whose waves need a whole SIMD's registers each, is what a resident GEMM wave hurts.
     // slot t's privileged rows are in the storage; the event is only looked at by a flush (an event record costs the
     // stream ~6 us, so not every step)
-    // with deferred stacking the privileged rows of slot t are assembled during env step t: a flush before it covers t - 1
-    const int flush_upto = pending ? t : t + 1;
+    const int flush_upto = t + 1;
     const bool flush_now = flush_upto - s->crit_done >= s->critic_chunk;
     if (flush_now && !s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));
     const Layer* La = s->L;
     const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && s->cfg.obs_ld == La[0].in_ld;
-    if (pending && !fused_ok) { hx_set_error("hx_ppo_act_pending: needs the fused rollout actor (hidden widths 512 / 256 / 128)"); return -2; }
     if (fused_ok) {
-      hx_pending_step pend{}; if (pending) pend = *pending;
       if (s->apack_dirty) {
         for (int l = 0; l < 3; ++l) {
           if (!s->apack[l]) { const int rc = palloc(s, &s->apack[l], (size_t)(La[l].out / 16) * ((La[l].in_ld + 15) / 16) * 256); if (rc) return rc; }
@@ -1651,7 +1728,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
 #define HX_FA_ARGS so, s->cfg.obs_ld, count, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                        \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts,        \
-                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, pend
+                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, FrameSrc{nullptr, nullptr, nullptr, 0}, hx_step_book{}, 0
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
       // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
       const dim3 fgrid((count + FA_ROWS - 1) / FA_ROWS);
@@ -1692,12 +1769,62 @@ extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const 
   s->act_counter++;
   return rc;
 }
-// PPO.act on rows that a deferred env step (hx_sim_step_deferred) left for the consumer to assemble
-extern "C" int hx_ppo_act_pending(hx_ppo* s, const hx_pending_step* pending, const float* priv, float** actions_out) {
-  if (!s || !pending || !pending->valid) { hx_set_error("hx_ppo_act_pending: nothing pending"); return -2; }
-  const int rc = act_impl(s, pending->obs.dst, priv, nullptr, 0, s->cfg.num_envs, s->stream, true, actions_out, pending);
-  s->act_counter++;
-  return rc;
+// the bookkeeping of the env step that produced the current rows, for rollout actors that do not do it themselves
+__global__ void __launch_bounds__(256) hx_ppo_book_kernel(hx_step_book b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < b.n) hx_step_book_row(b, e);
+  if (e == 0) hx_step_book_global(b);
+}
+
+// PPO.act for rollout slot s->step of a learner with single-frame storage: the rows of the slot are windows of the frame
+// rings (written there by hx_sim_export_stack / hx_sim_step_frames).  `book`: bookkeeping of the env step that completed
+// them, still owed (include/hx_sim.h hx_sim_take_book); nullable.
+static int act_frames(hx_ppo* s, const hx_step_book* book, float** actions_out) {
+  const int N = s->cfg.num_envs, A = s->cfg.num_actions, t = s->step;
+  hipStream_t st = s->stream;
+  if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }   // rollout_storage.py:88-89
+  if (t == 0) HX_CHECK(hipMemcpyAsync(s->sigma_old, s->params + s->std_off, A * sizeof(float), hipMemcpyDeviceToDevice, st));
+  float* acts = s->s_actions + (size_t)t * N * A;
+  const int flush_upto = t + 1;
+  const bool flush_now = flush_upto - s->crit_done >= s->critic_chunk;
+  if (flush_now && !s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));
+  const Layer* La = s->L;
+  const bool fused_ok = La[0].out == 512 && La[1].out == 256 && La[2].out == 128;
+  const FrameSrc fsrc{s->s_obs, s->off_obs + (size_t)t * N, s->kz_obs + (size_t)t * N, s->cfg.num_obs};
+  if (fused_ok) {
+    if (s->apack_dirty) {
+      for (int l = 0; l < 3; ++l) {
+        if (!s->apack[l]) { const int rc = palloc(s, &s->apack[l], (size_t)(La[l].out / 16) * ((La[l].in_ld + 15) / 16) * 256); if (rc) return rc; }
+        hipLaunchKernelGGL(hx_actor_pack_kernel, dim3(256), dim3(256), 0, st, s->params + La[l].w, La[l].out, La[l].in_ld, La[l].in_ld, s->apack[l]);
+      }
+      s->apack_dirty = false;
+    }
+    const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
+    hx_step_book bk{}; if (book) bk = *book;
+#define HX_FA_ARGS (const float*)nullptr, 0, N, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                       \
+                   s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
+                   s->params + La[3].b, s->params + s->std_off, (const float*)nullptr, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts, \
+                   s->s_mu + (size_t)t * N * A, s->s_logp + (size_t)t * N, fsrc, bk, book ? 1 : 0
+    const dim3 fgrid((N + FA_ROWS - 1) / FA_ROWS);
+    if (s->actor_waves == 8) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+    else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
+#undef HX_FA_ARGS
+  } else {
+    if (book) hipLaunchKernelGGL(hx_ppo_book_kernel, dim3((N + 255) / 256), dim3(256), 0, st, *book);
+    const RowTable rt{fsrc.off, fsrc.kz, fsrc.klim};
+    mlp_hidden_fwd(s, 0, s->s_obs, 0, N, s->act_a, st, false, &rt);
+    const int hw = s->cfg.actor_hidden[2];
+    hipLaunchKernelGGL(hx_actor_head_kernel, dim3((N + 15) / 16), dim3(256), A * hw * sizeof(float), st, s->act_a[2], hw,
+                       s->params + s->L[3].w, s->params + s->L[3].b, s->params + s->std_off, (const float*)nullptr, N, A, s->seed_lo, s->seed_hi,
+                       s->act_counter, s->row_base, acts, s->s_mu + (size_t)t * N * A, s->s_logp + (size_t)t * N);
+  }
+  if (flush_now) {
+    if (s->critic_late) HX_CHECK(hipEventRecord(s->ev_priv, st));
+    const int rc = critic_flush(s, flush_upto); if (rc) return rc;
+  }
+  HX_CHECK(hipGetLastError());
+  if (actions_out) *actions_out = acts;
+  return 0;
 }
 extern "C" int hx_ppo_act_range(hx_ppo* s, const float* obs, const float* priv, const float* eps, int env0, int count, void* stream,
                                 float** actions_out) {
@@ -1706,6 +1833,7 @@ extern "C" int hx_ppo_act_range(hx_ppo* s, const float* obs, const float* priv, 
 
 static int process_impl(hx_ppo* s, const float* rew, const uint8_t* dones, const uint8_t* timeouts, int env0, int count, hipStream_t st) {
   const int N = s->cfg.num_envs, t = s->step;
+  if (s->frames) { hx_set_error("hx_ppo_process_step: this learner keeps single-frame observation storage and is driven by hx_rollout"); return -2; }
   if (t >= s->cfg.num_steps) { hx_set_error("Rollout buffer overflow"); return -10; }
   hipLaunchKernelGGL(hx_process_step_kernel, dim3((count + 255) / 256), dim3(256), 0, st, rew, dones, timeouts, count,
                      s->s_rewards + (size_t)t * N + env0, s->s_dones + (size_t)t * N + env0, s->s_timeouts + (size_t)t * N + env0);
@@ -1763,6 +1891,16 @@ extern "C" int hx_ppo_update_begin(hx_ppo* s, const int32_t* perm) {
   const int TN = s->cfg.num_steps * s->cfg.num_envs;
   if (perm) HX_CHECK(hipMemcpyAsync(s->perm, perm, (size_t)TN * sizeof(int), hipMemcpyDeviceToDevice, s->stream));
   else hipLaunchKernelGGL(hx_perm_kernel, dim3((TN + 255) / 256), dim3(256), 0, s->stream, s->perm, TN, s->perm_key + 0x9E3779B9u * (s->perm_counter++));
+  if (s->frames) {
+    MbTableArgs g{};
+    g.perm = s->perm; g.TN = TN;
+    g.off_obs = s->off_obs; g.off_priv = s->off_priv; g.kz_obs = s->kz_obs; g.kz_priv = s->kz_priv;
+    g.mb_off_obs = s->mb_off_obs; g.mb_off_priv = s->mb_off_priv; g.mb_kz_obs = s->mb_kz_obs; g.mb_kz_priv = s->mb_kz_priv;
+    g.actions = s->s_actions; g.mu = s->s_mu; g.values = s->s_values; g.returns = s->s_returns; g.logp = s->s_logp; g.adv = s->s_adv;
+    g.A = s->cfg.num_actions; g.row_mb = s->row_mb_all;
+    hipLaunchKernelGGL(hx_mb_tables_kernel, dim3((TN + 255) / 256), dim3(256), 0, s->stream, g);
+    HX_CHECK(hipGetLastError());
+  }
   SchedState z{};
   // keep lr, clear the loss accumulators
   HX_CHECK(hipMemsetAsync(&s->sched->vloss_sum, 0, 2 * sizeof(float), s->stream));
@@ -1781,10 +1919,19 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   const int mb = mb_index % c.num_mini_batches;       // the permutation is reused by every epoch (rollout_storage.py:149,165)
   hipStream_t st = s->stream;
   const int slot = (s->mb_slots > 1) ? mb : 0;
-  s->obs_mb = s->obs_mb_all + (size_t)slot * s->Mmax * c.obs_ld;
-  s->priv_mb = s->priv_mb_all + (size_t)slot * s->Mmax * c.priv_ld;
-  s->row_mb = s->row_mb_all + (size_t)slot * s->Mmax * (2 * A + 4);
-  if (s->mb_slots == 1 || !((s->mb_gathered >> mb) & 1ull)) {
+  RowTable rt_obs{}, rt_priv{};
+  if (s->frames) {
+    // rows are read in place through the permutation-ordered tables of hx_ppo_update_begin: nothing to gather
+    s->obs_mb = s->s_obs; s->priv_mb = s->s_priv;
+    s->row_mb = s->row_mb_all + (size_t)mb * M * (2 * A + 4);
+    rt_obs = RowTable{s->mb_off_obs + (size_t)mb * M, s->mb_kz_obs + (size_t)mb * M, c.num_obs};
+    rt_priv = RowTable{s->mb_off_priv + (size_t)mb * M, s->mb_kz_priv + (size_t)mb * M, c.num_priv};
+  } else {
+    s->obs_mb = s->obs_mb_all + (size_t)slot * s->Mmax * c.obs_ld;
+    s->priv_mb = s->priv_mb_all + (size_t)slot * s->Mmax * c.priv_ld;
+    s->row_mb = s->row_mb_all + (size_t)slot * s->Mmax * (2 * A + 4);
+  }
+  if (!s->frames && (s->mb_slots == 1 || !((s->mb_gathered >> mb) & 1ull))) {
     GatherArgs ga{};
     ga.idx = s->perm + (size_t)mb * M; ga.M = M;
     ga.obs = s->s_obs; ga.obs_ld = c.obs_ld; ga.obs_mb = s->obs_mb;
@@ -1799,8 +1946,8 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   // previous one's tail; the critic joins before the loss head and forks again for the backward pass.
   hipStream_t sb = s->stream_b ? s->stream_b : st;
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
-  mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a, st);
-  mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c, sb);
+  mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a, st, false, s->frames ? &rt_obs : nullptr);
+  mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c, sb, false, s->frames ? &rt_priv : nullptr);
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   // heads: losses + gradient into the third hidden layer
   const int hw = c.actor_hidden[2], hwc = c.critic_hidden[2];
@@ -1835,7 +1982,8 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       float* slab = s->slab + s->slab_off[net * 4 + l];
       float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
       int bparts = 0;
-      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
+      const RowTable* rows = (s->frames && l == 0) ? (net ? &rt_priv : &rt_obs) : nullptr;
+      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l], rows);
       const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
       int k = rt.nseg;
       rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
@@ -1911,12 +2059,28 @@ extern "C" int hx_ppo_buffer(hx_ppo* s, int which, void** d) {
     case HX_PPO_BUF_ADVANTAGES: *d = s->s_adv; break;
     case HX_PPO_BUF_GRADS: *d = s->grads; break;
     case HX_PPO_BUF_PERM: *d = s->perm; break;
-    case HX_PPO_BUF_OBS: *d = s->s_obs; break;
-    case HX_PPO_BUF_PRIV: *d = s->s_priv; break;
+    case HX_PPO_BUF_OBS: case HX_PPO_BUF_PRIV:
+      if (s->frames) { hx_set_error("hx_ppo_buffer: with single-frame storage the observation rows do not exist in memory: hx_ppo_storage_rows expands them"); return -2; }
+      *d = (which == HX_PPO_BUF_OBS) ? s->s_obs : s->s_priv; break;
     case HX_PPO_BUF_DONES: *d = s->s_dones; break;
     case HX_PPO_BUF_TIMEOUTS: *d = s->s_timeouts; break;
     default: hx_set_error("hx_ppo_buffer: unknown id"); return -2;
   }
+  return 0;
+}
+extern "C" int hx_ppo_storage_rows(hx_ppo* s, int which, int t0, int t1, float* dst) {
+  if (!s || !dst || (which != HX_PPO_BUF_OBS && which != HX_PPO_BUF_PRIV)) { hx_set_error("hx_ppo_storage_rows: bad argument"); return -2; }
+  const int N = s->cfg.num_envs, T = s->cfg.num_steps;
+  const bool ob = which == HX_PPO_BUF_OBS;
+  const int ld = ob ? s->cfg.obs_ld : s->cfg.priv_ld;
+  if (t0 < 0 || t1 <= t0 || t1 > T + (s->frames ? 1 : 0)) { hx_set_error("hx_ppo_storage_rows: slot range out of bounds"); return -2; }
+  if (!s->frames) {
+    HX_CHECK(hipMemcpyAsync(dst, (ob ? s->s_obs : s->s_priv) + (size_t)t0 * N * ld, (size_t)(t1 - t0) * N * ld * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    return 0;
+  }
+  hipLaunchKernelGGL(hx_expand_rows_kernel, dim3((unsigned)((t1 - t0) * N)), dim3(256), 0, s->stream, ob ? s->s_obs : s->s_priv,
+                     (ob ? s->off_obs : s->off_priv) + (size_t)t0 * N, (ob ? s->kz_obs : s->kz_priv) + (size_t)t0 * N, ob ? s->cfg.num_obs : s->cfg.num_priv, ld, dst);
+  HX_CHECK(hipGetLastError());
   return 0;
 }
 extern "C" int hx_ppo_get_lr(hx_ppo* s, float* lr) {
@@ -1993,11 +2157,55 @@ extern "C" int hx_ppo_prof_end(hx_ppo* s, hx_prof_row* rows, int max_rows, int* 
 // that launch issue (~40 launches per step with two shards) never waits for the Python interpreter.
 // One shard: whole-batch calls (critic chain forked on the learner's second stream).  Several shards: every
 // shard advances on its own stream; one shard's env-step kernel overlaps the other shards' GEMMs.
+// frame-mode rollout: 2 launches per step -- the actor reads its rows as windows of the frame rings (and does the previous
+// step's bookkeeping), the env step writes the new frames, their rows' first-valid-element entries and nothing else.
+static int rollout_frames(hx_ppo* p, hx_sim* sim, int steps) {
+  const int N = p->cfg.num_envs, T = p->cfg.num_steps;
+  if (hx_sim_stream(sim) != (void*)p->stream) { hx_set_error("hx_rollout: simulator and learner must share one stream"); return -2; }
+  const int slot0 = p->step;
+  auto slot_of = [&](int frame_obs, int frame_priv, int row) {
+    hx_frame_slot f{};
+    f.obs = p->s_obs + (size_t)frame_obs * p->fo; f.obs_env_stride = (int64_t)p->Po * p->fo;
+    f.priv = p->s_priv + (size_t)frame_priv * p->fp; f.priv_env_stride = (int64_t)p->Pp * p->fp;
+    f.obs_kz = p->kz_obs + (size_t)row * N; f.priv_kz = p->kz_priv + (size_t)row * N;
+    return f;
+  };
+  if (slot0 == 0) {
+    // the simulator's current stack becomes frames 0 .. stack-1 of every ring (row 0)
+    const hx_frame_slot f0 = slot_of(0, 0, 0);
+    const int rc = hx_sim_export_stack(sim, &f0); if (rc) return rc;
+  } else if (p->frames_sim_step != hx_sim_step_counter(sim)) {
+    hx_set_error("hx_rollout: the simulator stepped outside this learner's rollout since slot 0 (frame rings are stale)"); return -2;
+  }
+  for (int t = 0; t < steps; ++t) {
+    const int slot = p->step;
+    if (slot >= T) { hx_set_error("Rollout buffer overflow"); return -10; }
+    hx_step_book book{}; int32_t owed = 0;
+    int rc = hx_sim_take_book(sim, &book, &owed); if (rc) return rc;
+    float* act = nullptr;
+    rc = act_frames(p, owed ? &book : nullptr, &act); if (rc) return rc;
+    p->act_counter++;
+    // row slot+1 = the windows ending at the frame this step produces: frame index slot + stack of either stream
+    const hx_frame_slot f = slot_of(slot + p->So, slot + p->Sp, slot + 1);
+    rc = hx_sim_step_frames(sim, act, nullptr, &f, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N, p->s_timeouts + (size_t)slot * N);
+    if (rc) return rc;
+    p->step += 1;
+  }
+  // the last step's bookkeeping, and the simulator's own row buffers back in step with the rings (HX_BUF_OBS / HX_BUF_PRIV are
+  // what the caller bootstraps from and what a row-API step would shift)
+  int rc = hx_sim_flush_book(sim); if (rc) return rc;
+  const hx_frame_slot fl = slot_of(p->step, p->step, p->step);
+  rc = hx_sim_import_stack(sim, &fl); if (rc) return rc;
+  p->frames_sim_step = hx_sim_step_counter(sim);
+  return 0;
+}
+
 extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps) {
   const int N = p->cfg.num_envs, T = p->cfg.num_steps;
-  hx_pending_step pend{};
-  const Layer* La = p->L;
-  const bool defer_ok = nshards == 1 && La[0].out == 512 && La[1].out == 256 && La[2].out == 128 && p->cfg.obs_ld == La[0].in_ld && getenv("HX_DEFER_STACK") && atoi(getenv("HX_DEFER_STACK")) == 1;
+  if (p->frames) {
+    if (nshards != 1 || count[0] != N) { hx_set_error("hx_rollout: single-frame storage takes one simulator with all of the learner's robots"); return -2; }
+    return rollout_frames(p, sims[0], steps);
+  }
   for (int t = 0; t < steps; ++t) {
     for (int h = 0; h < nshards; ++h) {
       void *obs, *priv, *rew, *rst, *tov;
@@ -2009,21 +2217,11 @@ extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const i
         // the rollout storage (slot t+1 rows / slot t scalars); 3 launches per step: actor, env step, stack
         const int slot = p->step;
         if (slot >= T) { hx_set_error("Rollout buffer overflow"); return -10; }
-        if (pend.valid) { rc = hx_ppo_act_pending(p, &pend, (const float*)priv, &act); if (rc) return rc; hx_sim_pending_consumed(sims[h]); pend.valid = 0; }
-        else { rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act); if (rc) return rc; }
+        rc = hx_ppo_act(p, (const float*)obs, (const float*)priv, nullptr, &act); if (rc) return rc;
         float* od = nullptr; float* pd = nullptr;
         if (slot + 1 < T) { od = p->s_obs + (size_t)(slot + 1) * N * p->cfg.obs_ld; pd = p->s_priv + (size_t)(slot + 1) * N * p->cfg.priv_ld; }
-        // HX_DEFER_STACK=1: every step but the last one defers its frame stacking -- the observation rows are assembled by
-        // the next actor launch, the privileged rows by spare workgroups of the next env-step launch (2 launches per step
-        // instead of 3).  Same storage contents bit for bit (tests/test_gpu_runner.py).  Off by default: 16 us per step
-        // faster undisturbed, but beside the deferred critic the longer actor prologue gives the gain back
-        // (profiles/r02_f_deferred_stacking.txt: 49.6 ms per iteration either way).
-        if (defer_ok && od != nullptr && t + 1 < steps)
-          rc = hx_sim_step_deferred(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
-                                    p->s_timeouts + (size_t)slot * N, &pend);
-        else
-          rc = hx_sim_step_ex(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
-                              p->s_timeouts + (size_t)slot * N);
+        rc = hx_sim_step_ex(sims[h], act, nullptr, od, pd, p->s_rewards + (size_t)slot * N, p->s_dones + (size_t)slot * N,
+                            p->s_timeouts + (size_t)slot * N);
         if (rc) return rc;
         p->step += 1;
       } else {

@@ -37,25 +37,6 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
   constexpr int NL = D::NL, ND = D::ND;
   constexpr SLay SL(ND);
   // dynamic LDS: staged constants | HX_RPW height windows | pooled bounds | cliff flags | window origins | per-lane contact buffer
-  if ((int)blockIdx.x >= A.env_blocks && A.stack_blocks > 0) {
-    // Spare workgroups of this launch: the privileged rows of the PREVIOUS step (deferred frame stacking).  They run on
-    // SIMDs the env-step waves leave idle (512 waves for 1024 SIMDs at 4096 robots) and read the previous step's frame /
-    // reset buffers, which this step's robots do not touch (ping-pong pairs).  The whole workgroup leaves before any barrier.
-    const hx_row_stack& ps = A.pstack;
-    for (int row = ((int)blockIdx.x - A.env_blocks) * HX_ENV_WPB + (int)(threadIdx.x >> 6); row < ps.n; row += A.stack_blocks * HX_ENV_WPB) {
-      const bool rst = ps.reset[row] != 0;
-      float* d = ps.dst + (size_t)row * ps.ld;
-      // a whole row in flight per pass where it fits (one wave has the SIMD's register file to itself)
-      for (int k0 = threadIdx.x & 63; k0 < ps.ld; k0 += 64 * 24) {
-        float v[24];
-#pragma unroll
-        for (int u = 0; u < 24; ++u) v[u] = *hx_row_stack_addr(ps, row, min(k0 + 64 * u, ps.ld - 1));
-#pragma unroll
-        for (int u = 0; u < 24; ++u) { const int k = k0 + 64 * u; if (k < ps.ld) d[k] = hx_row_stack_finish(ps, rst, k, v[u]); }
-      }
-    }
-    return;
-  }
 #if HX_ENV_WPB > 1
   extern __shared__ float lds_all0[];
   const int tidx = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -306,11 +287,9 @@ struct hx_sim {
   int cur;
   float *obs_cur, *priv_cur;      // where the current observation rows live (own buffer or the learner's storage)
   int* num_reset2[2]; int parity;
-  // deferred frame stacking (hx_sim_step_deferred): frame / reset buffers in ping-pong pairs so that the next launch can
-  // still read the previous step's; what is still owed from the previous step
-  unsigned char* reset2[2]; float* priv_frame2[2]; int fpar;
-  hx_row_stack pend_priv; bool pend_priv_valid; hx_pending_step pend; bool pend_obs_valid;
-  int stack_blocks;
+  // frame-mode steps (hx_sim_step_frames): the bookkeeping of the last step, owed until its rows' next reader takes it
+  hx_step_book book; bool book_owed;
+  bool rows_stale = false;       // frame-mode steps have run since the row buffers were last written
   unsigned char* timeout_visible;
   long long step_counter;
   uint32_t rng_step;
@@ -377,12 +356,10 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   rc |= dalloc(s, &s->p.contact, (size_t)(1 + s->nd) * 3 * n);
   rc |= dalloc(s, &s->p.bodies, 52 * n);
   rc |= dalloc(s, &s->p.obs_frame, (size_t)s->obs_f * n);
-  rc |= dalloc(s, &s->priv_frame2[0], (size_t)s->priv_f * n); rc |= dalloc(s, &s->priv_frame2[1], (size_t)s->priv_f * n);
+  rc |= dalloc(s, &s->p.priv_frame, (size_t)s->priv_f * n);
   rc |= dalloc(s, &s->p.rew, n);
-  rc |= dalloc(s, &s->reset2[0], n); rc |= dalloc(s, &s->reset2[1], n);
-  s->fpar = 0; s->p.priv_frame = s->priv_frame2[0]; s->p.reset = s->reset2[0];
-  s->pend_priv_valid = false; s->pend_obs_valid = false; s->pend.valid = 0;
-  { const char* e = getenv("HX_STACK_BLOCKS"); s->stack_blocks = (e && atoi(e) > 0) ? atoi(e) : 256; }
+  rc |= dalloc(s, &s->p.reset, n); rc |= dalloc(s, &s->p.age, n);
+  s->book_owed = false;
   rc |= dalloc(s, &s->p.timeout, n);
   rc |= dalloc(s, &s->num_reset2[0], 1); rc |= dalloc(s, &s->num_reset2[1], 1);
   s->p.num_reset = s->num_reset2[0]; s->parity = 0;
@@ -490,36 +467,60 @@ extern "C" void hx_sim_destroy(hx_sim* s) {
 
 struct StepOut { float* obs; float* priv; float* rew; unsigned char* done; unsigned char* timeout; };
 
-// obs rows + bookkeeping of a deferred step that nobody consumed (hx_sim_step_deferred followed by a plain step)
-__global__ void __launch_bounds__(256) hx_flush_pending_kernel(hx_pending_step pd) {
-  const int e = blockIdx.x;
-  const bool rst = pd.obs.reset[e] != 0;
-  for (int k = threadIdx.x; k < pd.obs.ld; k += blockDim.x) pd.obs.dst[(size_t)e * pd.obs.ld + k] = hx_row_stack_value(pd.obs, e, rst, k);
-  if (threadIdx.x == 0) { hx_step_book_row(pd.book, e); if (e == 0) hx_step_book_global(pd.book); }
+// the bookkeeping of a frame-mode step that nobody took (hx_sim_take_book): one thread per robot
+__global__ void __launch_bounds__(256) hx_book_kernel(hx_step_book b) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < b.n) hx_step_book_row(b, e);
+  if (e == 0) hx_step_book_global(b);
+}
+static int flush_book(hx_sim* s) {
+  if (!s->book_owed) return 0;
+  hipLaunchKernelGGL(hx_book_kernel, dim3((s->cfg.num_envs + 255) / 256), dim3(256), 0, s->stream, s->book);
+  s->book_owed = false;
+  HX_CHECK(hipGetLastError());
+  return 0;
 }
 
-static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode, const StepOut* out, hx_pending_step* defer = nullptr) {
-  const int n = s->cfg.num_envs;
-  if (s->pend_obs_valid) {          // a deferred step whose observation rows were never consumed: assemble them now
-    hipLaunchKernelGGL(hx_flush_pending_kernel, dim3(n), dim3(256), 0, s->stream, s->pend);
-    s->pend_obs_valid = false; s->pend.valid = 0;
+// frames <-> rows (include/hx_sim.h): one workgroup per robot, coalesced along the row.
+//   TO_FRAMES: frame p of the consumer's ring <- elements [p * f, (p + 1) * f) of the simulator's current row; kz from the age
+//   else     : the simulator's row <- the window of `stack` frames starting at the slot, elements below kz read as zero
+struct StackIoArgs { hx_frame_slot fs; float* obs_rows; float* priv_rows; const unsigned char* age; int n, obs_f, obs_ld, obs_stack, priv_f, priv_ld, priv_stack; };
+template <bool TO_FRAMES> __global__ void __launch_bounds__(256) hx_stack_io_kernel(StackIoArgs a) {
+  const int e = blockIdx.x;
+  float* fo = a.fs.obs + (size_t)e * a.fs.obs_env_stride;
+  float* fp = a.fs.priv + (size_t)e * a.fs.priv_env_stride;
+  float* ro = a.obs_rows + (size_t)e * a.obs_ld;
+  float* rp = a.priv_rows + (size_t)e * a.priv_ld;
+  const int wo = a.obs_stack * a.obs_f, wp = a.priv_stack * a.priv_f;
+  if (TO_FRAMES) {
+    for (int k = threadIdx.x; k < wo; k += blockDim.x) fo[k] = ro[k];
+    for (int k = threadIdx.x; k < wp; k += blockDim.x) fp[k] = rp[k];
+    if (threadIdx.x == 0) {
+      const int age = a.age[e];
+      a.fs.obs_kz[e] = (a.obs_stack - min(age, a.obs_stack)) * a.obs_f;
+      a.fs.priv_kz[e] = (a.priv_stack - min(age, a.priv_stack)) * a.priv_f;
+    }
+  } else {
+    const int zo = a.fs.obs_kz[e], zp = a.fs.priv_kz[e];
+    for (int k = threadIdx.x; k < a.obs_ld; k += blockDim.x) ro[k] = (k >= zo && k < wo) ? fo[k] : 0.f;
+    for (int k = threadIdx.x; k < a.priv_ld; k += blockDim.x) rp[k] = (k >= zp && k < wp) ? fp[k] : 0.f;
   }
-  StepArgs A;
+}
+
+static int launch_step(hx_sim* s, const float* actions, const float* pack, int mode, const StepOut* out, const hx_frame_slot* frames = nullptr) {
+  const int n = s->cfg.num_envs;
+  { const int rc = flush_book(s); if (rc) return rc; }      // a frame-mode step whose bookkeeping nobody took
+  StepArgs A{};
   const int env_blocks = ((n + HX_RPW - 1) / HX_RPW + HX_ENV_WPB - 1) / HX_ENV_WPB;       // workgroups of HX_ENV_WPB waves
-  A.env_blocks = env_blocks;
-  A.stack_blocks = s->pend_priv_valid ? s->stack_blocks : 0;
-  A.pstack = s->pend_priv;
-  s->pend_priv_valid = false;
-  // this step's robots write the other halves of the frame / reset pairs; the spare workgroups read the previous step's
-  s->fpar ^= 1;
-  s->p.priv_frame = s->priv_frame2[s->fpar]; s->p.reset = s->reset2[s->fpar];
+  A.frames = frames != nullptr; A.obs_stack = HX_FRAME_STACK; A.priv_stack = s->priv_stack; A.clip = s->cfg.clip_observations;
+  if (frames) A.fs = *frames;
   A.mode = mode;
   if (mode == 0) s->step_counter += 1;
   A.step_counter = s->step_counter;
   A.k0 = (uint32_t)(s->seed & 0xffffffffu);
   A.k1 = (uint32_t)(s->seed >> 32);
   A.rng_step = s->rng_step++;
-  // reset counter: ping-pong pair; the stack kernel of step t zeroes the counter step t+1 will use
+  // reset counter: ping-pong pair; the bookkeeping of step t zeroes the counter step t+1 will use
   s->p.num_reset = s->num_reset2[s->parity];
   bool timed = s->timing && mode == 0;
   if (timed) {
@@ -527,10 +528,21 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
     timed = s->ev_used + 2 <= s->ev.size();
   }
   if (timed) (void)hipEventRecord(s->ev[s->ev_used], s->stream);
-  if (s->nd == HX_XBOT_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelXBot>, dim3(env_blocks + A.stack_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelXBot>(), s->stream, s->p, s->cfg_d, actions, pack, A);
-  else if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3(env_blocks + A.stack_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
-  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3(env_blocks + A.stack_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  if (s->nd == HX_XBOT_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelXBot>, dim3(env_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelXBot>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else if (s->nd == HX_NUM_DOF) hipLaunchKernelGGL(hx_env_step_kernel<ModelHector>, dim3(env_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelHector>(), s->stream, s->p, s->cfg_d, actions, pack, A);
+  else hipLaunchKernelGGL(hx_env_step_kernel<ModelFull>, dim3(env_blocks), dim3(64 * HX_ENV_WPB), HX_ENV_WPB * env_step_lds_bytes<ModelFull>(), s->stream, s->p, s->cfg_d, actions, pack, A);
   if (timed) { (void)hipEventRecord(s->ev[s->ev_used + 1], s->stream); s->ev_used += 2; }
+  if (frames) {
+    // no stacking launch and no rows: the step's bookkeeping travels to the next reader of the frames
+    s->book = hx_step_book{s->p.reset, s->p.timeout, s->timeout_visible, s->num_reset2[s->parity], s->num_reset2[s->parity ^ 1], s->p.stat_sum, s->p.stat_last,
+                           s->p.stat_acc, s->p.stat_steps, s->p.rew, out ? out->rew : nullptr, out ? out->done : nullptr, out ? out->timeout : nullptr, n};
+    s->book_owed = true;
+    s->rows_stale = true;
+    s->parity ^= 1;
+    HX_CHECK(hipGetLastError());
+    return 0;
+  }
+  if (s->rows_stale) { hx_set_error("hx_sim_step: the simulator's row buffers are stale after frame-mode steps (call hx_sim_import_stack first)"); return -2; }
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
   if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }
@@ -544,21 +556,7 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
   k.n = n; k.clip = s->cfg.clip_observations;
   k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld; k.priv_stack = s->priv_stack;
-  if (defer != nullptr) {
-    // no stacking launch: the observation rows and the bookkeeping travel to the consumer, the privileged rows to the
-    // spare workgroups of the next env-step launch
-    hx_pending_step& P = s->pend;
-    P.valid = 1;
-    P.obs = hx_row_stack{k.obs_src, k.obs_dst, k.obs_frame, k.reset, n, k.obs_f, k.obs_ld, HX_FRAME_STACK, k.clip};
-    P.book = hx_step_book{k.reset, k.timeout, k.timeout_visible, k.num_reset, k.num_reset_next, k.stat_sum, k.stat_last, k.stat_acc, k.stat_steps,
-                          k.rew, k.rew_out, k.done_out, k.timeout_out, n};
-    s->pend_obs_valid = true;
-    s->pend_priv = hx_row_stack{k.priv_src, k.priv_dst, k.priv_frame, k.reset, n, k.priv_f, k.priv_ld, k.priv_stack, k.clip};
-    s->pend_priv_valid = true;
-    *defer = P;
-  } else {
-    hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
-  }
+  hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
   s->obs_cur = od; s->priv_cur = pd;
   s->parity ^= 1;
   HX_CHECK(hipGetLastError());
@@ -579,15 +577,44 @@ extern "C" int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack
   return launch_step(s, actions, pack, 0, &o);
 }
 
-extern "C" int hx_sim_step_deferred(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
-                                    float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst, hx_pending_step* pending) {
-  if (!s || !actions || !pending || !obs_dst || !priv_dst) { hx_set_error("hx_sim_step_deferred: null argument"); return -2; }
-  StepOut o{obs_dst, priv_dst, rew_dst, done_dst, timeout_dst};
-  return launch_step(s, actions, pack, 0, &o, pending);
+// ---- single-frame observation storage (include/hx_sim.h)
+extern "C" int hx_sim_step_frames(hx_sim* s, const float* actions, const float* pack, const hx_frame_slot* dst,
+                                  float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst) {
+  if (!s || !actions || !dst || !dst->obs || !dst->priv || !dst->obs_kz || !dst->priv_kz) { hx_set_error("hx_sim_step_frames: null argument"); return -2; }
+  StepOut o{nullptr, nullptr, rew_dst, done_dst, timeout_dst};
+  return launch_step(s, actions, pack, 0, &o, dst);
 }
-extern "C" int hx_sim_pending_consumed(hx_sim* s) {
-  if (!s) { hx_set_error("hx_sim_pending_consumed: null sim"); return -2; }
-  s->pend_obs_valid = false; s->pend.valid = 0;
+extern "C" int hx_sim_take_book(hx_sim* s, hx_step_book* book, int32_t* valid) {
+  if (!s || !book || !valid) { hx_set_error("hx_sim_take_book: null argument"); return -2; }
+  *valid = s->book_owed ? 1 : 0;
+  if (s->book_owed) *book = s->book;
+  s->book_owed = false;
+  return 0;
+}
+extern "C" int hx_sim_flush_book(hx_sim* s) {
+  if (!s) { hx_set_error("hx_sim_flush_book: null sim"); return -2; }
+  return flush_book(s);
+}
+static StackIoArgs stack_io_args(hx_sim* s, const hx_frame_slot* f) {
+  StackIoArgs a{};
+  a.fs = *f; a.obs_rows = s->obs_cur; a.priv_rows = s->priv_cur; a.age = s->p.age; a.n = s->cfg.num_envs;
+  a.obs_f = s->obs_f; a.obs_ld = s->obs_ld; a.obs_stack = HX_FRAME_STACK; a.priv_f = s->priv_f; a.priv_ld = s->priv_ld; a.priv_stack = s->priv_stack;
+  return a;
+}
+extern "C" int hx_sim_export_stack(hx_sim* s, const hx_frame_slot* first) {
+  if (!s || !first || !first->obs || !first->priv || !first->obs_kz || !first->priv_kz) { hx_set_error("hx_sim_export_stack: null argument"); return -2; }
+  if (s->rows_stale) { hx_set_error("hx_sim_export_stack: the simulator's rows are stale (frame-mode steps since the last hx_sim_import_stack)"); return -2; }
+  hipLaunchKernelGGL(hx_stack_io_kernel<true>, dim3(s->cfg.num_envs), dim3(256), 0, s->stream, stack_io_args(s, first));
+  HX_CHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int hx_sim_import_stack(hx_sim* s, const hx_frame_slot* first) {
+  if (!s || !first || !first->obs || !first->priv || !first->obs_kz || !first->priv_kz) { hx_set_error("hx_sim_import_stack: null argument"); return -2; }
+  // rows land in the simulator's own buffers (not in a caller's storage a former hx_sim_step_ex pointed obs_cur at)
+  s->obs_cur = s->obs[s->cur]; s->priv_cur = s->priv[s->cur];
+  hipLaunchKernelGGL(hx_stack_io_kernel<false>, dim3(s->cfg.num_envs), dim3(256), 0, s->stream, stack_io_args(s, first));
+  s->rows_stale = false;
+  HX_CHECK(hipGetLastError());
   return 0;
 }
 
@@ -671,6 +698,7 @@ extern "C" int hx_sim_set_episode_length(hx_sim* s, const int32_t* h) {
   return 0;
 }
 extern "C" int hx_sim_set_step_counter(hx_sim* s, int64_t c) { s->step_counter = c; return 0; }
+extern "C" int64_t hx_sim_step_counter(hx_sim* s) { return s ? (int64_t)s->step_counter : -1; }
 
 extern "C" int hx_sim_episode_stats(hx_sim* s, float* mean_h, int32_t* count_h) {
   if (!s || !mean_h || !count_h) { hx_set_error("hx_sim_episode_stats: null argument"); return -2; }

@@ -116,6 +116,7 @@ class HectorFreeEnv(VecEnv):
         self.dof_names, self.body_names = DOF_NAMES, BODY_NAMES
         self.obs_frame, self.priv_frame = 11 + 3 * nd, self.PRIV_BASE + 3 * nd         # 41 / 70, with arms 65 / 94, XBot-L 47 / 73
         self.obs_ld, self.priv_ld = -(-15 * self.obs_frame // 4) * 4, -(-self.PRIV_STACK * self.priv_frame // 4) * 4
+        self.frame_dims = (self.obs_frame, self.priv_frame, 15, self.PRIV_STACK)      # what PPO.init_storage(frames=...) takes
         if (self.num_obs, self.num_privileged_obs, self.num_actions) != (15 * self.obs_frame, self.PRIV_STACK * self.priv_frame, nd):
             raise ValueError(f"{type(self).__name__} serves the {15 * self.obs_frame} / {self.PRIV_STACK * self.priv_frame} / {nd} layout only")
         self.feet_indices = [i for i, n in enumerate(BODY_NAMES) if cfg.asset.foot_name in n]

@@ -64,6 +64,7 @@ extern "C" hxh_env* hxh_create(const hx_sim_cfg* cfg, const float* friction, con
   p.priv_frame = halloc<float>(s, (size_t)s->priv_f * n);
   p.rew = halloc<float>(s, n);
   p.reset = halloc<unsigned char>(s, n);
+  p.age = halloc<unsigned char>(s, n);
   p.timeout = halloc<unsigned char>(s, n);
   p.num_reset = halloc<int>(s, 1);
   p.stat_sum = halloc<float>(s, HX_NUM_REWARDS); p.stat_last = halloc<float>(s, HX_NUM_REWARDS); p.stat_acc = halloc<float>(s, HX_NUM_REWARDS);
@@ -205,7 +206,8 @@ static void stack_frames(hxh_env* s) {
 }
 
 static void run_step(hxh_env* s, const float* actions, const float* pack, int mode) {
-  StepArgs A;
+  StepArgs A{};
+  A.frames = 0; A.obs_stack = HX_FRAME_STACK; A.priv_stack = HX_FRAME_STACK; A.clip = s->cfg.clip_observations;
   A.mode = mode;
   if (mode == 0) s->step_counter += 1;
   A.step_counter = s->step_counter;

@@ -47,12 +47,12 @@ def test_config1_64_envs_full_iteration_against_oracle(hxlib):
     ref = PPOOracle(ActorCriticOracle.default_init(np.random.default_rng(seed)), n, T, **kw)
     obs, priv = env.get_observations(), env.get_privileged_observations()
     o2, p2 = orc.obs_buf, orc.priv_buf
-    stale_fired, worst = 0, dict(act=0.0, obs=0.0, rew=0.0)
+    stale_fired, errs = 0, dict(act=[], obs=[], rew=[])
     for t in range(T):
         eps = rng.standard_normal((n, 10)).astype(np.float32)
         a_hip = alg.act(obs, priv, eps=eps).numpy().copy()
         a_ref = ref.act(o2, p2, eps)
-        worst["act"] = max(worst["act"], float(np.abs(a_hip - a_ref).max()))
+        errs["act"].append(np.abs(a_hip - a_ref).max(axis=1))
         pk = pack()
         # teacher-forced: both simulators take the oracle's action from the oracle's state, so that 64 chaotic robots do
         # not amplify round-off over 60 steps; the learner sees each side's own observations
@@ -66,12 +66,19 @@ def test_config1_64_envs_full_iteration_against_oracle(hxlib):
         tv = infos["time_outs"].numpy().astype(bool)
         assert np.array_equal(tv, orc.time_outs_visible), f"extras time_outs differ at step {t}"
         stale_fired += int((tv & ~orc.time_out_buf).sum())                  # flagged as timed out although this step's buffer is clear
-        worst["obs"] = max(worst["obs"], float(np.abs(obs.numpy() - o2).max()))
-        worst["rew"] = max(worst["rew"], float(np.abs(rew.numpy() - r2).max()))
+        errs["obs"].append(np.abs(obs.numpy() - o2).max(axis=1))
+        errs["rew"].append(np.abs(rew.numpy() - r2))
         alg.process_env_step(rew, done, infos)
         ref.process_env_step(r2, d2, orc.time_outs_visible)
     assert stale_fired > 0, "the stale extras['time_outs'] quirk never fired: the test lost its point"
-    assert worst["act"] < 1e-4 and worst["obs"] < 5e-3 and worst["rew"] < 1e-4, worst       # measured 8e-6 / 6e-4 / 4e-6
+    # per (step, robot) pair, as in tests/step_errors.py: the tight bound for all but a counted handful of pairs (a PD torque
+    # crossing its clip, a threshold reward), the loose one for every pair
+    e = {k: np.concatenate(v) for k, v in errs.items()}
+    worst = {k: float(v.max()) for k, v in e.items()}
+    over = {k: int((e[k] > tight).sum()) for k, tight in (("act", 2e-5), ("obs", 2e-4), ("rew", 2e-5))}
+    print("config 1 per-pair errors: worst", worst, "pairs over the tight bound", over, "of", e["obs"].size)
+    assert over["act"] <= 8 and over["obs"] <= 8 and over["rew"] <= 8, (over, worst)
+    assert worst["act"] < 1e-3 and worst["obs"] < 0.4 and worst["rew"] < 5e-3, worst
     alg.compute_returns(priv)
     ref.compute_returns(p2)
     np.testing.assert_allclose(alg.buffer(4, (T, n)).numpy(), ref.rewards, rtol=0, atol=3e-3)        # incl. the (stale) time-out bootstrap
@@ -83,6 +90,8 @@ def test_config1_64_envs_full_iteration_against_oracle(hxlib):
     assert abs(alg.learning_rate / ref.lr - 1) < 1e-6
     print("config 1: stale time-out flags seen %d times; worst |action| %.1e, |obs| %.1e, |reward| %.1e; losses %.5f / %.5f (oracle %.5f / %.5f)"
           % (stale_fired, worst["act"], worst["obs"], worst["rew"], vl, sl, vl2, sl2))
+    print("config 1: max |reward - oracle| %.2e, max |advantage - oracle| %.2e" % (float(np.abs(alg.buffer(4, (T, n)).numpy() - ref.rewards).max()),
+                                                                                float(np.abs(alg.buffer(6, (T, n)).numpy() - ref.advantages).max())))
     alg.close()
     env.close()
 

@@ -89,57 +89,91 @@ def test_pipelined_runner_trains(hxlib):
     env.close()
 
 
-def test_deferred_stacking_fills_the_storage_identically(hxlib, monkeypatch):
-    """HX_DEFER_STACK=1 (include/hx_sim.h hx_sim_step_deferred: observation rows assembled by the next actor launch, privileged
-    rows by spare workgroups of the next env-step launch, no stacking launch) against the default three-launch step: same
-    kernels on the same numbers in another place, so every stored array -- stacked rows, rewards, dones, the stale
-    extras["time_outs"], values -- must be equal bit for bit, and the episode statistics up to the order of their atomic sums.  Robots start near their time limit so that
-    resets (zeroed history) and the time-out bookkeeping occur inside the 16 steps."""
+@pytest.mark.parametrize("task", ["hector", "humanoid_ppo"])
+def test_frame_storage_equals_row_storage(hxlib, task):
+    """Single-frame observation storage (include/hx_ppo.h hx_ppo_cfg.obs_frame; include/hx_sim.h hx_sim_step_frames) against the
+    reference's stacked rows: the frame rings hold every robot's frames once, the fused actor / deferred critic / first-layer
+    forward and weight-gradient products read their rows through (row start, first valid element) tables, there is no stacking
+    launch and no minibatch gather -- the same numbers reach the same fma chains in the same order, so every stored array
+    (rows expanded on request, actions, values, rewards, dones, the stale extras["time_outs"]), the env's own row buffers
+    after the rollout AND the parameters after two updates must be equal bit for bit; the episode statistics up to the order
+    of their atomic sums.  Robots start near their time limit so that resets (zeroed history) and the time-out bookkeeping occur
+    inside the 16 steps.  humanoid_ppo: 47 x 15 / 73 x 3 frames, generic (unfused) rollout actor."""
     from isaac_amd import capi
-    from isaac_amd.envs.configs import HectorCfg
-    from isaac_amd.envs.hector_env import HectorFreeEnv
+    from isaac_amd.envs.configs import HectorCfg, XBotLCfg
+    from isaac_amd.envs.hector_env import HectorFreeEnv, XBotLFreeEnv
     from isaac_amd.algo.ppo import PPO, ActorCritic
     from isaac_amd.utils.helpers import set_seed
-    from oracle.ppo import ActorCriticOracle
+    import torch
     N, T = 200, 16                       # not a multiple of the actor's 16-row workgroups nor of the 8 robots per wave
-    init = ActorCriticOracle.default_init(np.random.default_rng(4)).state_dict()
+    cfg_cls, env_cls = (HectorCfg, HectorFreeEnv) if task == "hector" else (XBotLCfg, XBotLFreeEnv)
     res = []
-    for defer in ("0", "1"):
-        monkeypatch.setenv("HX_DEFER_STACK", defer)
-        cfg = HectorCfg(); cfg.env.num_envs = N; cfg.seed = set_seed(9)
-        env = HectorFreeEnv(cfg)
+    for frames in (False, True):
+        cfg = cfg_cls(); cfg.env.num_envs = N; cfg.seed = set_seed(9)
+        if task != "hector":
+            cfg.terrain.mesh_type = "plane"
+        env = env_cls(cfg)
         ep = np.random.default_rng(1).integers(0, 2000, N).astype(np.int32)
-        ep[::7] = 2394 + (np.arange(len(ep[::7])) % 5)
+        ep[::7] = int(env.max_episode_length) - 6 + (np.arange(len(ep[::7])) % 5)
         env.episode_length_buf = ep
-        ac = ActorCritic(615, 1050, 10, [512, 256, 128], [768, 256, 128]); ac.load_state_dict(init)
-        alg = PPO(ac, num_learning_epochs=1, num_mini_batches=4, gamma=0.994, lam=0.9, learning_rate=1e-5, schedule="adaptive",
+        torch.manual_seed(3)
+        # hector: the fused rollout actor (512 / 256 / 128); humanoid_ppo: other widths -> the layer-by-layer rollout actor
+        dims = ([512, 256, 128], [768, 256, 128]) if task == "hector" else ([256, 128, 64], [256, 128, 64])
+        ac = ActorCritic(env.num_obs, env.num_privileged_obs, env.num_actions, *dims)
+        alg = PPO(ac, num_learning_epochs=2, num_mini_batches=4, gamma=0.994, lam=0.9, learning_rate=1e-5, schedule="adaptive",
                   desired_kl=0.01, stream=env.stream)
-        alg.init_storage(N, T, [615], [1050], [10], obs_ld=616, priv_ld=1052)
+        alg.init_storage(N, T, [env.num_obs], [env.num_privileged_obs], [env.num_actions], obs_ld=env.obs_ld, priv_ld=env.priv_ld,
+                         frames=env.frame_dims if frames else None)
+        assert (alg.frames is not None) == frames
         out = {}
-        for it in range(2):              # two rollouts: the second starts from rows the first one's last (plain) step left
+        for it in range(2):              # two rollouts: the second starts from the rows the first one left in the simulator
             alg.rollout([env], T)
             alg.compute_returns(env.get_privileged_observations())
             out.update({f"{k}{it}": alg.buffer(i, shp, dt).numpy().copy() for k, i, shp, dt in
-                        (("actions", 0, (T, N, 10), np.float32), ("values", 1, (T, N), np.float32), ("logp", 2, (T, N), np.float32),
+                        (("actions", 0, (T, N, env.num_actions), np.float32), ("values", 1, (T, N), np.float32), ("logp", 2, (T, N), np.float32),
                          ("rewards", 4, (T, N), np.float32), ("returns", 5, (T, N), np.float32))})
-            out[f"obs{it}"] = alg.buffer(capi.PPO_BUF_OBS, (T, N, 616)).numpy().copy()
-            out[f"priv{it}"] = alg.buffer(capi.PPO_BUF_PRIV, (T, N, 1052)).numpy().copy()
+            out[f"obs{it}"] = alg.storage_rows(capi.PPO_BUF_OBS).numpy().copy()
+            out[f"priv{it}"] = alg.storage_rows(capi.PPO_BUF_PRIV).numpy().copy()
             out[f"dones{it}"] = alg.buffer(capi.PPO_BUF_DONES, (T, N), np.uint8).numpy().copy()
             out[f"timeouts{it}"] = alg.buffer(capi.PPO_BUF_TIMEOUTS, (T, N), np.uint8).numpy().copy()
             out[f"final_obs{it}"] = env.get_observations().numpy().copy()
             out[f"final_priv{it}"] = env.get_privileged_observations().numpy().copy()
-            alg.update()
+            out[f"losses{it}"] = np.array(alg.update())
+            out[f"params{it}"] = np.concatenate([v.reshape(-1) for v in ac.state_dict().values()])
+        if frames:                       # the rows after the last step exist too (what the bootstrap value is computed from)
+            last = alg.storage_rows(capi.PPO_BUF_PRIV, T, T + 1).numpy()[0]
+            np.testing.assert_array_equal(last[:, :env.num_privileged_obs], out["final_priv1"])
+        # a row-API step after a frame-mode rollout continues from the imported rows
+        o2, p2, _, _, _ = env.step(np.zeros((N, env.num_actions), np.float32))
+        out["next_obs"] = o2.numpy().copy()
         info, n_ep = env.episode_stats()
         out["stats"] = np.array([info[k] for k in sorted(info)] + [n_ep], np.float64)
         res.append(out)
+        alg.close()
         env.close()
     a, b = res
     assert a["dones0"].sum() > 0 and a["timeouts0"].sum() > 0
+    assert (a["obs1"][:, :, :env.obs_frame] == 0).all(axis=2).any(), "no zeroed history in the rollout: the test lost its point"
     for k in a:
         if k == "stats":      # sums of float atomics over the robots that reset: equal up to the order of the additions
             np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-9, err_msg=k)
         else:
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_frame_storage_refuses_ready_made_rows(hxlib):
+    from isaac_amd.envs.configs import HectorCfg
+    from isaac_amd.envs.hector_env import HectorFreeEnv
+    from isaac_amd.algo.ppo import PPO, ActorCritic
+    cfg = HectorCfg(); cfg.env.num_envs = 32
+    env = HectorFreeEnv(cfg)
+    alg = PPO(ActorCritic(615, 1050, 10, [512, 256, 128], [768, 256, 128]), stream=env.stream)
+    alg.init_storage(32, 4, [615], [1050], [10], obs_ld=616, priv_ld=1052, frames=env.frame_dims)
+    with pytest.raises(RuntimeError, match="single-frame"):
+        alg.act(env.get_observations(), env.get_privileged_observations())
+    with pytest.raises(RuntimeError, match="storage_rows|do not exist"):
+        alg.buffer(9, (4, 32, 616))
+    alg.close(); env.close()
 
 
 def test_deferred_critic_batching_does_not_change_the_values(hxlib, monkeypatch):

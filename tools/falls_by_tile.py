@@ -28,6 +28,7 @@ ap.add_argument("--variants", default="default,ramps,no_flatten,no_wallpush,plai
 ap.add_argument("--push", default="off", choices=["on", "off"])
 ap.add_argument("--steps", type=int, default=1000)
 ap.add_argument("--envs", type=int, default=4096)
+ap.add_argument("--cmd", default="0.5", help="fixed forward command in m/s (the play protocol), or 'env' for the env's own resampled commands (training conditions)")
 ap.add_argument("--json", default=None, help="also append one JSON line per variant to this file")
 args = ap.parse_args()
 sd = load_actor_npz(os.path.join(ROOT, "tests", "golden", "actors", "locomotion_net.npz")) if args.policy == "physx" else load_actor_checkpoint(args.policy)
@@ -49,8 +50,9 @@ for name in args.variants.split(","):
         if "edit" in v:
             v["edit"](cfg)
     r = roll_actor(sd, num_envs=args.envs, steps=args.steps, mesh_type="trimesh", cfg_edit=edit, phys=v.get("phys"),
+                   command=None if args.cmd == "env" else (float(args.cmd), 0.0, 0.0, 0.0),
                    terrain_flags=v.get("flags", 0), by_tile=True)
-    print(f"== policy {os.path.basename(args.policy)}  variant {name}  pushes {args.push}: survival {r['survival']:.3f}  "
+    print(f"== policy {os.path.basename(args.policy)}  variant {name}  pushes {args.push}  command {args.cmd}: survival {r['survival']:.3f}  "
           f"falls/robot/10s {r['falls_per_robot_10s']:.2f}  median first fall {r['median_first_fall']:.0f} steps  vx of robots still up {r['mean_vx']:.3f}")
     print("kind          robots  survival  falls/robot/10s |  survival by difficulty tercile (easy, mid, hard) | falls/robot/10s by tercile")
     tiles = r["tiles"]
