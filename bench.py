@@ -69,16 +69,20 @@ def pmc_env_step(build_id):
     return _committed("*_env_step_pmc.json", build_id)
 
 
-def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_rows=16384):
-    """CPU baseline on this box's host cores, kind = "port": the env step is the HOST build of the product's own single-source
-    kernel text (oracle/host: isaac_amd/csrc/hx_math.h + hx_dyn.h + hx_env.h compiled with g++ -O3 -march=native -fopenmp,
-    OpenMP over robots) -- what SURVEY.md 8(d) specifies -- and the learner is the numpy oracle (oracle/ppo.py, BLAS threads).
-    Timed: `sample_steps` env steps of `sample_envs` robots on the same terrain (all host threads, then OMP_NUM_THREADS = 10,
-    the reference's physx.num_threads, hector_config.py:109) and one PPO minibatch step on `update_rows` rows scaled to the
-    8 x 61 440 rows of an iteration; combined into env-steps/s of a whole iteration."""
+def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_rows=61440):
+    """CPU baseline on this box's host cores, kind = "port" (SURVEY.md 8d ii: the build's own host-compiled restatement):
+      * env step = the HOST build of the product's own single-source kernel text (oracle/host/hx_host.cpp: hx_math.h + hx_dyn.h +
+        hx_env.h compiled with g++ -O3 -fopenmp, OpenMP over robots);
+      * learner = the compiled host restatement of the learner's dense arithmetic (oracle/host/hx_learner_host.cpp: AVX2-FMA GEMM,
+        ELU, Adam; OpenMP) under the numpy oracle's PPO (loss head, GAE, schedule), parity-checked against the reference's own
+        PPO outputs (tests/test_host_learner.py, tests/golden/ppo_small.npz).
+    Timed: `sample_steps` env steps of `sample_envs` robots on the same terrain (all host threads, then OMP_NUM_THREADS = 10, the
+    reference's physx.num_threads, hector_config.py:109); 15 policy steps at 4096 rows + ONE full-size minibatch step
+    (forward, loss, backward, clip, Adam on `update_rows` = 61 440 rows) scaled to the 8 minibatch steps of an iteration;
+    combined into env-steps/s of a whole iteration.  For scale: the reference's own torch-CPU learner does 18.1 k env-steps/s
+    on 8 cores; its env cannot run anywhere (PhysX)."""
     import subprocess
-    from isaac_amd.envs.configs import HectorCfg
-    code = (
+    env_code = (
         "import sys, time, json, numpy as np\n"
         f"sys.path.insert(0, {ROOT!r})\n"
         "from isaac_amd.envs.configs import HectorCfg\n"
@@ -94,46 +98,57 @@ def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_ro
         f"    for _ in range({max(1, sample_steps // 3)}): env.L.hxh_step(env.h, a.ctypes.data, None)\n"
         f"    best = min(best, (time.perf_counter() - t0) / {max(1, sample_steps // 3)})\n"
         "print(json.dumps(dict(s_per_step=best, threads=int(lib().hxh_num_threads()))))\n")
+    N, T = 4096, update_rows // 4096
+    learner_code = (
+        "import sys, time, json, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from oracle.ppo import ActorCriticOracle\n"
+        "from oracle.host.learner import HostPPOOracle, host_actor_critic, lib\n"
+        f"N, T = {N}, {T}\n"
+        "rng = np.random.default_rng(0)\n"
+        "ac = host_actor_critic(ActorCriticOracle.default_init(rng))\n"
+        "alg = HostPPOOracle(ac, N, T, num_learning_epochs=1, num_mini_batches=1)\n"
+        "O, P, E = (rng.standard_normal((N, k)).astype(np.float32) for k in (615, 1050, 10))\n"
+        "for rep in range(2):                              # first pass = warm-up: thread pool, first touch of storage and buffers\n"
+        "    alg.step = 0\n"
+        "    t0 = time.perf_counter()\n"
+        "    for t in range(T):\n"
+        "        alg.act(O, P, E); alg.process_env_step(np.full(N, 0.02, np.float32), np.zeros(N, bool))\n"
+        "    t_act = (time.perf_counter() - t0) / (N * T)\n"
+        "alg.compute_returns(P)\n"
+        "perm = rng.permutation(N * T)\n"
+        "alg.update(perm); alg.step = T                    # warm-up: first touch of the workspaces\n"
+        "t0 = time.perf_counter(); alg.update(perm)\n"
+        "t_upd = (time.perf_counter() - t0) / (N * T)\n"
+        "print(json.dumps(dict(t_act=t_act, t_upd_row=t_upd, threads=int(lib().hxl_num_threads()))))\n")
 
-    def run(threads):
-        env = dict(os.environ)
+    def run(code, threads, **extra):
+        env = dict(os.environ, **extra)
         if threads:
             env["OMP_NUM_THREADS"] = str(threads)
         else:
             env.pop("OMP_NUM_THREADS", None)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        out = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True, timeout=900)
+        if out.returncode != 0:
+            raise RuntimeError(out.stderr[-600:])
         return json.loads(out.stdout.strip().splitlines()[-1])
 
-    full, ten = run(None), run(10)
-    # learner: one minibatch step (forward, loss, backward, clip, Adam) of the numpy oracle on a bounded number of rows
-    from oracle.ppo import ActorCriticOracle, PPOOracle
-    rng = np.random.default_rng(0)
-    N, T = update_rows // 16, 16
-    alg = PPOOracle(ActorCriticOracle.default_init(rng), N, T, num_learning_epochs=1, num_mini_batches=1)
-    t0 = time.perf_counter()
-    for t in range(T):
-        o, pv = rng.standard_normal((N, 615)).astype(np.float32), rng.standard_normal((N, 1050)).astype(np.float32)
-        alg.act(o, pv, rng.standard_normal((N, 10)).astype(np.float32))
-        alg.process_env_step(rng.uniform(0, 0.05, N).astype(np.float32), rng.uniform(size=N) < 0.01)
-    t_act = (time.perf_counter() - t0) / (N * T)                  # policy forward + store, seconds per env-step
-    alg.compute_returns(pv)
-    t0 = time.perf_counter()
-    alg.update(rng.permutation(N * T))
-    t_upd_row = (time.perf_counter() - t0) / (N * T)              # seconds per minibatch row
-    try:
-        import threadpoolctl
-        blas_threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        blas_threads = os.cpu_count()
+    full, ten = run(env_code, None), run(env_code, 10)
+    # numpy's BLAS pool is kept to one thread here: its spinning workers would fight the OpenMP team of the compiled learner
+    lf, lt = run(learner_code, None, OPENBLAS_NUM_THREADS="1"), run(learner_code, 10, OPENBLAS_NUM_THREADS="1")
     n = sample_envs
-    per_env_step = lambda env_s: env_s / n + t_act + 2 * t_upd_row          # 2 epochs over every stored row
-    v_full, v_ten = 1.0 / per_env_step(full["s_per_step"]), 1.0 / per_env_step(ten["s_per_step"])
+    per_env_step = lambda env_s, l: env_s / n + l["t_act"] + 2 * l["t_upd_row"]          # 2 epochs over every stored row
+    v_full, v_ten = 1.0 / per_env_step(full["s_per_step"], lf), 1.0 / per_env_step(ten["s_per_step"], lt)
+    learner_only = lambda l: 1.0 / (l["t_act"] + 2 * l["t_upd_row"])
     return {"value": v_full, "unit": "env-steps/s", "cores": int(full["threads"]), "kind": "port",
             "sample": f"{sample_steps} env steps x {n} robots (terrain {terrain}) on the host build of the kernel source: "
                       f"{1e3 * full['s_per_step']:.1f} ms per step with {full['threads']} OpenMP threads, {1e3 * ten['s_per_step']:.1f} ms with 10; "
-                      f"learner = numpy oracle, {T} policy steps + one minibatch step on {N * T} rows ({blas_threads} BLAS threads), scaled to 2 epochs; "
+                      f"learner = compiled host restatement (AVX2 GEMM + numpy loss head), {T} policy steps at {N} rows + one minibatch step on {N * T} rows, "
+                      f"scaled to 2 epochs: {1e6 * lf['t_act']:.2f} + 2 x {1e6 * lf['t_upd_row']:.2f} us per env-step with {lf['threads']} threads; "
                       f"host has {os.cpu_count()} logical cores",
-            "env_only_env_steps_per_s": n / full["s_per_step"], "omp10": {"value": v_ten, "env_only_env_steps_per_s": n / ten["s_per_step"], "cores": 10}}
+            "env_only_env_steps_per_s": n / full["s_per_step"], "learner_only_env_steps_per_s": learner_only(lf),
+            "omp10": {"value": v_ten, "env_only_env_steps_per_s": n / ten["s_per_step"], "learner_only_env_steps_per_s": learner_only(lt), "cores": 10},
+            "reference_learner_8_cores_env_steps_per_s": 18.1e3}
 
 
 def spawn_ranks(n):
