@@ -5,6 +5,14 @@
 
 void hx_set_error(const std::string& s);
 
+// Experiment knobs are environment variables read when a simulator / learner is created.  None is needed to use
+// the library; all of them change scheduling only, never results.  They are VALIDATED: hx_knobs_check() fails creation on an
+// HX_* variable this build does not know (a typo would otherwise silently run the default) and hx_knob_int() on a value that is
+// not an integer inside the knob's range.
+int hx_knobs_check(void);
+int hx_knob_int(const char* name, int dflt, int lo, int hi, int* out);
+int hx_knob_hex32(const char* name, bool* present, unsigned* out);
+
 #define HX_CHECK(expr)                                                                         \
   do {                                                                                         \
     hipError_t _e = (expr);                                                                    \

@@ -1325,6 +1325,7 @@ extern "C" int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld,
 static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo* s);
 extern "C" void hx_ppo_destroy(hx_ppo* s);
 extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo** out) {
+  if (int rc = hx_knobs_check()) return rc;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_ppo_create: no HIP device (this library has no CPU path)"); return -1; }
   if (cfg->num_actions > MAX_A || cfg->num_actions < 1) { hx_set_error("hx_ppo_create: num_actions must be in [1, 32]"); return -2; }
@@ -1348,6 +1349,21 @@ extern "C" int hx_ppo_create(const hx_ppo_cfg* cfg, void* stream, void* ext_grad
 
 static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, hx_ppo* s) {
   s->cfg = *cfg;
+  if (int rc = hx_knobs_check()) return rc;
+  int knob_streams = 1, knob_bg_persist = -1, knob_wgrad = 0;
+  bool cu_set = false; unsigned cu_word = 0;
+  if (int rc = hx_knob_hex32("HX_CRITIC_CU_WORD", &cu_set, &cu_word)) return rc;
+  if (int rc = hx_knob_int("HX_UPDATE_STREAMS", 1, 1, 2, &knob_streams)) return rc;
+  if (int rc = hx_knob_int("HX_ACTOR_WAVES", 8, 4, 8, &s->actor_waves)) return rc;
+  if (s->actor_waves != 4 && s->actor_waves != 8) { hx_set_error("HX_ACTOR_WAVES: 4 or 8"); return -2; }
+  if (int rc = hx_knob_int("HX_CRITIC_LATE", 0, 0, 1, &s->critic_late)) return rc;
+  if (int rc = hx_knob_int("HX_BG_PERSIST", -1, 0, 4096, &knob_bg_persist)) return rc;
+  if (int rc = hx_knob_int("HX_FWD_IN_TILE", 128, 64, 128, &s->fwd_in_tile)) return rc;
+  if (s->fwd_in_tile != 64 && s->fwd_in_tile != 128) { hx_set_error("HX_FWD_IN_TILE: 64 or 128"); return -2; }
+  if (int rc = hx_knob_int("HX_BG_TILE", 0, 0, 128, &s->bg_tile)) return rc;
+  if (s->bg_tile != 0 && s->bg_tile != 64 && s->bg_tile != 128) { hx_set_error("HX_BG_TILE: 0 (by batch size), 64 or 128"); return -2; }
+  if (int rc = hx_knob_int("HX_CRITIC_CHUNK", HX_CRITIC_CHUNK, 1, 4096, &s->critic_chunk)) return rc;
+  if (int rc = hx_knob_int("HX_WGRAD_BLOCKS", 0, 1, 65536, &knob_wgrad)) return rc;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
   {
@@ -1356,9 +1372,9 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     // CUs (hipExtStreamCreateWithCUMask) was measured and is WORSE (profiles/r01_critic_cu_mask.txt): the env-step
     // kernel's slow-down during critic bursts is not a CU-occupancy effect, and a narrower critic only finishes later.
     // HX_CRITIC_CU_WORD=<hex 32-bit word, repeated for each group of 32 CUs> keeps the experiment reproducible.
-    if (const char* e = getenv("HX_CRITIC_CU_WORD")) {
+    if (cu_set) {
       uint32_t mask[8];
-      for (int i = 0; i < 8; ++i) mask[i] = (uint32_t)strtoul(e, nullptr, 16);
+      for (int i = 0; i < 8; ++i) mask[i] = cu_word;
       HX_CHECK(hipExtStreamCreateWithCUMask(&s->stream2, 8, mask));
     } else {
       int least = 0, greatest = 0;
@@ -1368,7 +1384,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   }
   // measured (profiles/r02_c_update_phase.txt): no gain at 4096 envs (31.70 ms against 31.41 ms on one stream) -- the launches
   // of one chain already keep every CU busy; kept behind HX_UPDATE_STREAMS=2 for other sizes
-  if (getenv("HX_UPDATE_STREAMS") && atoi(getenv("HX_UPDATE_STREAMS")) == 2) {
+  if (knob_streams == 2) {
     HX_CHECK(hipStreamCreateWithFlags(&s->stream_b, hipStreamNonBlocking));
     HX_CHECK(hipEventCreateWithFlags(&s->ev_b0, hipEventDisableTiming));
     HX_CHECK(hipEventCreateWithFlags(&s->ev_b1, hipEventDisableTiming));
@@ -1492,8 +1508,6 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   // 8 waves (each streams 1/8 of a layer's weight rows) keep twice the bytes in flight per CU: 68 us per call against
   // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
-  { const char* e = getenv("HX_ACTOR_WAVES"); s->actor_waves = (e && atoi(e) == 4) ? 4 : 8; }
-  { const char* e = getenv("HX_CRITIC_LATE"); s->critic_late = e ? atoi(e) : 0; }
   for (int l = 0; l < 3; ++l) s->apack[l] = nullptr;
   s->apack_dirty = true;
   {
@@ -1502,12 +1516,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     // the SIMDs of the other half.  More robots than that need every CU for the env step itself: ordinary launches then.
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* e = getenv("HX_BG_PERSIST");
-    s->bg_persist = e ? atoi(e) : ((cfg->num_envs <= 16 * cus) ? cus / 2 : 0);
+    s->bg_persist = knob_bg_persist >= 0 ? knob_bg_persist : ((cfg->num_envs <= 16 * cus) ? cus / 2 : 0);
   }
-  { const char* e = getenv("HX_FWD_IN_TILE"); s->fwd_in_tile = (e && atoi(e) == 64) ? 64 : 128; }
-  { const char* e = getenv("HX_BG_TILE"); s->bg_tile = e ? atoi(e) : 0; }
-  { const char* e = getenv("HX_CRITIC_CHUNK"); s->critic_chunk = (e && atoi(e) > 0) ? atoi(e) : HX_CRITIC_CHUNK; }
   {
     const int ha_ = cfg->actor_hidden[2], hc_ = cfg->critic_hidden[2];
     const size_t head_lds = head_lds_bytes(ha_, hc_, A, head_lds_bytes(ha_, hc_, A, true) <= 64 * 1024);

@@ -267,6 +267,47 @@ __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
 static thread_local std::string g_err;
 extern "C" const char* hx_last_error(void) { return g_err.c_str(); }
 void hx_set_error(const std::string& s) { g_err = s; }
+// ---- validated experiment knobs (hx_common.h)
+extern char** environ;
+int hx_knobs_check(void) {
+  // library knobs, then the names the Python host / tools / tests of this repository read themselves
+  static const char* known[] = {"HX_CRITIC_CHUNK", "HX_BG_PERSIST", "HX_BG_TILE", "HX_CRITIC_LATE", "HX_CRITIC_CU_WORD", "HX_ACTOR_WAVES", "HX_FWD_IN_TILE",
+                                "HX_UPDATE_STREAMS", "HX_WGRAD_BLOCKS", "HX_WGRAD_FLOOR", "HX_BENCH_LD0", "HX_BENCH_NODB", "HX_BENCH_NOKFULL", "HX_SIM_CU_WORD",
+                                "HX_COMM_TIMEOUT_S", "HX_COMM_INIT_TIMEOUT_S",
+                                "HX_DIST_BACKEND", "HX_DP_FORCE_RCCL", "HX_BENCH_CHILD_PROBE", "HX_STEP_PROF", "HX_STEP_PROF_CHILD", "HX_REFERENCE_ROOT"};
+  for (char** e = environ; e && *e; ++e) {
+    if (strncmp(*e, "HX_", 3) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+    if (name.rfind("HX_EXTRA_FLAGS_", 0) == 0) continue;      // build-time flags of isaac_amd/build.py
+    bool ok = false;
+    for (const char* k : known) ok = ok || name == k;
+    if (!ok) { hx_set_error("unknown environment variable " + name + ": this build reads no such knob (DESIGN.md 3.4 lists them)"); return -2; }
+  }
+  return 0;
+}
+int hx_knob_int(const char* name, int dflt, int lo, int hi, int* out) {
+  *out = dflt;
+  const char* e = getenv(name);
+  if (!e) return 0;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  if (end == e || *end != 0 || v < lo || v > hi) {
+    hx_set_error(std::string(name) + "=" + e + ": expected an integer in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]"); return -2;
+  }
+  *out = (int)v;
+  return 0;
+}
+int hx_knob_hex32(const char* name, bool* present, unsigned* out) {
+  const char* e = getenv(name);
+  *present = e != nullptr;
+  if (!e) return 0;
+  char* end = nullptr;
+  const unsigned long v = strtoul(e, &end, 16);
+  if (end == e || *end != 0 || v > 0xfffffffful || v == 0) { hx_set_error(std::string(name) + "=" + e + ": expected a non-zero 32-bit hex CU mask word"); return -2; }
+  *out = (unsigned)v;
+  return 0;
+}
 extern "C" int hx_version(void) { return 100; }
 #ifndef HX_BUILD_ID
 #define HX_BUILD_ID "unknown"
@@ -311,6 +352,7 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
 extern "C" void hx_sim_destroy(hx_sim* s);
 extern "C" int hx_sim_create(const hx_sim_cfg* cfg, const float* friction_h, const float* base_mass_h, const float* origins_h,
                              const float* start_pos_h, uint64_t seed, void* stream, hx_sim** out) {
+  if (int rc = hx_knobs_check()) return rc;      // before anything else: a mistyped knob must not run the default silently
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { hx_set_error("hx_sim_create: no HIP device (this library has no CPU path)"); return -1; }
   if (!cfg || cfg->num_envs <= 0) { hx_set_error("hx_sim_create: bad cfg"); return -2; }
@@ -334,11 +376,14 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   s->step_counter = 0;
   s->rng_step = 0;
   s->cur = 0;
+  if (int rc = hx_knobs_check()) return rc;
+  bool cu_set = false; unsigned cu_word = 0;
+  if (int rc = hx_knob_hex32("HX_SIM_CU_WORD", &cu_set, &cu_word)) return rc;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else {
-    if (const char* e = getenv("HX_SIM_CU_WORD")) {      // experiment hook: confine this simulator's stream to a CU subset
+    if (cu_set) {      // experiment hook: confine this simulator's stream to a CU subset
       uint32_t mask[8];
-      for (int i = 0; i < 8; ++i) mask[i] = (uint32_t)strtoul(e, nullptr, 16);
+      for (int i = 0; i < 8; ++i) mask[i] = cu_word;
       HX_CHECK(hipExtStreamCreateWithCUMask(&s->stream, 8, mask));
     } else {
       int least = 0, greatest = 0;

@@ -2,6 +2,7 @@
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -83,6 +84,21 @@ def test_no_device_fails_loudly(libpath):
     alg = PPO(ActorCritic(615, 1050, 10, [512, 256, 128], [768, 256, 128]))
     with pytest.raises(RuntimeError):
         alg.init_storage(16, 4, [615], [1050], [10])
+
+
+def test_unknown_experiment_knob_is_an_error(libpath):
+    """HX_* environment variables are validated when a simulator / learner is created: a name this build does not know fails
+    creation (before the device check, so this holds on the CPU container too) instead of silently running the default."""
+    code = ("import ctypes as C\nfrom isaac_amd import capi\nL = capi.lib()\nh = C.c_void_p()\n"
+            "rc = L.hx_sim_create(C.byref(capi.SimCfg()), None, None, None, None, 0, None, C.byref(h))\n"
+            "rc2 = L.hx_ppo_create(C.byref(capi.PpoCfg()), None, None, C.byref(h))\n"
+            "print(rc, rc2, L.hx_last_error().decode())\n")
+    env = dict(os.environ, HX_CRITC_CHUNK="3", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert out.startswith("-2 -2 ") and "HX_CRITC_CHUNK" in out, out
+    env.pop("HX_CRITC_CHUNK")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout
+    assert "HX_CRITC_CHUNK" not in out and not out.startswith("-2 -2 unknown"), out
 
 
 def test_product_never_imports_oracle():
