@@ -210,9 +210,10 @@ def main():
                     help="learner precision: f32 = the metric's configuration (BASELINE config 2); bf16 = BASELINE config 4 "
                          "(forward/dgrad products on the bf16 matrix cores, fp32 master weights and wgrads) -- a different "
                          "configuration, reported with dtype 'bf16' and never as the headline")
-    ap.add_argument("--storage", default="frames", choices=["frames", "rows"],
-                    help="rollout storage of the observations: frames = every robot's 41 / 70-wide frames once (the build's default), "
-                         "rows = the reference's stacked 615 / 1050-wide rows (stacking and gather launches; for A/B runs)")
+    ap.add_argument("--storage", default="auto", choices=["auto", "frames", "rows"],
+                    help="rollout storage of the observations: frames = every robot's 41 / 70-wide frames once, rows = the reference's "
+                         "stacked 615 / 1050-wide rows (stacking and gather launches), auto = by measurement (frames from 16 384 robots "
+                         "per GPU up; isaac_amd/algo/on_policy_runner.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic, one rank only: walk the N > 1 code path (RCCL all-reduce per optimiser step, as identity) "

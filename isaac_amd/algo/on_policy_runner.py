@@ -49,11 +49,16 @@ class OnPolicyRunner:
                                                               comm=comm, **alg_kw)
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
-        # an env served by one simulator object reports its frame dimensions: the learner then keeps single-frame observation
-        # storage and the rollout runs without stacking / gather launches (a sharded env keeps the row layout)
-        # runner.observation_storage = "rows" (not a reference key) keeps the reference's stacked-row layout for A/B runs
+        # Rollout storage of the observations (runner.observation_storage, not a reference key): "frames" = every robot's frames
+        # once (single-frame storage, include/hx_ppo.h), "rows" = the reference's stacked rows, "auto" (default) = by measurement
+        # (profiles/r03_g_storage.txt, 1 x MI355X fp32): frames are 0.9 % / 1.6 % faster at 16 384 / 65 536 robots per GPU and
+        # 12 x smaller; at 4096 robots the gathered first-layer loaders cost more than the stacking and gather launches they
+        # replace (-3 %), so small batches keep the rows.  Results are bit-identical either way (tests/test_gpu_runner.py).
+        mode = self.cfg.get("observation_storage", "auto")
+        if mode not in ("auto", "frames", "rows"):
+            raise ValueError("runner.observation_storage must be 'auto', 'frames' or 'rows'")
         frames = getattr(env, "frame_dims", None) if (hasattr(env, "_h") and hasattr(self.alg, "rollout")) else None
-        if self.cfg.get("observation_storage", "frames") == "rows":
+        if mode == "rows" or (mode == "auto" and env.num_envs < 16384):
             frames = None
         self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions],
                               obs_ld=getattr(env, "obs_ld", None), priv_ld=getattr(env, "priv_ld", None), frames=frames)

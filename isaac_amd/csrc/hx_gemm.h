@@ -37,11 +37,14 @@ struct GemmArgs {
   int db_parts;             // EPI_SLAB: the column-sum work of a (tile_m, split) is shared by the first db_parts tile_n blocks
   int tiles_m, tiles_n;
   // Gathered operand rows (single-frame observation storage): when the kernel is instantiated with GA (A, K-major)
-  // or GB (B, N-major: the reduction index runs over rows) the operand is not a matrix in memory but a table of row starts --
-  // row r begins at  base + off[r]  (a float offset, 4-byte aligned only: 15 consecutive 41-wide frames of one robot) and its
-  // elements  [0, kz[r])  and  [klim, ...)  read as zero (frames older than the robot's last reset; the padding columns).
+  // the operand is not a matrix in memory but a table of row starts -- row r begins at  base + off[r]  (a float offset, 4-byte
+  // aligned only: 15 consecutive 41-wide frames of one robot) and its elements  [0, kz[r])  and  [klim, ...)  read as zero
+  // (frames older than the robot's last reset; the padding columns).
   const int* a_off; const int* a_kz; int a_klim;
-  const int* b_off; const int* b_kz; int b_klim;
+  // GA only: the assembled rows are also written out as an ordinary matrix [M][a_copy_ld] (16-byte aligned rows), so that the
+  // weight-gradient product of the same layer reads them with the plain loader.  The tile_n workgroups of a row block share
+  // the work (workgroup tile_n writes the K tiles kt = tile_n, tile_n + tiles_n, ...).  nullptr: no copy.
+  float* a_copy; int a_copy_ld;
 };
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a float4 that is only float-aligned in memory
 
@@ -111,10 +114,10 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
   //     never stores), so no lane is ever masked off;
   //   * only the last tile of a reduction can be partial in k: a uniform branch takes the zero-filling path there.
   static_assert(!GA || A_KM, "gathered A rows are K-major (forward products)");
-  static_assert(!GB || !B_KM, "gathered B rows are the reduction index (weight-gradient products)");
+  static_assert(!GB, "gathered B rows were measured 14 % slower than the plain loader and are gone: the forward product writes the assembled rows out instead (a_copy)");
   const float* pa[A_LOADS]; const float* pb[B_LOADS];
   int ka[A_LOADS], kb_[B_LOADS];                    // k offset of the slot inside a tile
-  int za[A_LOADS];                                  // GA: first valid k of the slot's row, relative to the slot's own k offset
+  int za[A_LOADS]; unsigned wa[A_LOADS];            // GA: first valid k of the slot's row and the number of valid k from there (klim - kz)
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
     const int idx = tid + i * 256;
@@ -122,7 +125,7 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
       const int row = idx / (HX_BK / 4), k4 = idx % (HX_BK / 4);
       ka[i] = k4 * 4;
       const int gr = min(m0 + row, g.M - 1);
-      if (GA) { pa[i] = g.A + g.a_off[gr] + k_begin + k4 * 4; za[i] = g.a_kz[gr]; }
+      if (GA) { pa[i] = g.A + g.a_off[gr] + k_begin + k4 * 4; za[i] = g.a_kz[gr]; wa[i] = (unsigned)(g.a_klim - za[i]); }
       else pa[i] = g.A + (size_t)gr * g.lda + k_begin + k4 * 4;
     } else {
       const int k = idx / (BM / 4), m4 = idx % (BM / 4);
@@ -142,53 +145,30 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
       const int k = idx / (BN / 4), n4 = idx % (BN / 4);
       const int gn = n0 + n4 * 4;
       kb_[i] = k;
-      if (GB) pb[i] = g.B + (gn < g.N ? gn : 0);          // column part only: the row start comes from the table, tile by tile
-      else pb[i] = g.B + (size_t)(k_begin + k) * g.ldb + (gn < g.N ? gn : 0);
+      pb[i] = g.B + (size_t)(k_begin + k) * g.ldb + (gn < g.N ? gn : 0);
     }
   }
-  // GB: the (row start, first valid column) pair of the k row each slot reads in the NEXT tile, fetched one tile ahead so that
-  // the dependent address never waits in the loop
-  int ob[B_LOADS], zb[B_LOADS], cb[B_LOADS];
-  if (GB) {
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      const int kr = min(k_begin + kb_[i], g.K - 1);
-      ob[i] = g.b_off[kr]; zb[i] = g.b_kz[kr];
-      const int idx = tid + i * 256, n4 = idx % (BN / 4), gn = n0 + n4 * 4;
-      cb[i] = (gn < g.N ? gn : 0);
-    }
-  }
+  unsigned mka[A_LOADS];      // GA: mask parameter of the tile that is in the staging registers
+  int lt = 0;                 // K tile index of the staging registers
   const size_t stride_a = A_KM ? (size_t)HX_BK : (size_t)HX_BK * g.lda;
   const size_t stride_b = B_KM ? (size_t)HX_BK : (size_t)HX_BK * g.ldb;
   auto load_tile = [&](int kt) {        // tiles must be requested in order 0, 1, 2, ...: the slot pointers advance
     const int k0 = k_begin + kt * HX_BK;
-    if (GA || GB) {
-      // gathered rows: float-aligned 16-byte loads, then the zero prefix / padding mask (v_cmp + v_cndmask per element; the
-      // compares are against tile-uniform k, no divergence).  Rows are whole in k (the tables describe complete rows), so the
-      // partial-tile path is only needed for the ordinary operand.
+    if (GA) {
+      // Gathered rows.  The loads are issued here and NOT touched: the zero prefix / padding mask is applied when the tile is
+      // written to LDS (store_tile), one iteration later -- masking at load time makes the wave wait for the data it has just
+      // requested and exposes the whole global latency in every K tile (measured: +9-14 % on the update's products, +45 % on
+      // the rollout critic's one-wave-per-SIMD grid, profiles/r03_c).  What the mask needs is remembered per slot (mka).
       const bool whole = KFULL || k0 + HX_BK <= k_end;
+      lt = kt;
 #pragma unroll
       for (int i = 0; i < A_LOADS; ++i) {
-        if (GA) {
-          f32x4 v = *reinterpret_cast<const f32x4u*>(pa[i]); pa[i] += stride_a;
-          const int kk = k0 - k_begin + ka[i];                       // k of element 0 of this slot (k_begin = 0 for forward products)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (kk + j >= za[i] && kk + j < g.a_klim) ? v[j] : 0.f;
-          ra[i] = v;
-        } else if (whole) { ra[i] = *reinterpret_cast<const f32x4*>(pa[i]); pa[i] += stride_a; }
-        else { f32x4 v = {0.f, 0.f, 0.f, 0.f}; if (k0 + ka[i] < k_end) v = *reinterpret_cast<const f32x4*>(pa[i]); ra[i] = v; }
+        ra[i] = *reinterpret_cast<const f32x4u*>(pa[i]); pa[i] += stride_a;
+        mka[i] = (unsigned)(k0 - k_begin + ka[i] - za[i]);          // k of element 0 relative to the first valid one; valid: 0 <= . < wa
       }
 #pragma unroll
       for (int i = 0; i < B_LOADS; ++i) {
-        if (GB) {
-          f32x4 v = *reinterpret_cast<const f32x4u*>(pb[i] + ob[i]);
-          const bool in = whole || (k0 + kb_[i] < k_end);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (in && cb[i] + j >= zb[i] && cb[i] + j < g.b_klim) ? v[j] : 0.f;
-          rb[i] = v;
-          const int kr = min(k0 + HX_BK + kb_[i], g.K - 1);         // next tile's row of this slot
-          ob[i] = g.b_off[kr]; zb[i] = g.b_kz[kr];
-        } else if (whole) { rb[i] = *reinterpret_cast<const f32x4*>(pb[i]); pb[i] += stride_b; }
+        if (whole) { rb[i] = *reinterpret_cast<const f32x4*>(pb[i]); pb[i] += stride_b; }
         else { f32x4 v = {0.f, 0.f, 0.f, 0.f}; if (k0 + kb_[i] < k_end) v = *reinterpret_cast<const f32x4*>(pb[i]); rb[i] = v; }
       }
     } else if (KFULL || k0 + HX_BK <= k_end) { // uniform: whole tile inside the reduction range
@@ -214,6 +194,19 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
   auto store_tile = [&](int buf) {
     float* As = lds + buf * (A_ELEMS + B_ELEMS);
     float* Bs = As + A_ELEMS;
+    if (GA) {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[i][j] = (mka[i] + (unsigned)j < wa[i]) ? ra[i][j] : 0.f;
+      if (g.a_copy != nullptr && (lt % g.tiles_n) == tile_n) {       // uniform: this workgroup's share of the row block's K tiles
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+          const int idx = tid + i * 256, row = idx / (HX_BK / 4), k = lt * HX_BK + ka[i];
+          if (m0 + row < g.M && k < g.a_copy_ld) *reinterpret_cast<f32x4*>(g.a_copy + (size_t)(m0 + row) * g.a_copy_ld + k) = ra[i];
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const int idx = tid + i * 256;

@@ -292,12 +292,22 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     // Single-frame storage (include/hx_sim.h): the 16 rows are windows of the robots' frame rings.  Row start and first valid
     // element come from the tables; elements before it (frames older than the robot's last reset) and the padding read as
     // zero.  Row starts are only float-aligned (41-wide frames), so the loads are scalar, coalesced along the row.
-    const int total = FA_ROWS * K1;
-    for (int i = tid; i < total; i += 64 * NW) {
-      const int r = i / K1, k = i - r * K1, gr = min(row0 + r, n - 1);
-      const float v = fsrc.base[(size_t)fsrc.off[gr] + k];          // always inside the ring (+ slack): no guard around the load
-      const float o = (k >= fsrc.kz[gr] && k < fsrc.klim) ? v : 0.f;
-      Xs[r * ldx + k] = BF ? hx_bf16r(o) : o;
+    // 64 * NW / 16 threads per row.  Row starts are only float-aligned (41-wide frames), so a thread loads ALIGNED float4 from the
+    // row start rounded down -- covering elements -m .. K1 + 3 - m of the row, m = the start's misalignment in floats -- and
+    // scatters the four values to their columns in LDS: a quarter of the load instructions of an element-wise copy, no split
+    // 16-byte accesses, no index division.  All loads of a thread are independent of each other.
+    constexpr int TPR = 64 * NW / FA_ROWS;
+    const int r = tid / TPR, q0 = tid % TPR, gr = min(row0 + r, n - 1);
+    const int off = fsrc.off[gr], kz = fsrc.kz[gr], m = off & 3;
+    const f32x4v* src = reinterpret_cast<const f32x4v*>(fsrc.base + (off - m));
+    float* xr = Xs + r * ldx;
+    for (int q = q0; 4 * q - m < K1; q += TPR) {
+      const f32x4v v = src[q];                                       // always inside the ring (+ slack): no guard around the load
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = 4 * q + c - m;
+        if (k >= 0 && k < K1) { const float o = (k >= kz && k < fsrc.klim) ? v[c] : 0.f; xr[k] = BF ? hx_bf16r(o) : o; }
+      }
     }
     // bookkeeping of the env step that produced these rows (it needs that launch's total reset count, hx_common.h)
     if (book_valid) {
@@ -1001,7 +1011,7 @@ static void refresh_transposes(hx_ppo* s, hipStream_t st) {
 // epilogue all variants are within ~5 %; BK = 32 is best for the forward layers and 64-row BK = 32 tiles for dgrad
 // (short K = 128..256, where a shorter launch tail matters most).
 // rows given as windows of the frame rings (first layer of a network with single-frame storage): table slices for the M rows
-struct RowTable { const int* off; const int* kz; int klim; };
+struct RowTable { const int* off; const int* kz; int klim; float* copy = nullptr; int copy_ld = 0; };
 static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int M, int N, int K,
                      bool background = false, bool fp32_only = false, const RowTable* rt = nullptr) {
   GemmArgs g{};
@@ -1009,7 +1019,7 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   if (rt) {
     // gathered A rows: BK16 tiles (K = 616 / 1052 are not multiples of 32), 128-row tiles at update size, 64-row below, the
     // persistent half-chip grid for the rollout's background critic
-    g.a_off = rt->off; g.a_kz = rt->kz; g.a_klim = rt->klim;
+    g.a_off = rt->off; g.a_kz = rt->kz; g.a_klim = rt->klim; g.a_copy = rt->copy; g.a_copy_ld = rt->copy_ld;
     if (background && s->bg_persist > 0) {
       g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 127) / 128;
       hipLaunchKernelGGL((hx_gemm_persistent_kernel<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU, false, true, false>), dim3(s->bg_persist), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
@@ -1055,9 +1065,8 @@ static void gemm_dgrad(hx_ppo* s, hipStream_t st, const float* dZ, int ldz, cons
 // dW[out][in_ld] = dZ[Mrows][out]^T X[Mrows][in_ld] ; returns the number of splits written to slab; *bias_parts = number of
 // partial rows written to bias_slab (splits x the tile_n blocks that share the column-sum work)
 static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const float* X, int ldx, int in_ld, int Mrows, float* slab, float* bias_slab,
-                      int* bias_parts, int alloc_splits, const RowTable* rt = nullptr) {
+                      int* bias_parts, int alloc_splits) {
   GemmArgs g{};
-  if (rt) { g.b_off = rt->off; g.b_kz = rt->kz; g.b_klim = rt->klim; }
   g.A = dZ; g.lda = out; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = in_ld; g.M = out; g.N = in_ld; g.K = Mrows;
   const int tiles = ((out + 127) / 128) * ((in_ld + 127) / 128);
   // Split-K grid = ONE full wave of workgroups: 3 resident per CU (144 VGPRs -> 3 waves per SIMD; 32 KB LDS), never
@@ -1096,11 +1105,6 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
     return splits;
   }
   // kchunk is a multiple of 32; with a row count that is a multiple of the K tile every split is whole tiles
-  if (rt) {        // X rows gathered from the frame rings
-    if (Mrows % HX_BK_UPD == 0) launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true, false, true>(s, g, st);
-    else launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, false, false, true>(s, g, st);
-    return splits;
-  }
   if (Mrows % HX_BK_UPD == 0) launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true>(s, g, st);
   else launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
   return splits;
@@ -1460,8 +1464,9 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   // minibatch i holds the same rows in each epoch: with more than one epoch the gathered rows are kept per minibatch
   // (a permuted copy of the rollout, 1.6 GB at 4096 envs) and gathered once per update instead of once per epoch.
   s->mb_slots = (cfg->num_learning_epochs > 1 && cfg->num_mini_batches <= 64 && mbs >= N) ? cfg->num_mini_batches : 1;
-  if (s->frames) {        // no gathered copies of the rows: tables in permutation order instead (hx_mb_tables_kernel)
-    s->obs_mb_all = nullptr; s->priv_mb_all = nullptr;
+  if (s->frames) {        // no permuted copy of the rollout: tables in permutation order (hx_mb_tables_kernel) + one minibatch of rows
+    s->mb_slots = 1;
+    rc |= palloc(s, &s->obs_mb_all, Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, Mm * cfg->priv_ld);
     rc |= palloc(s, &s->row_mb_all, TN * (2 * A + 4));
   } else {
     rc |= palloc(s, &s->obs_mb_all, (size_t)s->mb_slots * Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, (size_t)s->mb_slots * Mm * cfg->priv_ld);
@@ -1931,11 +1936,14 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   const int slot = (s->mb_slots > 1) ? mb : 0;
   RowTable rt_obs{}, rt_priv{};
   if (s->frames) {
-    // rows are read in place through the permutation-ordered tables of hx_ppo_update_begin: nothing to gather
-    s->obs_mb = s->s_obs; s->priv_mb = s->s_priv;
+    // The first-layer forward products read the minibatch's rows in place through the permutation-ordered tables of
+    // hx_ppo_update_begin and, as a side effect, leave the assembled rows in a one-minibatch workspace (obs_mb / priv_mb),
+    // from which the first-layer weight-gradient products read them with the plain loader: the gather is fused into the
+    // forward GEMM, there is no gather launch and no permuted copy of the rollout.
+    s->obs_mb = s->obs_mb_all; s->priv_mb = s->priv_mb_all;
     s->row_mb = s->row_mb_all + (size_t)mb * M * (2 * A + 4);
-    rt_obs = RowTable{s->mb_off_obs + (size_t)mb * M, s->mb_kz_obs + (size_t)mb * M, c.num_obs};
-    rt_priv = RowTable{s->mb_off_priv + (size_t)mb * M, s->mb_kz_priv + (size_t)mb * M, c.num_priv};
+    rt_obs = RowTable{s->mb_off_obs + (size_t)mb * M, s->mb_kz_obs + (size_t)mb * M, c.num_obs, s->obs_mb, c.obs_ld};
+    rt_priv = RowTable{s->mb_off_priv + (size_t)mb * M, s->mb_kz_priv + (size_t)mb * M, c.num_priv, s->priv_mb, c.priv_ld};
   } else {
     s->obs_mb = s->obs_mb_all + (size_t)slot * s->Mmax * c.obs_ld;
     s->priv_mb = s->priv_mb_all + (size_t)slot * s->Mmax * c.priv_ld;
@@ -1956,8 +1964,8 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   // previous one's tail; the critic joins before the loss head and forks again for the backward pass.
   hipStream_t sb = s->stream_b ? s->stream_b : st;
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
-  mlp_hidden_fwd(s, 0, s->obs_mb, c.obs_ld, M, s->act_a, st, false, s->frames ? &rt_obs : nullptr);
-  mlp_hidden_fwd(s, 1, s->priv_mb, c.priv_ld, M, s->act_c, sb, false, s->frames ? &rt_priv : nullptr);
+  mlp_hidden_fwd(s, 0, s->frames ? s->s_obs : s->obs_mb, c.obs_ld, M, s->act_a, st, false, s->frames ? &rt_obs : nullptr);
+  mlp_hidden_fwd(s, 1, s->frames ? s->s_priv : s->priv_mb, c.priv_ld, M, s->act_c, sb, false, s->frames ? &rt_priv : nullptr);
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   // heads: losses + gradient into the third hidden layer
   const int hw = c.actor_hidden[2], hwc = c.critic_hidden[2];
@@ -1992,8 +2000,7 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       float* slab = s->slab + s->slab_off[net * 4 + l];
       float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
       int bparts = 0;
-      const RowTable* rows = (s->frames && l == 0) ? (net ? &rt_priv : &rt_obs) : nullptr;
-      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l], rows);
+      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
       const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
       int k = rt.nseg;
       rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
