@@ -35,17 +35,23 @@ __device__ __forceinline__ void hx_step_book_row(const hx_step_book& b, int e) {
   if (*b.num_reset > 0) { tv = b.timeout[e]; b.timeout_visible[e] = tv; }
   if (b.rew_out) { b.rew_out[e] = b.rew[e]; b.done_out[e] = b.reset[e] ? 1 : 0; b.timeout_out[e] = tv; }
 }
-// once per step: recycle the other reset counter, fold the step's episode statistics (on_policy_runner.py:141-142)
-__device__ __forceinline__ void hx_step_book_global(const hx_step_book& b) {
-  *b.num_reset_next = 0;
+// once per step: recycle the other reset counter, fold the step's episode statistics (on_policy_runner.py:141-142).
+// Called by the lanes 0 .. HX_NUM_REWARDS-1 (at least) of ONE wave, lane = `j`: every lane folds one reward term, so the
+// chain of dependent memory operations is a few deep instead of 4 x 22 (the one-thread form was most of the stacking
+// kernel's duration).  Lock-step execution of a wave orders the flag reads of all lanes before lane 0's writes.
+__device__ __forceinline__ void hx_step_book_global(const hx_step_book& b, int j) {
   const int nr = *b.num_reset;
-  if (nr > 0) {
-    for (int r = 0; r < HX_NUM_REWARDS; ++r) { b.stat_last[r] = b.stat_sum[r] / (float)nr; b.stat_sum[r] = 0.f; }
-    b.stat_steps[1] = 1;
+  const int had = b.stat_steps[1];
+  const bool have = (nr > 0) || (had != 0);
+  if (j < HX_NUM_REWARDS) {
+    float last = b.stat_last[j];
+    if (nr > 0) { last = b.stat_sum[j] / (float)nr; b.stat_last[j] = last; b.stat_sum[j] = 0.f; }
+    if (have) b.stat_acc[j] += last;
   }
-  if (b.stat_steps[1]) {
-    for (int r = 0; r < HX_NUM_REWARDS; ++r) b.stat_acc[r] += b.stat_last[r];
-    b.stat_steps[0] += 1;
+  if (j == 0) {
+    *b.num_reset_next = 0;
+    if (nr > 0) b.stat_steps[1] = 1;
+    if (have) b.stat_steps[0] += 1;
   }
 }
 #endif

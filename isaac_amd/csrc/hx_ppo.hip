@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     // bookkeeping of the env step that produced these rows (it needs that launch's total reset count, hx_common.h)
     if (book_valid) {
       if (tid < FA_ROWS && row0 + tid < n) hx_step_book_row(book, row0 + tid);
-      if (blockIdx.x == 0 && tid == 64) hx_step_book_global(book);
+      if (blockIdx.x == 0 && tid >= 64 && tid < 128) hx_step_book_global(book, tid - 64);
     }
   } else {
     // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
@@ -1788,7 +1788,7 @@ extern "C" int hx_ppo_act(hx_ppo* s, const float* obs, const float* priv, const 
 __global__ void __launch_bounds__(256) hx_ppo_book_kernel(hx_step_book b) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < b.n) hx_step_book_row(b, e);
-  if (e == 0) hx_step_book_global(b);
+  if (blockIdx.x == 0 && threadIdx.x < 64) hx_step_book_global(b, (int)threadIdx.x);
 }
 
 // PPO.act for rollout slot s->step of a learner with single-frame storage: the rows of the slot are windows of the frame

@@ -246,20 +246,14 @@ __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
     unsigned char tv = a.timeout_visible[e];
     if (*a.num_reset > 0) { tv = a.timeout[e]; a.timeout_visible[e] = tv; }
     if (a.rew_out) { a.rew_out[e] = a.rew[e]; a.done_out[e] = rst ? 1 : 0; a.timeout_out[e] = tv; }
-    if (e == 0) {
-      *a.num_reset_next = 0;          // the other counter of the ping-pong pair: free until the next step
-      // extras["episode"] is rebuilt only on steps with a reset and the runner appends the (possibly stale) dict every
-      // step (on_policy_runner.py:141-142): per step the mean over that step's resets, then the mean over steps
-      const int nr = *a.num_reset;
-      if (nr > 0) {
-        for (int r = 0; r < HX_NUM_REWARDS; ++r) { a.stat_last[r] = a.stat_sum[r] / (float)nr; a.stat_sum[r] = 0.f; }
-        a.stat_steps[1] = 1;
-      }
-      if (a.stat_steps[1]) {
-        for (int r = 0; r < HX_NUM_REWARDS; ++r) a.stat_acc[r] += a.stat_last[r];
-        a.stat_steps[0] += 1;
-      }
-    }
+  }
+  if (e == 0 && threadIdx.x >= 64 && threadIdx.x < 128) {
+    // the other counter of the ping-pong pair is free until the next step; extras["episode"] is rebuilt only on steps with a
+    // reset and the runner appends the (possibly stale) dict every step (on_policy_runner.py:141-142): per step the mean over
+    // that step's resets, then the mean over steps -- one wave, one reward term per lane (hx_common.h)
+    const hx_step_book b{a.reset, a.timeout, a.timeout_visible, a.num_reset, a.num_reset_next, a.stat_sum, a.stat_last, a.stat_acc, a.stat_steps,
+                         a.rew, a.rew_out, a.done_out, a.timeout_out, a.n};
+    hx_step_book_global(b, (int)threadIdx.x - 64);
   }
 }
 
@@ -516,7 +510,7 @@ struct StepOut { float* obs; float* priv; float* rew; unsigned char* done; unsig
 __global__ void __launch_bounds__(256) hx_book_kernel(hx_step_book b) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < b.n) hx_step_book_row(b, e);
-  if (e == 0) hx_step_book_global(b);
+  if (blockIdx.x == 0 && threadIdx.x < 64) hx_step_book_global(b, (int)threadIdx.x);
 }
 static int flush_book(hx_sim* s) {
   if (!s->book_owed) return 0;
