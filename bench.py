@@ -69,6 +69,30 @@ def pmc_env_step(build_id):
     return _committed("*_env_step_pmc.json", build_id)
 
 
+def host_cpus():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box hands a job a
+    share of its host, e.g. 16 of 256 logical cores: an OpenMP team sized by os.cpu_count() would spend its time in barriers
+    waiting for descheduled threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = int(f.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_rows=61440):
     """CPU baseline on this box's host cores, kind = "port" (SURVEY.md 8d ii: the build's own host-compiled restatement):
       * env step = the HOST build of the product's own single-source kernel text (oracle/host/hx_host.cpp: hx_math.h + hx_dyn.h +
@@ -122,20 +146,19 @@ def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_ro
         "t_upd = (time.perf_counter() - t0) / (N * T)\n"
         "print(json.dumps(dict(t_act=t_act, t_upd_row=t_upd, threads=int(lib().hxl_num_threads()))))\n")
 
+    ncpu = host_cpus()
+
     def run(code, threads, **extra):
-        env = dict(os.environ, **extra)
-        if threads:
-            env["OMP_NUM_THREADS"] = str(threads)
-        else:
-            env.pop("OMP_NUM_THREADS", None)
-        out = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True, timeout=900)
+        env = dict(os.environ, OMP_WAIT_POLICY="passive", **extra)
+        env["OMP_NUM_THREADS"] = str(threads if threads else ncpu)          # "all cores" = all this job may use (host_cpus)
+        out = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True, timeout=240)
         if out.returncode != 0:
             raise RuntimeError(out.stderr[-600:])
         return json.loads(out.stdout.strip().splitlines()[-1])
 
-    full, ten = run(env_code, None), run(env_code, 10)
+    full, ten = run(env_code, None), run(env_code, min(10, ncpu))
     # numpy's BLAS pool is kept to one thread here: its spinning workers would fight the OpenMP team of the compiled learner
-    lf, lt = run(learner_code, None, OPENBLAS_NUM_THREADS="1"), run(learner_code, 10, OPENBLAS_NUM_THREADS="1")
+    lf, lt = run(learner_code, None, OPENBLAS_NUM_THREADS="1"), run(learner_code, min(10, ncpu), OPENBLAS_NUM_THREADS="1")
     n = sample_envs
     per_env_step = lambda env_s, l: env_s / n + l["t_act"] + 2 * l["t_upd_row"]          # 2 epochs over every stored row
     v_full, v_ten = 1.0 / per_env_step(full["s_per_step"], lf), 1.0 / per_env_step(ten["s_per_step"], lt)
@@ -145,9 +168,9 @@ def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_ro
                       f"{1e3 * full['s_per_step']:.1f} ms per step with {full['threads']} OpenMP threads, {1e3 * ten['s_per_step']:.1f} ms with 10; "
                       f"learner = compiled host restatement (AVX2 GEMM + numpy loss head), {T} policy steps at {N} rows + one minibatch step on {N * T} rows, "
                       f"scaled to 2 epochs: {1e6 * lf['t_act']:.2f} + 2 x {1e6 * lf['t_upd_row']:.2f} us per env-step with {lf['threads']} threads; "
-                      f"host has {os.cpu_count()} logical cores",
+                      f"this job may use {ncpu} of the host's {os.cpu_count()} logical cores (affinity / cgroup quota)",
             "env_only_env_steps_per_s": n / full["s_per_step"], "learner_only_env_steps_per_s": learner_only(lf),
-            "omp10": {"value": v_ten, "env_only_env_steps_per_s": n / ten["s_per_step"], "learner_only_env_steps_per_s": learner_only(lt), "cores": 10},
+            "omp10": {"value": v_ten, "env_only_env_steps_per_s": n / ten["s_per_step"], "learner_only_env_steps_per_s": learner_only(lt), "cores": min(10, ncpu)},
             "reference_learner_8_cores_env_steps_per_s": 18.1e3}
 
 
