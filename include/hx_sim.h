@@ -129,6 +129,10 @@ typedef struct hx_sim_cfg {
    * num_position_iterations, num_velocity_iterations and bounce_threshold_velocity (restitution is 0) have no counterpart:
    * nothing here iterates.  DESIGN.md 4. */
   float max_depenetration_velocity, contact_offset, rest_offset;
+  /* 1: the robot's links collide with each other (asset.self_collisions = 0 in the reference's bit-filter convention,
+   * humanoid_config.py:66).  Built for humanoid_ppo: knee-knee and foot-foot sphere pairs (isaac_amd/csrc/hx_dyn.h ModelXBot);
+   * the hector configs switch self-collision off (hector_config.py:37) and their models carry no pairs. */
+  int32_t self_collisions;
 } hx_sim_cfg;
 
 typedef struct hx_sim hx_sim;

@@ -59,6 +59,7 @@ class SimCfg(C.Structure):
         ("limit_k", C.c_float), ("limit_d", C.c_float), ("terrain_mu", C.c_float),
         ("env_id_offset", C.c_int32), ("num_dof", C.c_int32),
         ("max_depenetration_velocity", C.c_float), ("contact_offset", C.c_float), ("rest_offset", C.c_float),
+        ("self_collisions", C.c_int32),
     ]
 
 

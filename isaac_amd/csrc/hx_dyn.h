@@ -24,8 +24,15 @@
 #include "hx_model_data_xbot.h"
 
 // ---- the robots of the family: generated tables (tools/compile_urdf.py) + what the task glue needs to know about them
+// Self-collision (asset.self_collisions = 0, humanoid_config.py:66; hector's configs disable it): the two legs of a biped can
+// only meet foot against foot and knee against knee, so a model lists NSELF side-local bodies that carry one sphere each --
+// SELF_AT_SHAPE: centred on the body's collision shape (its bounding-sphere centre) or on the body origin (the joint) -- and
+// body k of the left side collides with body k of the right side.  PhysX collides the links' convex hulls pairwise; the
+// spheres are this model's proxy for the pairs that can touch.
 struct ModelHector : HXM_Hector {
   static constexpr bool ARMS = false, XBOT = false;
+  static constexpr int NSELF = 0;
+  static constexpr int SELF_BODY[1] = {0}; static constexpr bool SELF_AT_SHAPE[1] = {false}; static constexpr float SELF_RADIUS[1] = {0.f};
   static constexpr int KNEE = 3, FOOT = 4;       // side-local bodies named by asset.knee_name / foot_name (hector_config.py:31-32)
   HXD static const float* side_table() { return HXM_SIDE; }
   HXD static const float* base_table() { return HXM_BASE; }
@@ -33,6 +40,8 @@ struct ModelHector : HXM_Hector {
 };
 struct ModelFull : HXM_Full {             // hector with arms (task hector_full): leg bodies 0-4, arm bodies 5-8 per side
   static constexpr bool ARMS = true, XBOT = false;
+  static constexpr int NSELF = 0;
+  static constexpr int SELF_BODY[1] = {0}; static constexpr bool SELF_AT_SHAPE[1] = {false}; static constexpr float SELF_RADIUS[1] = {0.f};
   static constexpr int KNEE = 3, FOOT = 4;
   HXD static const float* side_table() { return HXF_SIDE; }
   HXD static const float* base_table() { return HXF_BASE; }
@@ -41,6 +50,10 @@ struct ModelFull : HXM_Full {             // hector with arms (task hector_full)
 struct ModelXBot : HXM_XBot {             // XBot-L (task humanoid_ppo): roll, yaw, pitch, knee, ankle pitch, ankle roll
   static constexpr bool ARMS = false, XBOT = true;
   static constexpr int KNEE = 3, FOOT = 5;       // 'knee' / 'ankle_roll' (humanoid_config.py:64-65)
+  // knee against knee: 6 cm spheres on the knee joints (origin of knee_link); foot against foot: 5 cm spheres (half the sole's
+  // width) on the centre of the ankle_roll_link hull
+  static constexpr int NSELF = 2;
+  static constexpr int SELF_BODY[2] = {3, 5}; static constexpr bool SELF_AT_SHAPE[2] = {false, true}; static constexpr float SELF_RADIUS[2] = {0.06f, 0.05f};
   HXD static const float* side_table() { return HXX_SIDE; }
   HXD static const float* base_table() { return HXX_BASE; }
   static constexpr float MASS0 = HXX_MASS0;
@@ -73,6 +86,7 @@ struct DynParams {
                           // outside, the damper acts on the part of its approach speed that would carry it through the surface
                           // within this substep (vn + gap / dt < 0) -- the penalty form of PhysX's speculative contact
   float roff;             // rest_offset: distance at which shapes come to rest (added to the penetration)
+  int self_on;            // 1: the model's self-collision pairs are active (asset.self_collisions = 0)
   int tflags;             // ablation switches of the trimesh walls (hx_sim_set_terrain_options): 1 = cliff cells keep their
                           // ramp (no flattening), 2 = no sideways wall contact
   const float* patch;     // LDS, [HX_PATCH][HX_PATCH] row-major (row = x index), or nullptr
@@ -427,10 +441,59 @@ template <class M> struct SideWork {
   uint32_t touched;                              // contact-buffer slots that hold contact terms this substep (wave-uniform)
 };
 
-// ---- upward half of a substep for one side: kinematics, the contact phase, articulated inertias leaf -> root;
-// hands (accI, accP) = the side's contribution to the base system.  target = PD position target per joint.
+// world position and velocity of a side's self-collision sphere centres (what the two sides exchange)
+template <class M> struct SelfProbeT { V3 c[M::NSELF > 0 ? M::NSELF : 1], v[M::NSELF > 0 ? M::NSELF : 1]; };
+template <class M> HXD void self_probe(const SideConst<M>& C, const ContactBuf& cb, SelfProbeT<M>& out) {
+  using MI = ModelInfo<M>;
+  static_for<(M::NSELF > 0 ? M::NSELF : 0)>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value, B = M::SELF_BODY[Q], SL = MI::slot(B);
+    static_assert(SL >= 0, "a self-collision body must carry a collision shape (its state is parked in the contact buffer)");
+    const M3 Rb = cb.rot_of(SL);
+    const V3 rc = M::SELF_AT_SHAPE[Q] ? ld3(C.shape(B)) : mk(0.f, 0.f, 0.f);
+    const V3 vw = mk(cb.at(SL, HX_CB_V), cb.at(SL, HX_CB_V + 1), cb.at(SL, HX_CB_V + 2)), vv = mk(cb.at(SL, HX_CB_V + 3), cb.at(SL, HX_CB_V + 4), cb.at(SL, HX_CB_V + 5));
+    out.c[Q] = mk(cb.at(SL, HX_CB_P), cb.at(SL, HX_CB_P + 1), cb.at(SL, HX_CB_P + 2)) + mul(Rb, rc);
+    out.v[Q] = mul(Rb, vv + cross(vw, rc));
+  });
+}
+// Sphere-sphere contact of this side's self-collision bodies with the other side's: the same normal law as the ground contact
+// (capped spring on the overlap, damper on the closing speed, onset inside the contact offset), no friction; the other body's
+// velocity enters explicitly, this body's own linearly-implicitly.  Every lane of the side holds the same values: no lane sums.
 template <class M>
-HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb, const float* target, SI& accI, SV& accP) {
+HXD void self_contact(SideWork<M>& W, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb, const SelfProbeT<M>& own, const SelfProbeT<M>& oth) {
+  using MI = ModelInfo<M>;
+  static_for<(M::NSELF > 0 ? M::NSELF : 0)>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value, B = M::SELF_BODY[Q], SL = MI::slot(B);
+    const V3 d = own.c[Q] - oth.c[Q];
+    const float dist = sqrtf(dot(d, d));
+    const V3 n = (1.0f / fmaxf(dist, 1e-6f)) * d;               // from the other body to this one
+    const float c_n = P.dn + P.kn * P.dt;
+    const float pen = 2.0f * M::SELF_RADIUS[Q] - dist + P.roff;
+    const float vn = dot(own.v[Q] - oth.v[Q], n);
+    const float spring = P.kn * fmaxf(pen, 0.f);
+    const float fn0 = ((P.vdep > 0.f) ? fminf(spring, c_n * P.vdep) : spring) - c_n * (vn + fmaxf(-pen, 0.f) * P.inv_dt);
+    const bool act = (pen > -P.coff) && (fn0 > 0.f);
+    if (!hx_any(act)) return;
+    const float on = act ? 1.f : 0.f;
+    const M3 Rb = cb.rot_of(SL);
+    const V3 rc = M::SELF_AT_SHAPE[Q] ? ld3(C.shape(B)) : mk(0.f, 0.f, 0.f);
+    const V3 nb = mulT(Rb, n), f = (on * fn0) * nb, m = cross(rc, nb), fw = cross(rc, f);
+    const float beta = on * P.dt * c_n;
+    const bool accumulate = (W.touched >> SL) & 1u;
+    auto acc = [&](int field, float val) { float& dd = cb.at(SL, field); dd = accumulate ? dd + val : val; };
+    acc(HX_CB_F, fw.x); acc(HX_CB_F + 1, fw.y); acc(HX_CB_F + 2, fw.z); acc(HX_CB_F + 3, f.x); acc(HX_CB_F + 4, f.y); acc(HX_CB_F + 5, f.z);
+    acc(HX_CB_A, beta * m.x * m.x); acc(HX_CB_A + 1, beta * m.x * m.y); acc(HX_CB_A + 2, beta * m.x * m.z);
+    acc(HX_CB_A + 3, beta * m.y * m.y); acc(HX_CB_A + 4, beta * m.y * m.z); acc(HX_CB_A + 5, beta * m.z * m.z);
+    const float mm[3] = {m.x, m.y, m.z}, nn[3] = {nb.x, nb.y, nb.z};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) acc(HX_CB_H + 3 * i + j, beta * mm[i] * nn[j]);
+    acc(HX_CB_M, beta * nb.x * nb.x); acc(HX_CB_M + 1, beta * nb.x * nb.y); acc(HX_CB_M + 2, beta * nb.x * nb.z);
+    acc(HX_CB_M + 3, beta * nb.y * nb.y); acc(HX_CB_M + 4, beta * nb.y * nb.z); acc(HX_CB_M + 5, beta * nb.z * nb.z);
+    W.touched |= (1u << SL);
+  });
+}
+
+// ---- upward half of a substep for one side, first part: kinematics and the ground-contact phase
+template <class M>
+HXD void side_kin(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb) {
   using MI = ModelInfo<M>;
   W.R0 = quat_to_mat(S.quat);
   W.v0.w = mulT(W.R0, S.angvel); W.v0.v = mulT(W.R0, S.linvel);
@@ -481,6 +544,13 @@ HXD void side_up(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, cons
     W.touched = touched;
   }
   HX_T(P.prof, 3);
+}
+
+// ---- second part: articulated inertias leaf -> root; hands (accI, accP) = the side's contribution to the base system.
+// target = PD position target per joint.
+template <class M>
+HXD void side_art(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, const SideConst<M>& C, const ContactBuf& cb, const float* target, SI& accI, SV& accP) {
+  using MI = ModelInfo<M>;
   // ---- pass 2: articulated inertias, leaf -> root of every chain
   accI = si0(); accP = sv0();
   static_for<M::NCH>([&](auto cc) {
@@ -660,7 +730,16 @@ __device__ __forceinline__ void dyn_substep(DynStateT<M>& S, const DynParams& P,
                      float* tau_out, bool want_forces, SideForcesT<M>& F) {
   SideWork<M> W;
   SI accI; SV accP;
-  side_up<M>(W, S, P, C, cb, target, accI, accP);
+  side_kin<M>(W, S, P, C, cb);
+  if constexpr (M::NSELF > 0) {
+    if (P.self_on) {                     // uniform
+      SelfProbeT<M> own, oth;
+      self_probe<M>(C, cb, own);
+      for (int q = 0; q < M::NSELF; ++q) { oth.c[q] = hx_xchg(own.c[q]); oth.v[q] = hx_xchg(own.v[q]); }
+      self_contact<M>(W, P, C, cb, own, oth);
+    }
+  }
+  side_art<M>(W, S, P, C, cb, target, accI, accP);
   for (int i = 0; i < 9; ++i) {
     accI.A.m[i] += hx_xchg(accI.A.m[i]);
     accI.H.m[i] += hx_xchg(accI.H.m[i]);
@@ -687,8 +766,18 @@ HXD void dyn_substep_pair(DynStateT<M>& SL, DynStateT<M>& SR, const DynParams& P
   SI aI, bI; SV aP, bP;
   float bufL[ModelInfo<M>::NSLOT * HX_CB_FIELDS], bufR[ModelInfo<M>::NSLOT * HX_CB_FIELDS];
   ContactBuf cbL, cbR; cbL.base = bufL; cbL.stride = 1; cbR.base = bufR; cbR.stride = 1;
-  side_up<M>(WL, SL, P, CL, cbL, targetL, aI, aP);
-  side_up<M>(WR, SR, P, CR, cbR, targetR, bI, bP);
+  side_kin<M>(WL, SL, P, CL, cbL);
+  side_kin<M>(WR, SR, P, CR, cbR);
+  if constexpr (M::NSELF > 0) {
+    if (P.self_on) {
+      SelfProbeT<M> pl, pr;
+      self_probe<M>(CL, cbL, pl); self_probe<M>(CR, cbR, pr);
+      self_contact<M>(WL, P, CL, cbL, pl, pr);
+      self_contact<M>(WR, P, CR, cbR, pr, pl);
+    }
+  }
+  side_art<M>(WL, SL, P, CL, cbL, targetL, aI, aP);
+  side_art<M>(WR, SR, P, CR, cbR, targetR, bI, bP);
   siadd(aI, bI); aP = aP + bP;
   const SV a0 = base_solve<M>(CL, WL.v0, mass_scale, aI, aP);
   side_down<M>(WL, SL, P, CL, cbL, a0, want_forces, FL);

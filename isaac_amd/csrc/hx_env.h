@@ -724,7 +724,7 @@ inline void terrain_pool_build(const float* h, int rows, int cols, float wall, f
 HXD DynParams dyn_params(const hx_sim_cfg& cfg, float friction) {
   DynParams P;
   P.dt = cfg.sim_dt; P.inv_dt = 1.0f / cfg.sim_dt; P.gz = cfg.gravity_z;
-  P.vdep = cfg.max_depenetration_velocity; P.coff = cfg.contact_offset; P.roff = cfg.rest_offset; P.tflags = 0; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
+  P.vdep = cfg.max_depenetration_velocity; P.coff = cfg.contact_offset; P.roff = cfg.rest_offset; P.tflags = 0; P.self_on = cfg.self_collisions; P.kn = cfg.contact_kn; P.dn = cfg.contact_dn; P.veps = cfg.friction_veps;
   P.lim_k = cfg.limit_k; P.lim_d = cfg.limit_d; P.mu = 0.5f * (cfg.terrain_mu + friction);
   P.patch = nullptr; P.pool = nullptr; P.poolw = nullptr; P.prof = nullptr; P.pt0 = 0; P.ptstep = 1; P.px0 = 0.f; P.py0 = 0.f; P.inv_hs = 0.f; P.wall = 0.f;
   return P;

@@ -224,6 +224,7 @@ class HectorFreeEnv(VecEnv):
         # sim.physx of the config as far as the contact model has a place for it (include/hx_sim.h): hector_config.py:113-117
         px = cfg.sim.physx
         c.max_depenetration_velocity, c.contact_offset, c.rest_offset = float(px.max_depenetration_velocity), float(px.contact_offset), float(px.rest_offset)
+        c.self_collisions = int(getattr(cfg.asset, "self_collisions", 1) == 0)      # the reference's bit filter: 0 = enabled
         for k, v in PHYS.items():      # model constants without a config counterpart; studies may also override the three above
             setattr(c, k, v)
         c.terrain_mu = cfg.terrain.static_friction

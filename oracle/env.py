@@ -227,6 +227,8 @@ class HectorEnvOracle:
         m0 = model["bodies"][0]["mass"]
         self.phys = P.HectorPhysics(n, base_mass_added=np.asarray(base_mass, np.float64) - m0,
                                     shape_friction=shape_friction, dtype=phys_dtype, terrain=terrain, model=model)
+        if T.name == "humanoid_ppo":                        # asset.self_collisions = 0 (humanoid_config.py:66)
+            self.phys.enable_self_collision()
         self.state = P.State(n, phys_dtype, T.ndof)
         if start_xy is not None:
             # actor creation pose (legged_robot.py:653-655): origin + U[-1,1]^2, z of the origin; the first

@@ -172,12 +172,36 @@ class HectorPhysics:
             self.I[i, :, 3:, :3] = m[:, None, None] * np.swapaxes(cx, -1, -2)
             self.I[i, :, 3:, 3:] = m[:, None, None] * np.eye(3, dtype=dtype)
         self.contacts = [(c["body"], np.array(c["points"], dtype)) for c in self.model["contacts"]]
+        # self-collision sphere pairs (left body, right body, centre in the left / right body frame, radius): set by
+        # enable_self_collision(); empty = the links do not collide with each other (hector_config.py:37)
+        self.self_pairs = []
         # outputs of the last substep
         self.contact_force = np.zeros((n, self.nb, 3), dtype)
         self.ndof = self.nb - 1
         self.tau = np.zeros((n, self.ndof), dtype)
 
     # ------------------------------------------------------------------ kinematics
+    def enable_self_collision(self):
+        """asset.self_collisions = 0 (humanoid_config.py:66).  The product's proxy for the link pairs of a biped that can touch
+        (isaac_amd/csrc/hx_dyn.h ModelXBot): knee against knee -- 6 cm spheres on the knee joints -- and foot against foot -- 5 cm
+        spheres on the centre of the ankle_roll hull's bounding box.  Only the XBot-L model carries pairs."""
+        names = [b["name"] for b in self.model["bodies"]]
+        nl = (self.nb - 1) // 2
+        by_body = {}
+        for c in self.model["contacts"]:
+            by_body.setdefault(c["body"], []).extend(c["points"])
+
+        def bbox_centre(body):
+            pts = np.array(by_body[body], self.dtype)
+            return (pts.min(0) + pts.max(0)) / 2
+        self.self_pairs = []
+        self.self_contact_count = 0           # active (robot, pair side, substep) triples so far: fixtures assert that it is not zero
+        for local, at_shape, radius in ((3, False, 0.06), (5, True, 0.05)):
+            bl, br = 1 + local, 1 + nl + local
+            cl = bbox_centre(bl) if at_shape else np.zeros(3, self.dtype)
+            cr = bbox_centre(br) if at_shape else np.zeros(3, self.dtype)
+            self.self_pairs.append((bl, br, cl, cr, radius))
+
     def kinematics(self, s):
         """Returns per body: R (body->world) [nb,N,3,3], p (world) [nb,N,3], Xup (parent->body 6x6),
         v (spatial velocity, body coords) [nb,N,6]."""
@@ -290,6 +314,32 @@ class HectorPhysics:
                 f0[body] += np.einsum("nij,nj->ni", XcT, fvec)
                 Bm[body] += XcT @ K @ Xc
                 point_rec.append((body, Xc, K, fvec, Rb))
+
+        # ---- self-collision sphere pairs: the ground contact's normal law without friction; each body sees the other one's
+        # velocity explicitly and its own linearly-implicitly
+        for bl, br, cl, cr, radius in self.self_pairs:
+            cw = {b: p[b] + np.einsum("nij,j->ni", R[b], c) for b, c in ((bl, cl), (br, cr))}
+            vw = {b: np.einsum("nij,nj->ni", R[b], v[b][:, 3:] + np.cross(v[b][:, :3], c)) for b, c in ((bl, cl), (br, cr))}
+            for own, oth, rc in ((bl, br, cl), (br, bl, cr)):
+                d = cw[own] - cw[oth]
+                dist = np.sqrt(np.einsum("ni,ni->n", d, d))
+                nrm = d / np.maximum(dist, 1e-6)[:, None]
+                pen = 2.0 * radius - dist + REST_OFFSET
+                vn = np.einsum("ni,ni->n", vw[own] - vw[oth], nrm)
+                spring = CONTACT_KN * np.maximum(pen, 0.0)
+                if MAX_DEPEN_VEL > 0:
+                    spring = np.minimum(spring, c_n * MAX_DEPEN_VEL)
+                fn0 = spring - c_n * (vn + np.maximum(-pen, 0.0) / dt)
+                act = (pen > -CONTACT_OFFSET) & (fn0 > 0)
+                self.self_contact_count += int(act.sum())
+                nrm_b = np.einsum("nji,nj->ni", R[own], nrm)
+                fvec = np.where(act[:, None], fn0[:, None] * nrm_b, 0.0)
+                K = np.where(act[:, None, None], dt * c_n * nrm_b[:, :, None] * nrm_b[:, None, :], 0.0)
+                Xc = np.concatenate([np.broadcast_to(-skew(rc), (n, 3, 3)), np.broadcast_to(np.eye(3, dtype=dtp), (n, 3, 3))], -1)
+                XcT = np.swapaxes(Xc, -1, -2)
+                f0[own] += np.einsum("nij,nj->ni", XcT, fvec)
+                Bm[own] += XcT @ K @ Xc
+                point_rec.append((own, Xc, K, fvec, R[own]))
 
         # ---- bias forces: RNEA with zero generalized acceleration, gravity as base acceleration
         g_b = np.zeros((n, 6), dtp)

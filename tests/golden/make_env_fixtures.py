@@ -252,6 +252,9 @@ def generate(name, n_envs, n_steps, seed, action_std, ep_len_init=None, step_cou
             res["terrain_curriculum"] = np.array(int(curriculum))
             res["terrain_level_stat"] = np.array(float(env.extras["episode"]["terrain_level"])) if "episode" in env.extras and "terrain_level" in env.extras["episode"] else np.array(np.nan)
         path = os.path.join(HERE, name + ".npz")
+        if getattr(gym.phys, "self_pairs", None):
+            res["self_contact_count"] = np.int64(gym.phys.self_contact_count)
+            print(name, "self-collision: %d active (robot, pair side, substep) triples" % gym.phys.self_contact_count)
         np.savez_compressed(path, **res)
         print(name, "steps", n_steps, "resets", int(res["reset"].sum()), "timeouts", int(res["timeout"].sum()),
               "torque checks", gym.torque_checks, "size %.0f KB" % (os.path.getsize(path) / 1024),

@@ -164,6 +164,7 @@ class Gym:
         self._pending_friction = float(f.item() if hasattr(f, "item") else f)
 
     def create_actor(self, env, asset, pose, name, group, filt, seg):
+        self.self_collision_filter = filt          # asset.self_collisions (legged_robot.py:656): 0 = links collide with each other
         self.shape_friction.append(getattr(self, "_pending_friction", 1.0))
         self.start_pos.append([pose.p.x, pose.p.y, pose.p.z])
         self.base_mass.append(self.model["bodies"][0]["mass"])
@@ -189,6 +190,8 @@ class Gym:
         m0 = self.model["bodies"][0]["mass"]
         self.phys = _phys.HectorPhysics(n, base_mass_added=np.array(self.base_mass) - m0,
                                         shape_friction=np.array(self.shape_friction), terrain=self.terrain_hf, model=self.model)
+        if getattr(self, "self_collision_filter", 1) == 0 and self.nd == 12:      # only the XBot-L model carries self-collision pairs
+            self.phys.enable_self_collision()
         self.state = _phys.State(n, ndof=self.nd)
         self.state.root_pos[:] = np.array(self.start_pos)
         self.root_t = torch.zeros(n, 13)

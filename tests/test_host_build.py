@@ -64,6 +64,34 @@ def test_host_build_replays_reference_fixture(name, steps):
     env.close()
 
 
+def test_self_collision_pairs_are_exercised_by_fixture_h():
+    """humanoid_ppo keeps self-collision on (asset.self_collisions = 0, humanoid_config.py:66): fixture H holds robots whose knees /
+    feet touch (the generator counted the active pair contacts), and the same replay with the pairs switched off must leave the
+    tight tier at those steps -- i.e. the test above really checks the pair contact, not its absence."""
+    from isaac_amd.envs.configs import XBotLCfg
+    from oracle.host import HostEnv
+    fx = np.load(os.path.join(GOLD, "env_rollout_h.npz"))
+    assert int(fx["self_contact_count"]) > 100
+    n, _, seed, sc0, noise = (int(x) for x in fx["meta"])
+    worst = {}
+    for flag in (0, 1):
+        cfg = XBotLCfg(); cfg.env.num_envs = n; cfg.noise.add_noise = bool(noise); cfg.terrain.mesh_type = "plane"
+        cfg.asset.self_collisions = flag
+        env = HostEnv(cfg, creation=_creation(fx), init_pack=fx["packs"][0], task="humanoid_ppo")
+        env.episode_length_buf = fx["ep_len_init"].astype(np.int32)
+        env.set_step_counter(sc0)
+        w = 0.0
+        for t in range(80):
+            if t > 0:
+                env.set_state(fx["root"][t - 1], fx["q"][t - 1], fx["qd"][t - 1])
+            obs, priv, rew, reset = env.step(fx["actions"][t], fx["packs"][t + 1])
+            w = max(w, float(np.abs(env.contact_forces - fx["contact"][t]).max()))
+        worst[flag] = w
+        env.close()
+    print("worst contact-force error vs fixture H: pairs on %.3g N, pairs off %.3g N" % (worst[0], worst[1]))
+    assert worst[0] < 1.0 and worst[1] > 10.0, worst
+
+
 def test_host_build_free_run_stays_close():
     fx = np.load(os.path.join(GOLD, "env_rollout_a.npz"))
     env, n, sc0 = _env_from_fixture(fx)
