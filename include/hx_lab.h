@@ -14,11 +14,13 @@ extern "C" {
 /* HIP-event timing of the learner's GEMM launches on the learner's stream, ONE row per kernel symbol, named exactly as
  * rocprofv3 prints it (e.g. "hx_gemm_kernel<128, 128, 16, false, false, 2, true, false, false>"), so a row here and a row of
  * `rocprofv3 --kernel-trace --stats` are the same launches.  hx_ppo_prof_begin(p, NULL) brackets every symbol;
- * (p, symbol) only that one (an event pair costs ~1 us of GPU time per bracketed launch).  The deferred critic's launches
+ * (p, symbol) only that one.  An event pair is not free: the kernel trace shows ~7 us of idle stream on either side of a
+ * bracketed launch and none between unbracketed ones (profiles/r03_z), 0.6 ms per iteration when every launch of the dominant
+ * symbol carries one -- so a benchmark brackets a uniform SAMPLE of the launches in its timed region (sample_every).  The deferred critic's launches
  * on the background stream are never bracketed (they overlap the rollout's kernels).  hx_ppo_prof_end stops and returns
  * the rows with at least one launch. */
 typedef struct hx_prof_row { char symbol[128]; double ms; int64_t launches; double flops; } hx_prof_row;
-int hx_ppo_prof_begin(hx_ppo* p, const char* only_symbol /*nullable*/);
+int hx_ppo_prof_begin(hx_ppo* p, const char* only_symbol /*nullable*/, int sample_every /*<= 1: every launch; n: a uniform sample, every n-th launch of the selected symbols*/);
 int hx_ppo_prof_end(hx_ppo* p, hx_prof_row* rows_h, int max_rows, int* n_rows);
 
 /* unit-test hook: one GEMM of the given mode (0/3 fwd bias+ELU 128/64-row tile, 1/4 dgrad * elu', 2 wgrad single

@@ -387,11 +387,11 @@ class PPO:
     def load_rng_state(self, act_counter, perm_counter):
         capi.check(self._L.hx_ppo_set_rng_state(self._h, int(act_counter), int(perm_counter)), "set_rng_state")
 
-    def prof_begin(self, only=None):
+    def prof_begin(self, only=None, sample_every=1):
         """Bracket the learner's GEMM launches with HIP events on its stream (include/hx_lab.h).  only: a kernel symbol as
-        returned by prof_end -- the rocprofv3 name, template arguments included -- to bracket just that symbol (each event
-        pair costs about a microsecond of GPU time, 1.5 % of an iteration when every GEMM launch carries one)."""
-        capi.check(self._L.hx_ppo_prof_begin(self._h, None if only is None else only.encode()), "prof_begin")
+        returned by prof_end -- the rocprofv3 name, template arguments included -- to bracket just that symbol; sample_every = n brackets
+        every n-th of those launches only (an event pair idles the stream for ~7 us on either side of the launch)."""
+        capi.check(self._L.hx_ppo_prof_begin(self._h, None if only is None else only.encode(), int(sample_every)), "prof_begin")
 
     def prof_end(self):
         rows = (capi.ProfRow * 64)()

@@ -438,6 +438,52 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
   hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB>(g, logical, lds);
 }
 
+// Several products in ONE launch.
+// (1) The weight gradients of a minibatch (split-K).  Launched layer by layer, every product gets its own full wave of
+// workgroups: the 256 x 128 layer (2 tiles) is cut into 240 slices of 256 rows and every layer leaves ~50 MB of partial slabs
+// whatever its size.  In a group all members are cut into the SAME number of slices, chosen so that the tiles of all members
+// together fill the chip once (hector: five layers, 44 tiles x 17 slices): every workgroup runs the same long K loop, the
+// slabs shrink with the slice count, and four launch boundaries go.
+// (2) The same layer of the actor and of the critic (forward and input-gradient products): two short launches of 1.25 rounds
+// of workgroups each become one of 2.5, with one ramp and one tail.
+// `first[i]` = first logical block of member i; a member's blocks are numbered like a launch of its own (hx_gemm_tile's
+// `logical`: split-major for split-K).  Block -> work map: blocks b, b + 8, ... share an XCD and its L2; XCD x walks its
+// contiguous share of member 0's tiles, then its share of member 1's, ... -- every XCD gets the same mix of long and short
+// tiles, and neighbours in an XCD's queue re-use the same A rows.  Grid = 8 x the longest queue; the few surplus blocks exit.
+#define HX_GROUP_MAX 6
+struct GemmGroup { GemmArgs p[HX_GROUP_MAX]; int first[HX_GROUP_MAX + 1]; int n; };
+static inline int hx_group_grid(const GemmGroup& G) {
+  int longest = 0;
+  for (int x = 0; x < 8; ++x) {
+    int len = 0;
+    for (int m = 0; m < G.n; ++m) { const int T = G.first[m + 1] - G.first[m]; len += T / 8 + (x < T % 8 ? 1 : 0); }
+    if (len > longest) longest = len;
+  }
+  return 8 * longest;
+}
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
+__global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_group_kernel(GemmGroup G) {
+  __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
+  const int xcd = blockIdx.x & 7;
+  int idx = blockIdx.x >> 3, pi = -1, logical = 0;
+#pragma unroll
+  for (int m = 0; m < HX_GROUP_MAX; ++m) {
+    if (m < G.n && pi < 0) {
+      const int T = G.first[m + 1] - G.first[m], q = T >> 3, r = T & 7;
+      const int cnt = q + (xcd < r ? 1 : 0);
+      if (idx < cnt) { pi = m; logical = xcd * q + min(xcd, r) + idx; }
+      else idx -= cnt;
+    }
+  }
+  if (pi < 0) return;
+  // member of this block: a chain of uniform selects (indexing the kernel-argument array with a run-time value would move
+  // the whole struct to scratch)
+  GemmArgs g = G.p[0];
+#pragma unroll
+  for (int i = 1; i < HX_GROUP_MAX; ++i) if (pi == i) g = G.p[i];
+  hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL>(g, logical, lds);
+}
+
 // The same product with a SMALL fixed grid whose workgroups walk the tiles (tile t, t + grid, ...).  Not faster per se
 // (profiles/README.md "persistent tiles"); its use is the background critic of the rollout: 128 workgroups settle on 128
 // CUs, one wave per SIMD there, and leave the other CUs entirely free -- an env-step wave needs a whole SIMD's registers,

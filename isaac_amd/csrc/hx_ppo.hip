@@ -910,6 +910,8 @@ struct hx_ppo {
   float* apack[3]; bool apack_dirty;   // actor hidden-layer weights in MFMA fragment order for the fused rollout actor; stale after any parameter change
   int critic_late;               // 1: a deferred critic batch starts after the actor kernel of its step instead of beside it
   int fwd_in_tile;               // rows per tile of the input layers' forward products at update size (HX_FWD_IN_TILE, 128 or 64)
+  int wgrad_group;               // 1: the weight-gradient products of a minibatch go out as grouped split-K launches (HX_WGRAD_GROUP)
+  int gemm_pair;                 // 1: layer l of the actor and of the critic share one launch in the update (HX_GEMM_PAIR)
   int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
@@ -928,6 +930,7 @@ struct hx_ppo {
   int64_t adam_t;
   int mb_done, mb_total;
   int prof_only;                 // -1: every symbol's launches are bracketed with HIP events while profiling; else only this registry id
+  int prof_every = 1; long prof_seen = 0;      // bracket every prof_every-th launch of the selected symbols
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
@@ -1108,6 +1111,75 @@ static int gemm_wgrad(hx_ppo* s, hipStream_t st, const float* dZ, int out, const
   if (Mrows % HX_BK_UPD == 0) launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true>(s, g, st);
   else launch_gemm<128, 128, HX_BK_UPD, false, false, EPI_SLAB>(s, g, st);
   return splits;
+}
+
+// ---- the weight-gradient products of one minibatch as grouped split-K launches (hx_gemm_group_kernel)
+struct WgradJob { const float* dZ; int out; const float* X; int ldx, in_ld; float* slab; float* bias_slab; int alloc_splits; int seg; };
+static int wgrad_target_blocks() {
+  static int target_blocks = -1;
+  if (target_blocks < 0) {
+    const char* e = getenv("HX_WGRAD_BLOCKS");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    target_blocks = e ? atoi(e) : 3 * cus;
+  }
+  return target_blocks;
+}
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL> static int gemm_group_kid() {
+  static const int id = prof_register("hx_gemm_group_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(BKT) + ", " + tf(AK) + ", " +
+                                      tf(BK_) + ", " + std::to_string(EPI) + ", " + tf(KFULL) + ">");
+  return id;
+}
+// members filled except tiles_m / tiles_n / first[]
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL> static void launch_gemm_group(hx_ppo* s, GemmGroup& G, hipStream_t st) {
+  int blocks = 0; double flops = 0.0;
+  for (int i = 0; i < G.n; ++i) {
+    GemmArgs& g = G.p[i];
+    g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
+    G.first[i] = blocks; blocks += g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
+    flops += 2.0 * g.M * g.N * g.K;
+  }
+  G.first[G.n] = blocks;
+  ProfScope ps(s, gemm_group_kid<BM, BN, BKT, AK, BK_, EPI, KFULL>(), st, flops);
+  hipLaunchKernelGGL((hx_gemm_group_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(hx_group_grid(G)), dim3(256), 0, st, G);
+}
+// Cuts `jobs` into groups whose tiles fill one wave of workgroups (>= 95 % of the 3-per-CU slots at a whole number of
+// slices per tile), peeling off the largest product while they do not, and launches each group.  splits_out[i] /
+// bias_parts_out[i] = slices written to job i's slab / partial rows written to its bias slab.
+static void gemm_wgrad_groups(hx_ppo* s, hipStream_t st, const WgradJob* jobs, int njobs, int Mrows, int* splits_out, int* bias_parts_out) {
+  const int target = wgrad_target_blocks();
+  int order[16], tiles[16];
+  for (int i = 0; i < njobs; ++i) { order[i] = i; tiles[i] = ((jobs[i].out + 127) / 128) * ((jobs[i].in_ld + 127) / 128); }
+  for (int i = 1; i < njobs; ++i)          // largest first (stable)
+    for (int j = i; j > 0 && tiles[order[j]] > tiles[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+  int pos = 0;
+  while (pos < njobs) {
+    int cnt = njobs - pos, T = 0;
+    for (int i = pos; i < njobs; ++i) T += tiles[order[i]];
+    while (cnt > 1) {          // the whole rest as one group, or without its largest members until it fits and fills
+      const int S = target / T;
+      if (cnt <= HX_GROUP_MAX && S >= 1 && (double)S * T >= 0.95 * target) break;
+      // peel: the group becomes the single largest product
+      cnt = 1; T = tiles[order[pos]];
+    }
+    int splits = target / T; if (splits < 1) splits = 1;
+    int max_splits = Mrows / HX_WGRAD_MIN_CHUNK; if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    for (int i = pos; i < pos + cnt; ++i) if (splits > jobs[order[i]].alloc_splits) splits = jobs[order[i]].alloc_splits;
+    const int kchunk = rup((Mrows + splits - 1) / splits, 32);
+    splits = (Mrows + kchunk - 1) / kchunk;
+    GemmGroup G{};
+    G.n = cnt;
+    for (int i = 0; i < cnt; ++i) {
+      const WgradJob& j = jobs[order[pos + i]];
+      GemmArgs& g = G.p[i];
+      g.A = j.dZ; g.lda = j.out; g.B = j.X; g.ldb = j.ldx; g.C = j.slab; g.ldc = j.in_ld; g.M = j.out; g.N = j.in_ld; g.K = Mrows;
+      g.splits = splits; g.kchunk = kchunk; g.dbias = j.bias_slab; g.db_parts = (j.in_ld + 127) / 128;
+      splits_out[order[pos + i]] = splits; bias_parts_out[order[pos + i]] = splits * g.db_parts;
+    }
+    launch_gemm_group<128, 128, HX_BK_UPD, false, false, EPI_SLAB, true>(s, G, st);
+    pos += cnt;
+  }
 }
 
 extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
@@ -1368,6 +1440,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (s->bg_tile != 0 && s->bg_tile != 64 && s->bg_tile != 128) { hx_set_error("HX_BG_TILE: 0 (by batch size), 64 or 128"); return -2; }
   if (int rc = hx_knob_int("HX_CRITIC_CHUNK", HX_CRITIC_CHUNK, 1, 4096, &s->critic_chunk)) return rc;
   if (int rc = hx_knob_int("HX_WGRAD_BLOCKS", 0, 1, 65536, &knob_wgrad)) return rc;
+  if (int rc = hx_knob_int("HX_WGRAD_GROUP", 1, 0, 1, &s->wgrad_group)) return rc;
+  if (int rc = hx_knob_int("HX_GEMM_PAIR", 1, 0, 1, &s->gemm_pair)) return rc;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
   {
@@ -1675,6 +1749,43 @@ static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, f
   gemm_fwd(s, st, act[1], L[2].in_ld, s->params + L[2].w, L[2].in_ld, s->params + L[2].b, act[2], M, L[2].out, L[2].in_ld, bg, fp32_only);
 }
 
+// Layers [l0, 3) of BOTH networks at update size, layer l of the actor and of the critic in one launch (hx_gemm_group_kernel):
+// fp32, plain rows.  X of a network is only read when l0 == 0.
+static void mlp_hidden_fwd_pair(hx_ppo* s, int l0, const float* Xa, int ldxa, const float* Xc, int ldxc, int M, hipStream_t st) {
+  for (int l = l0; l < 3; ++l) {
+    GemmGroup G{};
+    G.n = 2;
+    bool kfull = true;
+    for (int net = 0; net < 2; ++net) {
+      const Layer& Ly = s->L[net * 4 + l];
+      float** act = net ? s->act_c : s->act_a;
+      GemmArgs& g = G.p[1 - net];      // the critic's (longer K) tiles first in every XCD's queue, so that the launch's tail is short tiles
+      g.A = (l == 0) ? (net ? Xc : Xa) : act[l - 1]; g.lda = (l == 0) ? (net ? ldxc : ldxa) : Ly.in_ld;
+      g.B = s->params + Ly.w; g.ldb = Ly.in_ld; g.C = act[l]; g.ldc = Ly.out; g.M = M; g.N = Ly.out; g.K = Ly.in_ld; g.bias = s->params + Ly.b;
+      kfull = kfull && (g.K % 32 == 0);
+    }
+    if (kfull) launch_gemm_group<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, G, st);
+    else launch_gemm_group<128, 128, 16, true, true, EPI_BIAS_ELU, false>(s, G, st);
+  }
+}
+// input gradients of layer l of both networks in one launch: dZ[l-1] = (dZ[l] W[l]) * elu'(act[l-1])
+static void gemm_dgrad_pair(hx_ppo* s, int l, int M, hipStream_t st) {
+  GemmGroup G{};
+  G.n = 2;
+  bool kfull = true;
+  for (int net = 0; net < 2; ++net) {
+    const Layer& Ly = s->L[net * 4 + l];
+    float** act = net ? s->act_c : s->act_a;
+    float** dz = net ? s->dz_c : s->dz_a;
+    GemmArgs& g = G.p[net];
+    g.A = dz[l]; g.lda = Ly.out; g.B = s->params + Ly.w; g.ldb = Ly.in_ld; g.C = dz[l - 1]; g.ldc = Ly.in_ld; g.M = M; g.N = Ly.in_ld; g.K = Ly.out;
+    g.H = act[l - 1]; g.ldh = Ly.in_ld;
+    kfull = kfull && (g.K % 32 == 0);
+  }
+  if (kfull) launch_gemm_group<64, 128, 32, true, false, EPI_ELU_GRAD, true>(s, G, st);
+  else launch_gemm_group<64, 128, 32, true, false, EPI_ELU_GRAD, false>(s, G, st);
+}
+
 // values for rollout slots [crit_done, upto) on the second stream: one critic forward over (slots * N) rows
 static int critic_flush(hx_ppo* s, int upto) {
   const int N = s->cfg.num_envs;
@@ -1964,8 +2075,19 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   // previous one's tail; the critic joins before the loss head and forks again for the backward pass.
   hipStream_t sb = s->stream_b ? s->stream_b : st;
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
-  mlp_hidden_fwd(s, 0, s->frames ? s->s_obs : s->obs_mb, c.obs_ld, M, s->act_a, st, false, s->frames ? &rt_obs : nullptr);
-  mlp_hidden_fwd(s, 1, s->frames ? s->s_priv : s->priv_mb, c.priv_ld, M, s->act_c, sb, false, s->frames ? &rt_priv : nullptr);
+  // HX_GEMM_PAIR: layer l of both networks in one launch (fp32, update size, one stream); with single-frame storage the two
+  // gathered input layers keep their own launches
+  const bool pair = s->gemm_pair && !s->bf16 && !s->stream_b && M >= 16384 && s->fwd_in_tile == 128;
+  if (pair && !s->frames) mlp_hidden_fwd_pair(s, 0, s->obs_mb, c.obs_ld, s->priv_mb, c.priv_ld, M, st);
+  else if (pair) {
+    const Layer* La = s->L; const Layer* Lc = s->L + 4;
+    gemm_fwd(s, st, s->s_obs, c.obs_ld, s->params + La[0].w, La[0].in_ld, s->params + La[0].b, s->act_a[0], M, La[0].out, La[0].in_ld, false, false, &rt_obs);
+    gemm_fwd(s, st, s->s_priv, c.priv_ld, s->params + Lc[0].w, Lc[0].in_ld, s->params + Lc[0].b, s->act_c[0], M, Lc[0].out, Lc[0].in_ld, false, false, &rt_priv);
+    mlp_hidden_fwd_pair(s, 1, nullptr, 0, nullptr, 0, M, st);
+  } else {
+    mlp_hidden_fwd(s, 0, s->frames ? s->s_obs : s->obs_mb, c.obs_ld, M, s->act_a, st, false, s->frames ? &rt_obs : nullptr);
+    mlp_hidden_fwd(s, 1, s->frames ? s->s_priv : s->priv_mb, c.priv_ld, M, s->act_c, sb, false, s->frames ? &rt_priv : nullptr);
+  }
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   // heads: losses + gradient into the third hidden layer
   const int hw = c.actor_hidden[2], hwc = c.critic_hidden[2];
@@ -1986,32 +2108,43 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   hipLaunchKernelGGL(hx_head_scatter_kernel, dim3((s->head_slab_w + 255) / 256), dim3(256), 0, st, s->head_slab2, hchunks, s->head_slab_w, s->grads, hs, (float)M);
   // backward through the hidden layers of both networks; partial slabs go to per-layer regions, one reduce at the end
   ReduceTable rt{}; unsigned blocks = 0;
+  // Grouped weight gradients (hx_gemm_group_kernel): the input-gradient chain of both networks first, then every layer's
+  // dZ^T X in one or two launches.  fp32 path with whole K tiles only; HX_WGRAD_GROUP=0 launches layer by layer as before.
+  const bool grouped = s->wgrad_group && !s->bf16 && (M % HX_BK_UPD == 0);
+  WgradJob jobs[8]; int njobs = 0;
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
-  for (int net = 0; net < 2; ++net) {
-    const hipStream_t st = net ? sb : s->stream;          // shadows: the critic's backward chain on the second stream
-    const Layer* L = s->L + net * 4;
-    float** act = net ? s->act_c : s->act_a;
-    float** dz = net ? s->dz_c : s->dz_a;
-    const float* X = net ? s->priv_mb : s->obs_mb;
-    const int ldx = net ? c.priv_ld : c.obs_ld;
-    for (int l = 2; l >= 0; --l) {
+  for (int l = 2; l >= 0; --l) {
+    for (int net = 0; net < 2; ++net) {
+      const hipStream_t st = net ? sb : s->stream;          // shadows: the critic's backward chain on the second stream
+      const Layer* L = s->L + net * 4;
+      float** act = net ? s->act_c : s->act_a;
+      float** dz = net ? s->dz_c : s->dz_a;
+      const float* X = net ? s->priv_mb : s->obs_mb;
+      const int ldx = net ? c.priv_ld : c.obs_ld;
       const float* in = (l == 0) ? X : act[l - 1];
       const int ld_in = (l == 0) ? ldx : L[l].in_ld;
       float* slab = s->slab + s->slab_off[net * 4 + l];
       float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
-      int bparts = 0;
-      const int splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
+      int bparts = 0, splits = 0;
+      if (grouped) jobs[njobs++] = WgradJob{dz[l], L[l].out, in, ld_in, L[l].in_ld, slab, bslab, s->slab_splits[net * 4 + l], rt.nseg};
+      else splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
       const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
       int k = rt.nseg;
       rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
       k = ++rt.nseg;
       rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = bparts; rt.block0[k] = blocks; blocks += (L[l].out + 1023) / 1024;
       ++rt.nseg;
-      if (l > 0) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out, s->wT[net * 4 + l]);
+      if (l > 0 && !pair) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out, s->wT[net * 4 + l]);
     }
+    if (l > 0 && pair) gemm_dgrad_pair(s, l, M, st);
   }
   rt.block0[rt.nseg] = blocks;
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
+  if (grouped) {
+    int sp[8], bp[8];
+    gemm_wgrad_groups(s, st, jobs, njobs, M, sp, bp);
+    for (int i = 0; i < njobs; ++i) { rt.S[jobs[i].seg] = sp[i]; rt.S[jobs[i].seg + 1] = bp[i]; }
+  }
   hipLaunchKernelGGL(hx_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, rt);
   HX_CHECK(hipGetLastError());
   if (grad_buffer) *grad_buffer = s->grads;
@@ -2127,6 +2260,9 @@ extern "C" int hx_ppo_inference(hx_ppo* s, const float* obs, int rows, float* ou
 // kernels, so an event pair there measures contended time, not the kernel
 ProfScope::ProfScope(hx_ppo* s_, int kid, hipStream_t st_, double flops) : s(s_), st(st_), on(false) {
   if (!s || !s->prof || (s->prof_only >= 0 && s->prof_only != kid) || st == s->stream2) return;
+  // an event pair costs the stream ~7 us around the launch (kernel trace: 0 us between unbracketed launches): in the timed
+  // region of a benchmark only every prof_every-th launch of the selected symbol is bracketed -- a uniform sample
+  if (s->prof_every > 1 && (s->prof_seen++ % s->prof_every) != 0) return;
   while (s->ev_used + 2 > s->ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; s->ev.push_back(e); s->ev_kid.push_back(0); }
   if ((size_t)kid >= s->prof_flops.size()) { s->prof_flops.resize(kid + 1, 0.0); s->prof_launches.resize(kid + 1, 0); }
   (void)hipEventRecord(s->ev[s->ev_used], st);
@@ -2136,9 +2272,10 @@ ProfScope::ProfScope(hx_ppo* s_, int kid, hipStream_t st_, double flops) : s(s_)
 }
 ProfScope::~ProfScope() { if (on) { (void)hipEventRecord(s->ev[s->ev_used + 1], st); s->ev_used += 2; } }
 
-extern "C" int hx_ppo_prof_begin(hx_ppo* s, const char* only_symbol) {
+extern "C" int hx_ppo_prof_begin(hx_ppo* s, const char* only_symbol, int sample_every) {
   if (!s) { hx_set_error("hx_ppo_prof_begin: null learner"); return -2; }
   s->prof_only = -1;
+  s->prof_every = sample_every > 1 ? sample_every : 1; s->prof_seen = 0;
   if (only_symbol && *only_symbol) {
     const auto& names = prof_names();
     for (size_t i = 0; i < names.size(); ++i) if (names[i] == only_symbol) s->prof_only = (int)i;

@@ -221,3 +221,41 @@ def test_non_finite_gradient_skips_the_step(hxlib):
     for k in before:
         assert np.array_equal(before[k], after[k]) and np.isfinite(after[k]).all(), k
     alg.close()
+
+
+def test_grouped_launches_change_scheduling_only(hxlib, monkeypatch):
+    """The update's grouped launches (hx_gemm_group_kernel) at a size where they are active (N = 1024, T = 64: 4 minibatches
+    of 16 384 rows, 2 epochs).  HX_GEMM_PAIR only moves layer l of the actor and of the critic into one launch -- the same
+    tiles with the same k order -- so parameters and losses must be BIT-identical with and without it.  HX_WGRAD_GROUP cuts
+    the 16 384-row reduction of the weight gradients into other slices (one slice count per group instead of one per layer):
+    same sums in another association, so the eight Adam steps agree to fp32 round-off, not to the bit."""
+    seed, T, N = 41, 64, 1024
+    inp = rollout_inputs(seed, T, N)
+    perm = np.random.default_rng(1).permutation(T * N).astype(np.int32)
+
+    def run(env):
+        for k in ("HX_GEMM_PAIR", "HX_WGRAD_GROUP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _, ac, alg = _make(seed, T, N, 1e-4)
+        for t in range(T):
+            alg.act(inp["obs"][t], inp["priv"][t], eps=inp["eps"][t])
+            alg.process_env_step(inp["rewards"][t], inp["dones"][t].astype(np.uint8), {"time_outs": inp["time_outs"][t].astype(np.uint8)})
+        alg.compute_returns(inp["priv"][T])
+        losses = alg.update(perm=perm)
+        out = (losses, alg.learning_rate, ac.state_dict())
+        alg.close()
+        return out
+
+    base = run({})
+    unpaired = run({"HX_GEMM_PAIR": "0"})
+    assert base[0] == unpaired[0] and base[1] == unpaired[1]
+    for k in base[2]:
+        np.testing.assert_array_equal(base[2][k], unpaired[2][k], err_msg=k)
+    layerwise = run({"HX_WGRAD_GROUP": "0"})
+    assert abs(base[0][0] - layerwise[0][0]) < 1e-5 * max(1.0, abs(base[0][0])) and abs(base[0][1] - layerwise[0][1]) < 1e-5
+    assert base[1] == layerwise[1]
+    for k in base[2]:
+        d = np.abs(base[2][k] - layerwise[2][k])
+        assert d.max() < 2e-6 and np.mean(d > 2e-7) < 1e-2, (k, float(d.max()), float(np.mean(d > 2e-7)))
