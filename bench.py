@@ -373,7 +373,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": k["name"] + ("" if args.dtype == "f32" else " [bf16 operands]"), "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic if args.dtype == "f32" else None,
                                "traffic_detail": traffic_detail,
-                               "build_id": build_id, "launches": k["launches"], "launches_bracketed": f"every {sample_every}th launch of the symbol in the timed region ({per_iter} per iteration; the stride is coprime to that, so every shape sharing the symbol is sampled)" if sample_every > 1 else "all", "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
+                               "build_id": build_id, "launches": k["launches"], "launches_bracketed": f"1 launch in {sample_every} of the symbol in the timed region ({per_iter} launches per iteration; the stride is coprime to that, so every shape sharing the symbol is sampled)" if sample_every > 1 else "all", "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
                                "flop_per_launch": k["flops"] / max(1, k["launches"]),
                                "all_gemm_kernels": (prof_all or prof)["kernels"],
                                "all_gemm_kernels_from": "warm-up iterations (every launch on the learner's stream bracketed; the deferred critic's background launches overlap the rollout and are not)" if prof_all else "timed region",
