@@ -259,3 +259,37 @@ def test_grouped_launches_change_scheduling_only(hxlib, monkeypatch):
     for k in base[2]:
         d = np.abs(base[2][k] - layerwise[2][k])
         assert d.max() < 2e-6 and np.mean(d > 2e-7) < 1e-2, (k, float(d.max()), float(np.mean(d > 2e-7)))
+
+
+def test_launch_profiler_rows_and_sampling(hxlib):
+    """include/hx_lab.h: one row per kernel symbol, named as rocprofv3 prints it; selecting a symbol keeps only its launches;
+    sample_every = n brackets every n-th of them (what bench.py does in its timed region), and the flops of a row are those
+    of the bracketed launches -- so TFLOP/s of a sample is comparable with that of the full set."""
+    seed, T, N = 43, 16, 256
+    inp = rollout_inputs(seed, T, N)
+    perm = np.random.default_rng(1).permutation(T * N).astype(np.int32)
+    _, ac, alg = _make(seed, T, N, 1e-4)
+
+    def iteration():
+        for t in range(T):
+            alg.act(inp["obs"][t], inp["priv"][t], eps=inp["eps"][t])
+            alg.process_env_step(inp["rewards"][t], inp["dones"][t].astype(np.uint8), {"time_outs": inp["time_outs"][t].astype(np.uint8)})
+        alg.compute_returns(inp["priv"][T])
+        alg.update(perm=perm)
+
+    alg.prof_begin()
+    iteration()
+    full = {k["name"]: k for k in alg.prof_end()["kernels"]}
+    grouped = [n for n in full if n.startswith("hx_gemm_group_kernel<") and n.endswith(", 2, true>")]
+    assert len(grouped) == 1, sorted(full)                      # the weight-gradient groups: 2 epochs x 4 minibatches, >= 1 launch each
+    sym = grouped[0]
+    total = full[sym]["launches"]
+    assert total >= 8 and full[sym]["flops"] > 0 and full[sym]["ms"] > 0
+    alg.prof_begin(only=sym, sample_every=3)
+    iteration()
+    part = alg.prof_end()["kernels"]
+    assert [k["name"] for k in part] == [sym]
+    assert part[0]["launches"] == (total + 2) // 3                # launches 0, 3, 6, ... of the symbol
+    per_launch = full[sym]["flops"] / total
+    assert abs(part[0]["flops"] / part[0]["launches"] / per_launch - 1.0) < 0.35      # a sample of the same mix of launch shapes
+    alg.close()
