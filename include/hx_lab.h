@@ -12,10 +12,10 @@ extern "C" {
 #endif
 
 /* HIP-event timing of the learner's GEMM launches on the learner's stream, ONE row per kernel symbol, named exactly as
- * rocprofv3 prints it (e.g. "hx_gemm_kernel<128, 128, 16, false, false, 2, true, false, false>"), so a row here and a row of
- * `rocprofv3 --kernel-trace --stats` are the same launches.  hx_ppo_prof_begin(p, NULL) brackets every symbol;
- * (p, symbol) only that one.  An event pair is not free: the kernel trace shows ~7 us of idle stream on either side of a
- * bracketed launch and none between unbracketed ones (profiles/r03_z), 0.6 ms per iteration when every launch of the dominant
+ * rocprofv3 prints it (e.g. "hx_gemm_group_kernel<128, 128, 16, false, false, 2, true>"), so a row here and a row of
+ * `rocprofv3 --kernel-trace --stats` are the same launches.  hx_ppo_prof_begin(p, NULL, 1) brackets every symbol;
+ * (p, symbol, n) only that one, every n-th of its launches.  An event pair is not free: the kernel trace shows ~7 us of idle stream on either side of a
+ * bracketed launch and none between unbracketed ones (profiles/r03_p_grouped_launches.txt), 0.6 ms per iteration when every launch of the dominant
  * symbol carries one -- so a benchmark brackets a uniform SAMPLE of the launches in its timed region (sample_every).  The deferred critic's launches
  * on the background stream are never bracketed (they overlap the rollout's kernels).  hx_ppo_prof_end stops and returns
  * the rows with at least one launch. */

@@ -547,13 +547,16 @@ struct HeadArgs {
 };
 // dynamic LDS of the loss head: staged rows of the actor (and of the critic when stage_c), both head weights, per-row results
 static inline size_t head_lds_bytes(int hw, int hwc, int A, bool stage_c) {
-  return (size_t)(HEAD_ROWS * (hw + 1) + (stage_c ? HEAD_ROWS * (hwc + 1) : 0) + A * hw + hwc + HEAD_ROWS * (A + 1) +
+  return (size_t)(HEAD_ROWS * (hw + 8) + (stage_c ? HEAD_ROWS * (hwc + 8) : 0) + A * hw + hwc + HEAD_ROWS * (A + 1) +
                   HEAD_ROWS * (4 + A) + HEAD_ROWS) * sizeof(float);
 }
 template <int MA>   // register-array bound on the action count (16 for hector's 10, 32 otherwise): loops over MA are unrolled
 __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int hw = g.hw, hwc = g.hwc, A = g.A, hp = hw + 1, hpc = hwc + 1;
+  // staged rows are hw + 8 floats apart: 16-byte aligned for vector access, and the 8 rows x 8 k of a wave's dot-product step
+  // (lane = (row, part), k = part + 8 i) fall on 2 x 32 distinct banks; with hw + 1 and a contiguous k block per lane the four
+  // even parts of a row shared a bank (SQ_LDS_BANK_CONFLICT was 48 % of the kernel's LDS cycles)
+  const int hw = g.hw, hwc = g.hwc, A = g.A, hp = hw + 8, hpc = hwc + 8;
   float* sHa = sm;                       // [rows][hw+1]
   const bool stage_c = g.stage_c != 0;
   float* sHc = sHa + HEAD_ROWS * hp;     // [rows][hwc+1]   (empty when the critic is not staged)
@@ -572,15 +575,14 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
     float vp = 0.f;
     for (int k = 4 * (lane & 31); k < hmax; k += 128) {      // one loop for both nets: two loads in flight per trip
       if (k < hw) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3a + grow * hw + k);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sHa[r * hp + k + q] = ok ? x[q] : 0.f;
+        f32x4 x = *reinterpret_cast<const f32x4*>(g.h3a + grow * hw + k);
+        if (!ok) x = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sHa + r * hp + k) = x;
       }
       if (k < hwc) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3c + grow * hwc + k);
         if (stage_c) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sHc[r * hpc + k + q] = ok ? x[q] : 0.f;
+          *reinterpret_cast<f32x4*>(sHc + r * hpc + k) = ok ? x : (f32x4){0.f, 0.f, 0.f, 0.f};
         } else {
           const f32x4 w = *reinterpret_cast<const f32x4*>(g.W4c + k);
 #pragma unroll
@@ -597,26 +599,25 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
   for (int i = tid; i < hwc; i += 256) sWc[i] = g.W4c[i];
   __syncthreads();
   {
-    // 8 lanes per row: each lane owns hw/8 consecutive k of both dot products, 3 xor-shuffles reduce them,
+    // 8 lanes per row: lane `part` owns k = part, part + 8, ... of both dot products, 3 xor-shuffles reduce them,
     // lane 0 of the row finishes the loss terms
     const int r = tid >> 3, part = tid & 7, m = r0 + r;
-    const int per = hw / 8, perc = hwc / 8;
     float mu[MA];
 #pragma unroll
     for (int j = 0; j < MA; ++j) mu[j] = 0.f;
     float v = 0.f;
     if (hw == hwc && stage_c) {           // one pass over k for both nets (hector: 128 / 128)
-      for (int k = part * per; k < (part + 1) * per; ++k) {
+      for (int k = part; k < hw; k += 8) {
         const float x = sHa[r * hp + k];
         for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
         v = fmaf(sHc[r * hpc + k], sWc[k], v);
       }
     } else {
-      for (int k = part * per; k < (part + 1) * per; ++k) {
+      for (int k = part; k < hw; k += 8) {
         const float x = sHa[r * hp + k];
         for (int j = 0; j < A; ++j) mu[j] = fmaf(x, sW[j * hw + k], mu[j]);
       }
-      if (stage_c) { for (int k = part * perc; k < (part + 1) * perc; ++k) v = fmaf(sHc[r * hpc + k], sWc[k], v); }
+      if (stage_c) { for (int k = part; k < hwc; k += 8) v = fmaf(sHc[r * hpc + k], sWc[k], v); }
       else v = (part == 0) ? sV[r] : 0.f;
     }
     for (int o = 4; o > 0; o >>= 1) {
@@ -705,8 +706,9 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
           for (int q = 0; q < 4; ++q) s[q] = fmaf(dj, w[q], s[q]);
         }
         f32x4 o;
+        const f32x4 ha4 = *reinterpret_cast<const f32x4*>(sHa + r * hp + k);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const float ha = sHa[r * hp + k + q]; o[q] = s[q] * (ha > 0.f ? 1.f : ha + 1.f); }
+        for (int q = 0; q < 4; ++q) { const float ha = ha4[q]; o[q] = s[q] * (ha > 0.f ? 1.f : ha + 1.f); }
         *reinterpret_cast<f32x4*>(g.dz3a + (size_t)(r0 + r) * hw + k) = o;
       }
       if (k < hwc) {
@@ -714,8 +716,7 @@ __global__ void __launch_bounds__(256) hx_loss_head_kernel(HeadArgs g) {
         f32x4 o;
         f32x4 hc4;
         if (stage_c) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hc4[q] = sHc[r * hpc + k + q];
+          hc4 = *reinterpret_cast<const f32x4*>(sHc + r * hpc + k);
         } else {
           hc4 = *reinterpret_cast<const f32x4*>(g.h3c + (size_t)(r0 + r) * hwc + k);
         }
