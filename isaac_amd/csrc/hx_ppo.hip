@@ -806,6 +806,205 @@ __global__ void __launch_bounds__(256) hx_reduce_all_kernel(ReduceTable t) {
   *reinterpret_cast<f32x4*>(t.dst[seg] + i) = s;
 }
 
+// The same loss head on the matrix cores (v_mfma_f32_16x16x4_f32), for heads of up to 16 actions over staged rows (the hector
+// shape: 10 actions, 128 / 128 wide): the VALU version spends its time on LDS-fed dot products at the one-wave issue rate
+// (2.7 k vector + 0.8 k LDS instructions per wave, half of a wave's life waiting; profiles/r03_h2).  Four products per 32 rows:
+//   mu  [32 x 16]  = H3a [32 x hw] W4^T            waves 0, 1 (16 rows each), K = hw
+//   v   [32 x 1]   = H3c [32 x hwc] w4c            waves 2, 3, K = hwc (B operand: w4c in column 0)
+//   dZ3a[32 x hw]  = dmu [32 x 16] W4 [16 x hw]    all waves: one row tile x hw / 32 column tiles each, K = 16
+//   dW4 [16 x hw]  = dmu^T [16 x 32] H3a [32 x hw] all waves: hw / 64 column tiles each, K = 32
+// Operand layout of the instruction (as in the fused actor): lane l holds A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15];
+// four MFMAs consume k = 4 (l >> 4) + i of a 16-deep block; C: col = l & 15, row = 4 (l >> 4) + reg.  Same outputs and the same
+// slab layout as hx_loss_head_kernel; sums over k, actions and rows are associated differently (fp32 round-off).
+#define HEADM_NA 16
+static inline size_t head_mfma_lds_bytes(int hw, int hwc) {
+  return (size_t)(HEAD_ROWS * (hw + 4) + HEAD_ROWS * (hwc + 4) + HEADM_NA * (hw + 4) + hwc + HEAD_ROWS * HEADM_NA * 2 + HEAD_ROWS + HEAD_ROWS * 4) * sizeof(float);
+}
+__global__ void __launch_bounds__(256) hx_loss_head_mfma_kernel(HeadArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int hw = g.hw, hwc = g.hwc, A = g.A, lda = hw + 4, ldc = hwc + 4;
+  float* sHa = sm;                              // [32][hw + 4]
+  float* sHc = sHa + HEAD_ROWS * lda;           // [32][hwc + 4]
+  float* sW = sHc + HEAD_ROWS * ldc;            // [16][hw + 4]   W4, rows >= A zero
+  float* sWc = sW + HEADM_NA * lda;             // [hwc]
+  float* sD = sWc + hwc;                        // [32][16]  dmu (0 for actions >= A and rows >= M)
+  float* sS = sD + HEAD_ROWS * HEADM_NA;        // [32][16]  dsigma terms
+  float* sDv = sS + HEAD_ROWS * HEADM_NA;       // [32]      dv
+  float* sL = sDv + HEAD_ROWS;                  // [32][4]   kl, value loss, surrogate, entropy
+  const int r0 = blockIdx.x * HEAD_ROWS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, q4 = lane >> 4;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- stage the rows (half a wave per row, 16 bytes per lane) and the two head weights
+  {
+    const int hmax = hw > hwc ? hw : hwc;
+    for (int r = 2 * wave + (lane >> 5); r < HEAD_ROWS; r += 8) {
+      const bool ok = (r0 + r) < g.M;
+      const size_t grow = (size_t)(ok ? r0 + r : 0);
+      for (int k = 4 * (lane & 31); k < hmax; k += 128) {
+        if (k < hw) { const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3a + grow * hw + k); *reinterpret_cast<f32x4*>(sHa + r * lda + k) = ok ? x : zero4; }
+        if (k < hwc) { const f32x4 x = *reinterpret_cast<const f32x4*>(g.h3c + grow * hwc + k); *reinterpret_cast<f32x4*>(sHc + r * ldc + k) = ok ? x : zero4; }
+      }
+    }
+    for (int i = tid; i < HEADM_NA * (hw >> 2); i += 256) {
+      const int j = i / (hw >> 2), k = (i % (hw >> 2)) << 2;
+      *reinterpret_cast<f32x4*>(sW + j * lda + k) = (j < A) ? *reinterpret_cast<const f32x4*>(g.W4 + (size_t)j * hw + k) : zero4;
+    }
+    for (int i = tid; i < hwc; i += 256) sWc[i] = g.W4c[i];
+  }
+  __syncthreads();
+  // ---- forward heads + loss terms
+  if (wave < 2) {
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    const float* ap = sHa + (16 * wave + l15) * lda + 4 * q4;
+    const float* bp = sW + l15 * lda + 4 * q4;
+    for (int kb = 0; kb < hw; kb += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kb), b = *reinterpret_cast<const f32x4*>(bp + kb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+    }
+    const int j = l15;
+    const bool jv = j < A;
+    const float b4j = jv ? g.b4[j] : 0.f, sdj = jv ? g.stdp[j] : 1.f, soj = jv ? g.sigma_old[j] : 1.f;
+    const float invM = 1.0f / (float)g.M;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * wave + 4 * q4 + reg, m = r0 + r;
+      const bool rv = m < g.M;                                   // uniform over the 16 lanes of the row
+      const float* row = g.row_mb + (size_t)(rv ? m : 0) * (2 * A + 4);
+      float lp = 0.f, en = 0.f, kl = 0.f, d = 0.f, sgj = 1.f;
+      if (jv) {
+        const float mj = acc[reg] + b4j;
+        sgj = mj * 0.f + sdj;
+        d = row[j] - mj;
+        const float ls = logf(sgj);
+        lp = -(d * d) / (2.0f * sgj * sgj) - ls - LOG_SQRT_2PI;
+        en = 0.5f + LOG_SQRT_2PI + ls;
+        const float dm = row[A + j] - mj;
+        kl = logf(sgj / soj + 1.e-5f) + (soj * soj + dm * dm) / (2.0f * sgj * sgj) - 0.5f;
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { lp += __shfl_xor(lp, o); en += __shfl_xor(en, o); kl += __shfl_xor(kl, o); }
+      const float logp_old = row[2 * A + 2], adv = row[2 * A + 3];
+      const float ratio = expf(lp - logp_old);
+      const float lo = 1.0f - g.clip, hi = 1.0f + g.clip;
+      const float s = -adv * ratio, sc = -adv * fminf(fmaxf(ratio, lo), hi);
+      const float inr = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+      const float w = (s > sc) ? 1.f : ((s == sc) ? 0.5f + 0.5f * inr : inr);
+      const float dlogp = -adv * w * ratio * invM;
+      const bool on = rv && jv;
+      sD[r * HEADM_NA + j] = on ? dlogp * d / (sgj * sgj) : 0.f;
+      sS[r * HEADM_NA + j] = on ? dlogp * (d * d / (sgj * sgj * sgj) - 1.0f / sgj) - g.ecoef * invM / sgj : 0.f;
+      if (j == 0) { sL[r * 4 + 0] = rv ? kl : 0.f; sL[r * 4 + 2] = rv ? fmaxf(s, sc) : 0.f; sL[r * 4 + 3] = rv ? en : 0.f; }
+    }
+  } else {
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    const int rt = wave - 2;
+    const float* ap = sHc + (16 * rt + l15) * ldc + 4 * q4;
+    const float* bp = sWc + 4 * q4;
+    for (int kb = 0; kb < hwc; kb += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + kb);
+      f32x4 b = *reinterpret_cast<const f32x4*>(bp + kb);
+      if (l15 != 0) b = zero4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
+    }
+    if (l15 == 0) {
+      const float invM = 1.0f / (float)g.M, b4c = g.b4c[0];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * rt + 4 * q4 + reg, m = r0 + r;
+        float vl = 0.f, dvv = 0.f;
+        if (m < g.M) {
+          const float* row = g.row_mb + (size_t)m * (2 * A + 4);
+          const float v = acc[reg] + b4c, v_old = row[2 * A], ret = row[2 * A + 1];
+          float dv;
+          if (g.use_clipped_value_loss) {
+            const float vc = v_old + fminf(fmaxf(v - v_old, -g.clip), g.clip);
+            const float la = (v - ret) * (v - ret), lb = (vc - ret) * (vc - ret);
+            vl = fmaxf(la, lb);
+            const float inv = (fabsf(v - v_old) <= g.clip) ? 1.f : 0.f;
+            const float ga = 2.0f * (v - ret), gb = 2.0f * (vc - ret) * inv;
+            dv = (la > lb) ? ga : ((la == lb) ? 0.5f * ga + 0.5f * gb : gb);
+          } else {
+            vl = (ret - v) * (ret - v);
+            dv = 2.0f * (v - ret);
+          }
+          dvv = g.vcoef * dv * invM;
+        }
+        sDv[r] = dvv; sL[r * 4 + 1] = vl;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- dZ3a = (dmu W4) * elu'(h3a): wave = (row tile, half of the column tiles)
+  {
+    const int rt = wave & 1, nct = hw >> 4, c0 = (wave >> 1) * (nct >> 1);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(sD + (16 * rt + l15) * HEADM_NA + 4 * q4);
+    for (int ct = c0; ct < c0 + (nct >> 1); ++ct) {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      const int col = 16 * ct + l15;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], sW[(4 * q4 + i) * lda + col], acc, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = 16 * rt + 4 * q4 + reg;
+        if (r0 + r < g.M) { const float ha = sHa[r * lda + col]; g.dz3a[(size_t)(r0 + r) * hw + col] = acc[reg] * (ha > 0.f ? 1.f : ha + 1.f); }
+      }
+    }
+  }
+  // ---- dZ3c = dv w4c * elu'(h3c): half a wave per row, 16-byte stores
+  for (int r = 2 * wave + (lane >> 5); r < HEAD_ROWS; r += 8) {
+    if (r0 + r >= g.M) continue;
+    const float dv = sDv[r];
+    for (int k = 4 * (lane & 31); k < hwc; k += 128) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(sWc + k), hc4 = *reinterpret_cast<const f32x4*>(sHc + r * ldc + k);
+      f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = dv * w[q] * (hc4[q] > 0.f ? 1.f : hc4[q] + 1.f);
+      *reinterpret_cast<f32x4*>(g.dz3c + (size_t)(r0 + r) * hwc + k) = o;
+    }
+  }
+  // ---- partial parameter gradients of the two heads, summed over this workgroup's rows
+  float* slab = g.slab + (size_t)blockIdx.x * g.slab_w;
+  {
+    const int nct = hw >> 4, per = nct >> 2;              // dW4 = dmu^T H3a: column tiles split over the four waves
+    for (int ct = wave * per; ct < (wave + 1) * per; ++ct) {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      const int col = 16 * ct + l15;
+#pragma unroll
+      for (int kb = 0; kb < HEAD_ROWS; kb += 16)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = kb + 4 * q4 + i;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[r * HEADM_NA + l15], sHa[r * lda + col], acc, 0, 0, 0);
+        }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { const int j = 4 * q4 + reg; if (j < A) slab[j * hw + col] = acc[reg]; }
+    }
+  }
+  for (int k = tid; k < hwc; k += 256) {
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s = fmaf(sDv[r], sHc[r * ldc + k], s);
+    slab[A * hw + A + k] = s;
+  }
+  if (tid < A) {
+    float s = 0.f, d = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) { s += sD[r * HEADM_NA + tid]; d += sS[r * HEADM_NA + tid]; }
+    slab[A * hw + tid] = s;                      // db4
+    slab[A * hw + A + hwc + 1 + tid] = d;        // dstd
+  }
+  if (tid == 32) {
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s += sDv[r];
+    slab[A * hw + A + hwc] = s;                  // db4c
+  }
+  if (tid >= 64 && tid < 68) {
+    float s = 0.f;
+    for (int r = 0; r < HEAD_ROWS; ++r) s += sL[r * 4 + (tid - 64)];
+    slab[A * hw + A + hwc + 1 + A + (tid - 64)] = s;
+  }
+}
+
 // scatter the head slab sums into the flat gradient buffer + statistics
 struct HeadScatter { size_t w4, b4, w4c, b4c, stdo, stats; int A, hw, hwc; };
 __global__ void hx_head_scatter_kernel(const float* __restrict__ slab, int S, int slab_w, float* grads, HeadScatter o, float rows) {
@@ -913,6 +1112,7 @@ struct hx_ppo {
   int fwd_in_tile;               // rows per tile of the input layers' forward products at update size (HX_FWD_IN_TILE, 128 or 64)
   int wgrad_group;               // 1: the weight-gradient products of a minibatch go out as grouped split-K launches (HX_WGRAD_GROUP)
   int gemm_pair;                 // 1: layer l of the actor and of the critic share one launch in the update (HX_GEMM_PAIR)
+  int head_mfma;                 // 1: hector-shaped loss heads run on the matrix cores (HX_HEAD_MFMA)
   int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
@@ -1443,6 +1643,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_WGRAD_BLOCKS", 0, 1, 65536, &knob_wgrad)) return rc;
   if (int rc = hx_knob_int("HX_WGRAD_GROUP", 1, 0, 1, &s->wgrad_group)) return rc;
   if (int rc = hx_knob_int("HX_GEMM_PAIR", 1, 0, 1, &s->gemm_pair)) return rc;
+  if (int rc = hx_knob_int("HX_HEAD_MFMA", 1, 0, 1, &s->head_mfma)) return rc;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
   {
@@ -1604,6 +1805,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     if (head_lds > 64 * 1024) {      // a wide ACTOR last layer (the critic is then not staged); hector's 43 KB launch keeps the default
       HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HX_CHECK(hipFuncSetAttribute((const void*)hx_loss_head_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
   s->step = 0; s->adam_t = 0; s->mb_done = 0; s->mb_total = 0;
@@ -2101,7 +2303,10 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   h.dz3a = s->dz_a[2]; h.dz3c = s->dz_c[2]; h.slab = s->head_slab; h.slab_w = s->head_slab_w;
   h.stage_c = head_lds_bytes(hw, hwc, A, true) <= 64 * 1024;
   const size_t shm = head_lds_bytes(hw, hwc, A, h.stage_c != 0);
-  if (A <= 16) hipLaunchKernelGGL(hx_loss_head_kernel<16>, dim3(hblocks), dim3(256), shm, st, h);
+  // hector-shaped heads on the matrix cores (hx_loss_head_mfma_kernel); HX_HEAD_MFMA=0 keeps the VALU kernel
+  const bool head_mfma = s->head_mfma && A <= HEADM_NA && hw % 64 == 0 && hwc % 64 == 0 && head_mfma_lds_bytes(hw, hwc) <= 64 * 1024;
+  if (head_mfma) hipLaunchKernelGGL(hx_loss_head_mfma_kernel, dim3(hblocks), dim3(256), head_mfma_lds_bytes(hw, hwc), st, h);
+  else if (A <= 16) hipLaunchKernelGGL(hx_loss_head_kernel<16>, dim3(hblocks), dim3(256), shm, st, h);
   else hipLaunchKernelGGL(hx_loss_head_kernel<32>, dim3(hblocks), dim3(256), shm, st, h);
   HeadScatter hs{s->L[3].w, s->L[3].b, s->L[7].w, s->L[7].b, s->std_off, s->stats_off, A, hw, hwc};
   const int hchunk = 32, hchunks = (hblocks + hchunk - 1) / hchunk;

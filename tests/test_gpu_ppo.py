@@ -228,13 +228,13 @@ def test_grouped_launches_change_scheduling_only(hxlib, monkeypatch):
     of 16 384 rows, 2 epochs).  HX_GEMM_PAIR only moves layer l of the actor and of the critic into one launch -- the same
     tiles with the same k order -- so parameters and losses must be BIT-identical with and without it.  HX_WGRAD_GROUP cuts
     the 16 384-row reduction of the weight gradients into other slices (one slice count per group instead of one per layer):
-    same sums in another association, so the eight Adam steps agree to fp32 round-off, not to the bit."""
+    same sums in another association, so the eight Adam steps agree to fp32 round-off, not to the bit; HX_HEAD_MFMA likewise."""
     seed, T, N = 41, 64, 1024
     inp = rollout_inputs(seed, T, N)
     perm = np.random.default_rng(1).permutation(T * N).astype(np.int32)
 
     def run(env):
-        for k in ("HX_GEMM_PAIR", "HX_WGRAD_GROUP"):
+        for k in ("HX_GEMM_PAIR", "HX_WGRAD_GROUP", "HX_HEAD_MFMA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -253,12 +253,15 @@ def test_grouped_launches_change_scheduling_only(hxlib, monkeypatch):
     assert base[0] == unpaired[0] and base[1] == unpaired[1]
     for k in base[2]:
         np.testing.assert_array_equal(base[2][k], unpaired[2][k], err_msg=k)
-    layerwise = run({"HX_WGRAD_GROUP": "0"})
-    assert abs(base[0][0] - layerwise[0][0]) < 1e-5 * max(1.0, abs(base[0][0])) and abs(base[0][1] - layerwise[0][1]) < 1e-5
-    assert base[1] == layerwise[1]
-    for k in base[2]:
-        d = np.abs(base[2][k] - layerwise[2][k])
-        assert d.max() < 2e-6 and np.mean(d > 2e-7) < 1e-2, (k, float(d.max()), float(np.mean(d > 2e-7)))
+    # the same for the loss head on the matrix cores (hx_loss_head_mfma_kernel) against the VALU kernel it replaces for
+    # hector-shaped heads: the dot products, the sum over actions and the head's weight gradients are associated differently
+    for other in ({"HX_WGRAD_GROUP": "0"}, {"HX_HEAD_MFMA": "0"}):
+        alt = run(other)
+        assert abs(base[0][0] - alt[0][0]) < 1e-5 * max(1.0, abs(base[0][0])) and abs(base[0][1] - alt[0][1]) < 1e-5, other
+        assert base[1] == alt[1], other
+        for k in base[2]:
+            d = np.abs(base[2][k] - alt[2][k])
+            assert d.max() < 2e-6 and np.mean(d > 2e-7) < 1e-2, (other, k, float(d.max()), float(np.mean(d > 2e-7)))
 
 
 def test_launch_profiler_rows_and_sampling(hxlib):
