@@ -36,6 +36,10 @@ struct GemmArgs {
   float* dbias;             // EPI_SLAB: [splits * db_parts][M] partial column sums of A (bias gradient), nullable
   int db_parts;             // EPI_SLAB: the column-sum work of a (tile_m, split) is shared by the first db_parts tile_n blocks
   int tiles_m, tiles_n;
+  // POLL instantiations (the rollout's background critic): while *pause > 0 -- a foreground kernel that wants the CU's matrix
+  // pipes to itself is running (the fused actor counts its workgroups in and out) -- the waves sleep between K tiles instead
+  // of issuing.  The value is read one K tile ahead of its use (no wait on the critical path); the sleep is bounded.
+  const int* pause;
   // Gathered operand rows (single-frame observation storage): when the kernel is instantiated with GA (A, K-major)
   // the operand is not a matrix in memory but a table of row starts -- row r begins at  base + off[r]  (a float offset, 4-byte
   // aligned only: 15 consecutive 41-wide frames of one robot) and its elements  [0, kz[r])  and  [klim, ...)  read as zero
@@ -67,7 +71,15 @@ template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM> struct GemmLds {
 };
 
 // One output tile (`logical` = tile index, times the split for EPI_SLAB), start to finish, by the whole workgroup.
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL, bool GA = false, bool GB = false>
+__device__ __forceinline__ int hx_pause_load(const int* p) { return __builtin_nontemporal_load(p); }
+// sleeps while the flag read one K tile ago is up; returns a fresh request for the next check
+__device__ __forceinline__ void hx_pause_poll(const int* p, int& seen) {
+  if (seen < 0) return;                            // gave up once: this workgroup never waits again
+  int budget = 2048;                               // x (sleep 64 x 64 cycles + one L2 round trip) ~ 5 ms at most: never a hang
+  while (seen > 0 && budget > 0) { --budget; __builtin_amdgcn_s_sleep(64); seen = *reinterpret_cast<const volatile int*>(p); }
+  seen = (budget > 0) ? hx_pause_load(p) : -1;
+}
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL, bool GA = false, bool GB = false, bool POLL = false>
 __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logical, float* __restrict__ lds) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
@@ -292,8 +304,10 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
     if (nk > 1) load_tile(1);
     __syncthreads();
     read_frags(0, 0, f0);
+    int paused = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
+      if (POLL && g.pause != nullptr) hx_pause_poll(g.pause, paused);
       read_frags(cur, 1, f1);
       bias_grad(cur, kt);
       mfma_half(f0);
@@ -352,8 +366,10 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
     load_tile(0);
     store_tile(0);
     __syncthreads();
+    int paused = 0;
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = (kt + 1 < nk);
+      if (POLL && g.pause != nullptr) hx_pause_poll(g.pause, paused);
       if (more) load_tile(kt + 1);
       compute(kt & 1, kt);
       if (more) store_tile((kt + 1) & 1);
@@ -492,7 +508,7 @@ template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL =
 __global__ void __launch_bounds__(256) hx_gemm_persistent_kernel(GemmArgs g, int total_tiles) {
   __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
   for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB>(g, t, lds);
+    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB, true>(g, t, lds);
     __syncthreads();          // the next tile's first LDS stores must not overtake this tile's last fragment reads
   }
 }

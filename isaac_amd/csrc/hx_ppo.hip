@@ -277,8 +277,12 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
                                                              const float* __restrict__ W4, const float* __restrict__ b4,
                                                              const float* __restrict__ stdp, const float* __restrict__ eps, int A,
                                                              uint32_t k0, uint32_t k1, uint32_t step, uint32_t row_base,
-                                                             float* actions, float* mu_out, float* logp, FrameSrc fsrc, hx_step_book book, int book_valid) {
+                                                             float* actions, float* mu_out, float* logp, FrameSrc fsrc, hx_step_book book, int book_valid,
+                                                             int* pause) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
+  // the background critic's persistent workgroups sleep while this count is up (hx_gemm.h GemmArgs::pause): the actor is on
+  // the rollout's critical path and shares half the CUs with them
+  if (pause != nullptr && threadIdx.x == 0) atomicAdd(pause, 1);
   const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
   float* Xs = fsm;
   float* H1 = Xs + FA_ROWS * ldx;
@@ -365,6 +369,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     for (int j = 0; j < A; ++j) lp += sTerm[tid * MAX_A + j];
     logp[row0 + tid] = lp;
   }
+  if (pause != nullptr && tid == 0) atomicSub(pause, 1);
 }
 
 // critic head only (bootstrap value of compute_returns, ppo.py:116)
@@ -1113,6 +1118,7 @@ struct hx_ppo {
   int wgrad_group;               // 1: the weight-gradient products of a minibatch go out as grouped split-K launches (HX_WGRAD_GROUP)
   int gemm_pair;                 // 1: layer l of the actor and of the critic share one launch in the update (HX_GEMM_PAIR)
   int head_mfma;                 // 1: hector-shaped loss heads run on the matrix cores (HX_HEAD_MFMA)
+  int* pause_flag = nullptr;     // count of fused-actor workgroups in flight; the background critic sleeps while it is up (HX_CRITIC_YIELD)
   int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
@@ -1220,6 +1226,7 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
                      bool background = false, bool fp32_only = false, const RowTable* rt = nullptr) {
   GemmArgs g{};
   g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = N; g.M = M; g.N = N; g.K = K; g.bias = b;
+  if (background) g.pause = s->pause_flag;      // persistent launches only look at it
   if (rt) {
     // gathered A rows: BK16 tiles (K = 616 / 1052 are not multiples of 32), 128-row tiles at update size, 64-row below, the
     // persistent half-chip grid for the rollout's background critic
@@ -1644,6 +1651,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_WGRAD_GROUP", 1, 0, 1, &s->wgrad_group)) return rc;
   if (int rc = hx_knob_int("HX_GEMM_PAIR", 1, 0, 1, &s->gemm_pair)) return rc;
   if (int rc = hx_knob_int("HX_HEAD_MFMA", 1, 0, 1, &s->head_mfma)) return rc;
+  int knob_yield = 1;
+  if (int rc = hx_knob_int("HX_CRITIC_YIELD", 1, 0, 1, &knob_yield)) return rc;
   if (stream) { s->stream = (hipStream_t)stream; s->own_stream = false; }
   else { HX_CHECK(hipStreamCreate(&s->stream)); s->own_stream = true; }
   {
@@ -1774,6 +1783,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   rc |= palloc(s, &s->head_slab, (size_t)s->head_blocks_max * s->head_slab_w);
   rc |= palloc(s, &s->head_slab2, (size_t)((s->head_blocks_max + 31) / 32) * s->head_slab_w);
   rc |= palloc(s, &s->perm, TN);
+  if (knob_yield) rc |= palloc(s, &s->pause_flag, 16);      // zeroed; only element 0 is used
   rc |= palloc(s, &s->sumsq, 1); rc |= palloc(s, &s->sched, 1);
   if (rc) return -3;
   SchedState st0{cfg->learning_rate, 0.f, 0.f, 0.f};
@@ -2057,7 +2067,7 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
 #define HX_FA_ARGS so, s->cfg.obs_ld, count, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                        \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts,        \
-                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, FrameSrc{nullptr, nullptr, nullptr, 0}, hx_step_book{}, 0
+                   s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, FrameSrc{nullptr, nullptr, nullptr, 0}, hx_step_book{}, 0, s->pause_flag
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
       // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
       const dim3 fgrid((count + FA_ROWS - 1) / FA_ROWS);
@@ -2133,7 +2143,7 @@ static int act_frames(hx_ppo* s, const hx_step_book* book, float** actions_out) 
 #define HX_FA_ARGS (const float*)nullptr, 0, N, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                       \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, (const float*)nullptr, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts, \
-                   s->s_mu + (size_t)t * N * A, s->s_logp + (size_t)t * N, fsrc, bk, book ? 1 : 0
+                   s->s_mu + (size_t)t * N * A, s->s_logp + (size_t)t * N, fsrc, bk, book ? 1 : 0, s->pause_flag
     const dim3 fgrid((N + FA_ROWS - 1) / FA_ROWS);
     if (s->actor_waves == 8) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
     else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
