@@ -179,7 +179,8 @@ def test_frame_storage_refuses_ready_made_rows(hxlib):
 def test_deferred_critic_batching_does_not_change_the_values(hxlib, monkeypatch):
     """The critic runs beside the rollout in batches of HX_CRITIC_CHUNK slots (tile shape by batch size): however the slots are
     grouped -- one at a time, the default pairs, seven at a time (leaving a remainder for compute_returns), or all at the end --
-    values, returns and advantages must come out the same (same fp32 k order in every tile shape: bitwise)."""
+    values, returns and advantages must come out the same (same fp32 k order in every tile shape: bitwise) -- and likewise with the
+    critic's yield to the actor (HX_CRITIC_YIELD) switched off."""
     from isaac_amd import capi
     from isaac_amd.envs.configs import HectorCfg
     from isaac_amd.envs.hector_env import HectorFreeEnv
@@ -189,8 +190,9 @@ def test_deferred_critic_batching_does_not_change_the_values(hxlib, monkeypatch)
     N, T = 96, 20
     init = ActorCriticOracle.default_init(np.random.default_rng(4)).state_dict()
     res = []
-    for chunk in ("2", "1", "7", "60"):
+    for chunk, yield_ in (("2", "1"), ("1", "1"), ("7", "1"), ("60", "1"), ("2", "0")):
         monkeypatch.setenv("HX_CRITIC_CHUNK", chunk)
+        monkeypatch.setenv("HX_CRITIC_YIELD", yield_)      # the critic sleeping while actor workgroups are in flight is scheduling only
         cfg = HectorCfg(); cfg.env.num_envs = N; cfg.seed = set_seed(9)
         env = HectorFreeEnv(cfg)
         ac = ActorCritic(615, 1050, 10, [512, 256, 128], [768, 256, 128]); ac.load_state_dict(init)
