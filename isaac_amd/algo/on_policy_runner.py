@@ -45,8 +45,15 @@ class OnPolicyRunner:
         alg_kw = dict(self.alg_cfg)
         if "seed" in train_cfg and "seed" not in alg_kw:      # exploration noise keyed by seed + rank, permutation by seed
             alg_kw["seed"] = train_cfg["seed"]
+        # The rollout's background critic yields the matrix pipes to the actor (HX_CRITIC_YIELD).  That pays while the
+        # env step leaves the critic slack; on the ground plane the step is a third shorter and it does not (the critic's backlog
+        # then lands behind the rollout: profiles/r03_p_grouped_launches.txt), so the runner -- which knows the terrain -- creates
+        # the learner with the yield off there unless the variable is set.  Scheduling only: results are the same.
         self.alg = _CLASSES[self.cfg["algorithm_class_name"]](actor_critic, device=device, stream=getattr(env, "stream", None),
                                                               comm=comm, **alg_kw)
+        plane = getattr(getattr(getattr(env, "cfg", None), "terrain", None), "mesh_type", None) == "plane"
+        if plane and hasattr(self.alg, "creation_knobs"):
+            self.alg.creation_knobs.setdefault("HX_CRITIC_YIELD", "0")
         self.num_steps_per_env = self.cfg["num_steps_per_env"]
         self.save_interval = self.cfg["save_interval"]
         # Rollout storage of the observations (runner.observation_storage, not a reference key): "frames" = every robot's frames

@@ -156,6 +156,7 @@ class PPO:
         self._stream = stream
         self.comm = comm                  # isaac_amd.parallel.Comm or None (single process)
         self._L = capi.lib()
+        self.creation_knobs = {}          # HX_* scheduling knobs for this learner's creation (init_storage), e.g. from the runner
         self._keep = []
 
     # ------------------------------------------------------------------ construction
@@ -192,7 +193,16 @@ class PPO:
         if self._distributed() and not getattr(self.comm, "in_library", False):
             ext = self.comm.alloc_grad_buffer(self._padded_count(c) + 4)
         h = capi.C.c_void_p()
-        capi.check(self._L.hx_ppo_create(capi.C.byref(c), self._stream, ext, capi.C.byref(h)), "hx_ppo_create")
+        # experiment knobs a caller wants for THIS learner (they are environment variables read once, at creation): set for the
+        # duration of the call unless the process environment already says otherwise
+        import os
+        held = {k: v for k, v in self.creation_knobs.items() if k not in os.environ}
+        os.environ.update(held)
+        try:
+            capi.check(self._L.hx_ppo_create(capi.C.byref(c), self._stream, ext, capi.C.byref(h)), "hx_ppo_create")
+        finally:
+            for k in held:
+                del os.environ[k]
         self._h = h
         self._stream = self._L.hx_ppo_stream(h)
         self.N, self.T, self.A = num_envs, num_transitions_per_env, action_shape[0]

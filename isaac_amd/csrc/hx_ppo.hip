@@ -1953,9 +1953,9 @@ extern "C" int hx_ppo_get_opt_state_h(hx_ppo* s, float* m, float* v, int64_t* st
 
 // hidden layers of one network: X[M][ld] -> act[0..2]
 static void mlp_hidden_fwd(hx_ppo* s, int net, const float* X, int ldx, int M, float** act, hipStream_t st = nullptr, bool fp32_only = false,
-                           const RowTable* rt = nullptr) {
+                           const RowTable* rt = nullptr, bool whole_chip = false) {
   const Layer* L = s->L + net * 4;
-  const bool bg = (st != nullptr && st == s->stream2);
+  const bool bg = (st != nullptr && st == s->stream2) && !whole_chip;      // whole_chip: nothing runs beside it (the flush after the rollout)
   if (!st) st = s->stream;
   gemm_fwd(s, st, X, ldx, s->params + L[0].w, L[0].in_ld, s->params + L[0].b, act[0], M, L[0].out, L[0].in_ld, bg, fp32_only, rt);
   gemm_fwd(s, st, act[0], L[1].in_ld, s->params + L[1].w, L[1].in_ld, s->params + L[1].b, act[1], M, L[1].out, L[1].in_ld, bg, fp32_only);
@@ -2000,7 +2000,7 @@ static void gemm_dgrad_pair(hx_ppo* s, int l, int M, hipStream_t st) {
 }
 
 // values for rollout slots [crit_done, upto) on the second stream: one critic forward over (slots * N) rows
-static int critic_flush(hx_ppo* s, int upto) {
+static int critic_flush(hx_ppo* s, int upto, bool after_rollout = false) {
   const int N = s->cfg.num_envs;
   while (s->crit_done < upto) {
     int slots = upto - s->crit_done;
@@ -2010,10 +2010,10 @@ static int critic_flush(hx_ppo* s, int upto) {
     HX_CHECK(hipStreamWaitEvent(s->stream2, s->ev_priv, 0));   // the newest slot's rows have been copied
     if (s->frames) {
       const RowTable rt{s->off_priv + (size_t)s->crit_done * N, s->kz_priv + (size_t)s->crit_done * N, s->cfg.num_priv};
-      mlp_hidden_fwd(s, 1, s->s_priv, 0, rows, s->act_c, s->stream2, false, &rt);
+      mlp_hidden_fwd(s, 1, s->s_priv, 0, rows, s->act_c, s->stream2, false, &rt, after_rollout);
     } else {
       const float* sp = s->s_priv + (size_t)s->crit_done * N * s->cfg.priv_ld;
-      mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, rows, s->act_c, s->stream2);
+      mlp_hidden_fwd(s, 1, sp, s->cfg.priv_ld, rows, s->act_c, s->stream2, false, nullptr, after_rollout);
     }
     hipLaunchKernelGGL(hx_value_head_kernel, dim3((rows + 15) / 16), dim3(256), 0, s->stream2, s->act_c[2], s->cfg.critic_hidden[2],
                        s->params + s->L[7].w, s->params + s->L[7].b, rows, s->s_values + (size_t)s->crit_done * N);
@@ -2208,7 +2208,8 @@ extern "C" int hx_ppo_last_values_range(hx_ppo* s, const float* last_priv, int e
 extern "C" int hx_ppo_compute_returns(hx_ppo* s, const float* last_priv) {
   const int N = s->cfg.num_envs, T = s->cfg.num_steps;
   // finish the deferred critic for every stored slot, then make the main stream wait for it
-  if (s->crit_done < s->step) { HX_CHECK(hipEventRecord(s->ev_priv, s->stream)); const int rc = critic_flush(s, s->step); if (rc) return rc; }
+  // (whatever the background critic did not get to -- it yields to the actor -- runs here on the whole chip, not on its half-chip grid)
+  if (s->crit_done < s->step) { HX_CHECK(hipEventRecord(s->ev_priv, s->stream)); const int rc = critic_flush(s, s->step, true); if (rc) return rc; }
   HX_CHECK(hipStreamWaitEvent(s->stream, s->ev_crit, 0));
   if (last_priv) { const int rc = hx_ppo_last_values_range(s, last_priv, 0, N, s->stream); if (rc) return rc; }
   HX_CHECK(hipMemsetAsync(s->moments, 0, 3 * sizeof(double), s->stream));
