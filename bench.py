@@ -220,8 +220,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--task", default="hector", choices=["hector", "hector_full", "humanoid_ppo"],
                     help="hector is BASELINE.json's metric config; hector_full (18 DoF) and humanoid_ppo (XBot-L, 12 DoF) are the sibling "
