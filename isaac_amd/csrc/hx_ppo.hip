@@ -1049,7 +1049,8 @@ __global__ void __launch_bounds__(256) hx_sumsq_kernel(const float* __restrict__
 
 // adaptive-KL learning-rate schedule (ppo.py:136-148) + running loss sums, on device so no host sync is needed
 struct SchedState { float lr; float last_kl; float vloss_sum; float sloss_sum; };
-__global__ void hx_schedule_kernel(const float* __restrict__ stats, int adaptive, float desired_kl, SchedState* st) {
+__global__ void hx_schedule_kernel(const float* __restrict__ stats, int adaptive, float desired_kl, SchedState* st, double* sumsq) {
+  *sumsq = 0.0;                          // accumulator of the gradient-norm kernel that follows (was a memset launch per optimiser step)
   const float rows = stats[3];
   const float kl = stats[0] / rows;
   float lr = st->lr;
@@ -2378,8 +2379,7 @@ extern "C" int hx_ppo_minibatch_step(hx_ppo* s, float inv_world) {
     inv_world = 1.0f / (float)hx_comm_world(s->comm);
   }
   // after an all-reduce(sum) the statistics are global sums, so kl_mean = kl_sum / rows is already world-wide
-  hipLaunchKernelGGL(hx_schedule_kernel, dim3(1), dim3(1), 0, st, s->grads + s->stats_off, c.adaptive_schedule, c.desired_kl, s->sched);
-  HX_CHECK(hipMemsetAsync(s->sumsq, 0, sizeof(double), st));
+  hipLaunchKernelGGL(hx_schedule_kernel, dim3(1), dim3(1), 0, st, s->grads + s->stats_off, c.adaptive_schedule, c.desired_kl, s->sched, s->sumsq);
   hipLaunchKernelGGL(hx_sumsq_kernel, dim3(256), dim3(256), 0, st, s->grads, s->padded, inv_world, s->sumsq);
   s->adam_t += 1;
   const float bc1 = 1.0f - (float)pow(0.9, (double)s->adam_t);
