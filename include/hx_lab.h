@@ -27,6 +27,11 @@ int hx_ppo_prof_end(hx_ppo* p, hx_prof_row* rows_h, int max_rows, int* n_rows);
  * split; add 10 for the BK = 32 variant; 5-9: bf16 and persistent-grid variants, tests/test_gpu_gemm.py) */
 int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      const float* bias, float* C, int ldc, const float* H, void* hip_stream);
+/* unit-test hook: the weight gradients dW_l[out_l][in_ld_l] = dZ_l[rows][out_l]^T X_l[rows][in_ld_l] and bias gradients (column sums of
+ * dZ_l) of up to six layers through the one-workgroup-per-CU path of the update (planner hx_wgrad_plan.h, hx_wgrad_multi_kernel, slab
+ * reduction).  The pointer tables are HOST arrays of DEVICE pointers; slots <= 0: one workgroup per CU. */
+int hx_ppo_wgrad_multi_test(int nl, const int* out_h, const int* in_ld_h, int rows, const float* const* dZ_h, const float* const* X_h,
+                            float* const* dW_h, float* const* db_h, int slots, int* nlaunch_h, void* hip_stream);
 /* timing hook: mean ms per launch of one learner GEMM (kind 0 fwd, 1 dgrad, 2 wgrad split-K; bk 16 or 32) */
 int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out);
 /* measurement hook: TFLOP/s of 256-thread workgroups whose waves issue n v_mfma_f32_32x32x2_f32 each with, by mode,

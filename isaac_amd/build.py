@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in ("hx_sim.hip", "hx_ppo.hip", "hx_comm.hip")]
-HDR = [os.path.join(HERE, "csrc", f) for f in ("hx_math.h", "hx_dyn.h", "hx_env.h", "hx_gemm.h", "hx_gemm_bf16.h", "hx_common.h", "hx_model_data.h", "hx_model_data_full.h", "hx_model_data_xbot.h")] + \
+HDR = [os.path.join(HERE, "csrc", f) for f in ("hx_math.h", "hx_dyn.h", "hx_env.h", "hx_gemm.h", "hx_gemm_sp.h", "hx_wgrad_plan.h", "hx_gemm_bf16.h", "hx_common.h", "hx_model_data.h", "hx_model_data_full.h", "hx_model_data_xbot.h")] + \
       [os.path.join(os.path.dirname(HERE), "include", f) for f in ("hx_sim.h", "hx_ppo.h", "hx_lab.h")]
 OUT = os.path.join(HERE, "libhx.so")
 

@@ -466,31 +466,44 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_kernel(GemmArgs g) {
 // `logical`: split-major for split-K).  Block -> work map: blocks b, b + 8, ... share an XCD and its L2; XCD x walks its
 // contiguous share of member 0's tiles, then its share of member 1's, ... -- every XCD gets the same mix of long and short
 // tiles, and neighbours in an XCD's queue re-use the same A rows.  Grid = 8 x the longest queue; the few surplus blocks exit.
-#define HX_GROUP_MAX 6
+#define HX_GROUP_MAX 8
 struct GemmGroup { GemmArgs p[HX_GROUP_MAX]; int first[HX_GROUP_MAX + 1]; int n; };
+// Block -> work map of a grouped launch.  Member m has T_m blocks; XCD x (blocks x, x + 8, ...: they share an L2) takes a
+// contiguous run of  T_m / 8  of them, and the  T_m % 8  left over go one each to the XCDs  start_m, start_m + 1, ...  where
+// start_m continues where the previous member's leftovers ended -- so the XCDs' totals differ by at most one block.  (With
+// the leftovers always on XCDs 0, 1, ... a launch sized for one workgroup per CU put 34 workgroups on the first XCD's 32 CUs
+// and ran twice as long, profiles/r04_b_gemm_lab.txt.)
+static inline __host__ __device__ int hx_group_count(int T, int start, int xcd) { return (T >> 3) + ((((xcd - start) & 7) < (T & 7)) ? 1 : 0); }
 static inline int hx_group_grid(const GemmGroup& G) {
   int longest = 0;
   for (int x = 0; x < 8; ++x) {
-    int len = 0;
-    for (int m = 0; m < G.n; ++m) { const int T = G.first[m + 1] - G.first[m]; len += T / 8 + (x < T % 8 ? 1 : 0); }
+    int len = 0, start = 0;
+    for (int m = 0; m < G.n; ++m) { const int T = G.first[m + 1] - G.first[m]; len += hx_group_count(T, start, x); start = (start + T) & 7; }
     if (len > longest) longest = len;
   }
   return 8 * longest;
 }
-template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
-__global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_group_kernel(GemmGroup G) {
-  __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
+// member `pi` (-1: surplus block) and its logical block for blockIdx.x
+__device__ __forceinline__ void hx_group_pick(const GemmGroup& G, int& pi, int& logical) {
   const int xcd = blockIdx.x & 7;
-  int idx = blockIdx.x >> 3, pi = -1, logical = 0;
+  int idx = blockIdx.x >> 3, start = 0;
+  pi = -1; logical = 0;
 #pragma unroll
   for (int m = 0; m < HX_GROUP_MAX; ++m) {
     if (m < G.n && pi < 0) {
-      const int T = G.first[m + 1] - G.first[m], q = T >> 3, r = T & 7;
-      const int cnt = q + (xcd < r ? 1 : 0);
-      if (idx < cnt) { pi = m; logical = xcd * q + min(xcd, r) + idx; }
+      const int T = G.first[m + 1] - G.first[m], q = T >> 3, r = T & 7, xr = (xcd - start) & 7;
+      const int cnt = q + (xr < r ? 1 : 0);
+      if (idx < cnt) { pi = m; logical = xr * q + min(xr, r) + idx; }
       else idx -= cnt;
+      start = (start + T) & 7;
     }
   }
+}
+template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false>
+__global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_group_kernel(GemmGroup G) {
+  __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
+  int pi, logical;
+  hx_group_pick(G, pi, logical);
   if (pi < 0) return;
   // member of this block: a chain of uniform selects (indexing the kernel-argument array with a run-time value would move
   // the whole struct to scratch)

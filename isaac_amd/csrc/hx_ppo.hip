@@ -19,7 +19,10 @@
 #include "../../include/hx_sim.h"
 #include "../../include/hx_lab.h"
 #include "hx_common.h"
+#include <map>
 #include "hx_gemm.h"
+#include "hx_gemm_sp.h"
+#include "hx_wgrad_plan.h"
 #include "hx_gemm_bf16.h"
 
 #define MAX_A 32
@@ -781,10 +784,13 @@ __global__ void hx_slab_chunk_kernel(const float* __restrict__ slab, int S, int 
 // All split-K partial slabs of one minibatch (6 weight + 6 bias segments) summed in ONE launch: segment table in
 // kernel arguments, each workgroup owns 256 consecutive elements of one segment.  Fixed summation order -> bitwise
 // reproducible gradients.
-#define HX_MAX_SEG 12
+// A segment may be a column range of its destination matrix: the slabs are compact [S][rows x cols], element i of a slab goes
+// to dst[(i / cols) * ldd + i % cols]  (cols = ldd = count for a flat segment; cols is a multiple of 4).
+#define HX_MAX_SEG 24
 struct ReduceTable {
   const float* src[HX_MAX_SEG]; float* dst[HX_MAX_SEG];
   unsigned count[HX_MAX_SEG]; int S[HX_MAX_SEG]; unsigned block0[HX_MAX_SEG + 1];
+  unsigned cols[HX_MAX_SEG], ldd[HX_MAX_SEG];
   int nseg;
 };
 __global__ void __launch_bounds__(256) hx_reduce_all_kernel(ReduceTable t) {
@@ -808,7 +814,9 @@ __global__ void __launch_bounds__(256) hx_reduce_all_kernel(ReduceTable t) {
     s = s + v0; s = s + v1; s = s + v2; s = s + v3;
   }
   for (; k < S; ++k) s = s + *reinterpret_cast<const f32x4*>(src + (size_t)k * stride);
-  *reinterpret_cast<f32x4*>(t.dst[seg] + i) = s;
+  const unsigned cols = t.cols[seg];
+  const size_t di = (cols == t.count[seg]) ? (size_t)i : (size_t)(i / cols) * t.ldd[seg] + (i % cols);
+  *reinterpret_cast<f32x4*>(t.dst[seg] + di) = s;
 }
 
 // The same loss head on the matrix cores (v_mfma_f32_16x16x4_f32), for heads of up to 16 actions over staged rows (the hector
@@ -1117,6 +1125,9 @@ struct hx_ppo {
   int critic_late;               // 1: a deferred critic batch starts after the actor kernel of its step instead of beside it
   int fwd_in_tile;               // rows per tile of the input layers' forward products at update size (HX_FWD_IN_TILE, 128 or 64)
   int wgrad_group;               // 1: the weight-gradient products of a minibatch go out as grouped split-K launches (HX_WGRAD_GROUP)
+  int wgrad_multi;               // 1: ... at one workgroup per CU with per-product tile shapes (hx_wgrad_multi_kernel, HX_WGRAD_MULTI)
+  std::map<int, WgradPlan> wplans;          // per minibatch row count
+  float *wslab = nullptr, *wbslab = nullptr; size_t wslab_floats = 0, wbslab_floats = 0;
   int gemm_pair;                 // 1: layer l of the actor and of the critic share one launch in the update (HX_GEMM_PAIR)
   int head_mfma;                 // 1: hector-shaped loss heads run on the matrix cores (HX_HEAD_MFMA)
   int* pause_flag = nullptr;     // count of fused-actor workgroups in flight; the background critic sleeps while it is up (HX_CRITIC_YIELD)
@@ -1391,6 +1402,28 @@ static void gemm_wgrad_groups(hx_ppo* s, hipStream_t st, const WgradJob* jobs, i
   }
 }
 
+// plan of the one-workgroup-per-CU weight gradients for minibatches of M rows (hx_wgrad_plan.h); slab buffers grow on demand
+static int wgrad_plan_for(hx_ppo* s, const WgradLayerDesc* wl, int M, const WgradPlan** out) {
+  auto it = s->wplans.find(M);
+  if (it == s->wplans.end()) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    it = s->wplans.emplace(M, hx_wgrad_plan(wl, 6, M, cus)).first;
+    if ((int)it->second.pieces.size() * 2 > HX_MAX_SEG) { hx_set_error("wgrad plan: too many pieces for the reduce table"); return -2; }
+  }
+  const WgradPlan& p = it->second;
+  if (p.slab_floats > s->wslab_floats || p.bslab_floats > s->wbslab_floats) {
+    HX_CHECK(hipStreamSynchronize(s->stream));
+    if (s->wslab) (void)hipFree(s->wslab);
+    if (s->wbslab) (void)hipFree(s->wbslab);
+    s->wslab = s->wbslab = nullptr; s->wslab_floats = s->wbslab_floats = 0;
+    HX_CHECK(hipMalloc((void**)&s->wslab, p.slab_floats * sizeof(float))); s->wslab_floats = p.slab_floats;
+    HX_CHECK(hipMalloc((void**)&s->wbslab, (p.bslab_floats + 4) * sizeof(float))); s->wbslab_floats = p.bslab_floats;
+  }
+  *out = &p;
+  return 0;
+}
+
 extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, const float* B, int ldb, const float* bias,
                                 float* C, int ldc, const float* H, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -1441,6 +1474,46 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   if (variant == 0) { HX_DISPATCH(16) } else { HX_DISPATCH(32) }
 #undef HX_DISPATCH
   HX_CHECK(hipGetLastError());
+  return 0;
+}
+
+// unit-test hook (tests/test_gpu_gemm.py): the weight gradients of `nl` layers over `rows` rows through the planner, the
+// multi-shape kernel and the slab reduction, on caller-supplied device buffers; slots = 0: one workgroup per CU of this device
+extern "C" int hx_ppo_wgrad_multi_test(int nl, const int* out_h, const int* in_ld_h, int rows, const float* const* dZ_h, const float* const* X_h,
+                                       float* const* dW_h, float* const* db_h, int slots, int* nlaunch_h, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (nl < 1 || nl > 6 || rows % 32 != 0) { hx_set_error("hx_ppo_wgrad_multi_test: 1..6 layers, rows a multiple of 32"); return -2; }
+  WgradLayerDesc wl[6]; WgradOperands wo[6];
+  for (int l = 0; l < nl; ++l) { wl[l] = WgradLayerDesc{out_h[l], in_ld_h[l]}; wo[l] = WgradOperands{dZ_h[l], X_h[l], in_ld_h[l]}; }
+  if (slots <= 0) { int dev = 0; slots = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev); }
+  const WgradPlan plan = hx_wgrad_plan(wl, nl, rows, slots);
+  if ((int)plan.pieces.size() * 2 > HX_MAX_SEG) { hx_set_error("wgrad plan: too many pieces"); return -2; }
+  float *slab = nullptr, *bslab = nullptr;
+  HX_CHECK(hipMalloc((void**)&slab, plan.slab_floats * sizeof(float))); HX_CHECK(hipMalloc((void**)&bslab, (plan.bslab_floats + 4) * sizeof(float)));
+  HX_CHECK(hipMemsetAsync(slab, 0xff, plan.slab_floats * sizeof(float), st));        // NaN: an element nobody writes shows up in the sums
+  HX_CHECK(hipMemsetAsync(bslab, 0xff, plan.bslab_floats * sizeof(float), st));
+  for (int q = 0; q < plan.nlaunch; ++q) {
+    WgradMulti W;
+    hx_wgrad_fill(plan, q, wl, wo, rows, slab, bslab, W);
+    hipLaunchKernelGGL(hx_wgrad_multi_kernel, dim3(hx_group_grid(W.G)), dim3(256), 0, st, W);
+  }
+  ReduceTable rt{}; unsigned blocks = 0;
+  for (const WgradPiece& pc : plan.pieces) {
+    int k = rt.nseg++;
+    rt.src[k] = slab + pc.slab_off; rt.dst[k] = dW_h[pc.layer] + pc.col0; rt.count[k] = (unsigned)wl[pc.layer].out * (unsigned)pc.ncols;
+    rt.cols[k] = (unsigned)pc.ncols; rt.ldd[k] = (unsigned)wl[pc.layer].in_ld; rt.S[k] = pc.splits; rt.block0[k] = blocks; blocks += (rt.count[k] + 1023) / 1024;
+    if (pc.bias) {
+      k = rt.nseg++;
+      rt.src[k] = bslab + pc.bslab_off; rt.dst[k] = db_h[pc.layer]; rt.count[k] = (unsigned)wl[pc.layer].out; rt.cols[k] = rt.count[k]; rt.ldd[k] = rt.count[k];
+      rt.S[k] = pc.splits * pc.tiles_n; rt.block0[k] = blocks; blocks += (wl[pc.layer].out + 1023) / 1024;
+    }
+  }
+  rt.block0[rt.nseg] = blocks;
+  hipLaunchKernelGGL(hx_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, rt);
+  HX_CHECK(hipGetLastError());
+  HX_CHECK(hipStreamSynchronize(st));
+  (void)hipFree(slab); (void)hipFree(bslab);
+  if (nlaunch_h) *nlaunch_h = plan.nlaunch;
   return 0;
 }
 
@@ -1650,6 +1723,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_CRITIC_CHUNK", HX_CRITIC_CHUNK, 1, 4096, &s->critic_chunk)) return rc;
   if (int rc = hx_knob_int("HX_WGRAD_BLOCKS", 0, 1, 65536, &knob_wgrad)) return rc;
   if (int rc = hx_knob_int("HX_WGRAD_GROUP", 1, 0, 1, &s->wgrad_group)) return rc;
+  if (int rc = hx_knob_int("HX_WGRAD_MULTI", 1, 0, 1, &s->wgrad_multi)) return rc;
   if (int rc = hx_knob_int("HX_GEMM_PAIR", 1, 0, 1, &s->gemm_pair)) return rc;
   if (int rc = hx_knob_int("HX_HEAD_MFMA", 1, 0, 1, &s->head_mfma)) return rc;
   int knob_yield = 1;
@@ -1829,6 +1903,8 @@ extern "C" void hx_ppo_destroy(hx_ppo* s) {
   if (!s) return;
   (void)hipDeviceSynchronize();      // the stream may be borrowed from an env that no longer exists
   for (void* a : s->allocs) (void)hipFree(a);
+  if (s->wslab) (void)hipFree(s->wslab);
+  if (s->wbslab) (void)hipFree(s->wbslab);
   for (auto e : s->ev) (void)hipEventDestroy(e);
   // null checks: hx_ppo_create also ends here with a half-built object, and a failed destroy call would leave a
   // sticky HIP error for the next launch check to trip over
@@ -2328,8 +2404,10 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   ReduceTable rt{}; unsigned blocks = 0;
   // Grouped weight gradients (hx_gemm_group_kernel): the input-gradient chain of both networks first, then every layer's
   // dZ^T X in one or two launches.  fp32 path with whole K tiles only; HX_WGRAD_GROUP=0 launches layer by layer as before.
-  const bool grouped = s->wgrad_group && !s->bf16 && (M % HX_BK_UPD == 0);
+  const bool multi = s->wgrad_multi && !s->bf16 && (M % 32 == 0) && M >= 512;
+  const bool grouped = !multi && s->wgrad_group && !s->bf16 && (M % HX_BK_UPD == 0);
   WgradJob jobs[8]; int njobs = 0;
+  WgradLayerDesc wl[6]; WgradOperands wo[6];
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b0, st)); HX_CHECK(hipStreamWaitEvent(sb, s->ev_b0, 0)); }
   for (int l = 2; l >= 0; --l) {
     for (int net = 0; net < 2; ++net) {
@@ -2341,28 +2419,58 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
       const int ldx = net ? c.priv_ld : c.obs_ld;
       const float* in = (l == 0) ? X : act[l - 1];
       const int ld_in = (l == 0) ? ldx : L[l].in_ld;
-      float* slab = s->slab + s->slab_off[net * 4 + l];
-      float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
-      int bparts = 0, splits = 0;
-      if (grouped) jobs[njobs++] = WgradJob{dz[l], L[l].out, in, ld_in, L[l].in_ld, slab, bslab, s->slab_splits[net * 4 + l], rt.nseg};
-      else splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
-      const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
-      int k = rt.nseg;
-      rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
-      k = ++rt.nseg;
-      rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.S[k] = bparts; rt.block0[k] = blocks; blocks += (L[l].out + 1023) / 1024;
-      ++rt.nseg;
+      if (multi) {
+        wl[net * 3 + l] = WgradLayerDesc{L[l].out, L[l].in_ld};
+        wo[net * 3 + l] = WgradOperands{dz[l], in, ld_in};
+      } else {
+        float* slab = s->slab + s->slab_off[net * 4 + l];
+        float* bslab = s->bias_slab + s->bslab_off[net * 4 + l];
+        int bparts = 0, splits = 0;
+        if (grouped) jobs[njobs++] = WgradJob{dz[l], L[l].out, in, ld_in, L[l].in_ld, slab, bslab, s->slab_splits[net * 4 + l], rt.nseg};
+        else splits = gemm_wgrad(s, st, dz[l], L[l].out, in, ld_in, L[l].in_ld, M, slab, bslab, &bparts, s->slab_splits[net * 4 + l]);
+        const unsigned cnt = (unsigned)L[l].out * (unsigned)L[l].in_ld;
+        int k = rt.nseg;
+        rt.src[k] = slab; rt.dst[k] = s->grads + L[l].w; rt.count[k] = cnt; rt.cols[k] = cnt; rt.ldd[k] = cnt; rt.S[k] = splits; rt.block0[k] = blocks; blocks += (cnt + 1023) / 1024;
+        k = ++rt.nseg;
+        rt.src[k] = bslab; rt.dst[k] = s->grads + L[l].b; rt.count[k] = (unsigned)L[l].out; rt.cols[k] = rt.count[k]; rt.ldd[k] = rt.count[k]; rt.S[k] = bparts; rt.block0[k] = blocks; blocks += (L[l].out + 1023) / 1024;
+        ++rt.nseg;
+      }
       if (l > 0 && !pair) gemm_dgrad(s, st, dz[l], L[l].out, s->params + L[l].w, L[l].in_ld, act[l - 1], dz[l - 1], M, L[l].in_ld, L[l].out, s->wT[net * 4 + l]);
     }
     if (l > 0 && pair) gemm_dgrad_pair(s, l, M, st);
   }
-  rt.block0[rt.nseg] = blocks;
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   if (grouped) {
     int sp[8], bp[8];
     gemm_wgrad_groups(s, st, jobs, njobs, M, sp, bp);
     for (int i = 0; i < njobs; ++i) { rt.S[jobs[i].seg] = sp[i]; rt.S[jobs[i].seg + 1] = bp[i]; }
   }
+  if (multi) {
+    // every layer's dZ^T X at one workgroup per CU (hx_wgrad_multi_kernel): plan per minibatch size, made on first use
+    const WgradPlan* plan = nullptr;
+    if (int rc = wgrad_plan_for(s, wl, M, &plan)) return rc;
+    static const int kid = prof_register("hx_wgrad_multi_kernel");
+    for (int q = 0; q < plan->nlaunch; ++q) {
+      WgradMulti W;
+      hx_wgrad_fill(*plan, q, wl, wo, M, s->wslab, s->wbslab, W);
+      double flops = 0.0;
+      for (const WgradPiece& pc : plan->pieces) if (pc.launch == q) flops += 2.0 * wl[pc.layer].out * pc.ncols * (double)M;
+      ProfScope ps(s, kid, st, flops);
+      hipLaunchKernelGGL(hx_wgrad_multi_kernel, dim3(hx_group_grid(W.G)), dim3(256), 0, st, W);
+    }
+    for (const WgradPiece& pc : plan->pieces) {
+      const Layer& Ly = s->L[(pc.layer / 3) * 4 + pc.layer % 3];
+      int k = rt.nseg++;
+      rt.src[k] = s->wslab + pc.slab_off; rt.dst[k] = s->grads + Ly.w + pc.col0; rt.count[k] = (unsigned)Ly.out * (unsigned)pc.ncols;
+      rt.cols[k] = (unsigned)pc.ncols; rt.ldd[k] = (unsigned)Ly.in_ld; rt.S[k] = pc.splits; rt.block0[k] = blocks; blocks += (rt.count[k] + 1023) / 1024;
+      if (pc.bias) {
+        k = rt.nseg++;
+        rt.src[k] = s->wbslab + pc.bslab_off; rt.dst[k] = s->grads + Ly.b; rt.count[k] = (unsigned)Ly.out; rt.cols[k] = rt.count[k]; rt.ldd[k] = rt.count[k];
+        rt.S[k] = pc.splits * pc.tiles_n; rt.block0[k] = blocks; blocks += (Ly.out + 1023) / 1024;
+      }
+    }
+  }
+  rt.block0[rt.nseg] = blocks;
   hipLaunchKernelGGL(hx_reduce_all_kernel, dim3(blocks), dim3(256), 0, st, rt);
   HX_CHECK(hipGetLastError());
   if (grad_buffer) *grad_buffer = s->grads;

@@ -153,3 +153,39 @@ def test_bf16_wgrad(hxlib, M, N, K):
     scale = np.abs(ref).max() + 1.0
     assert np.abs(out - ref).max() <= 5e-5 * scale * max(1.0, np.sqrt(K) / 16)
     np.testing.assert_allclose(dbias.download(np.float32, (M,)), A.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("layers,rows,slots", [
+    # the hector networks' six products at a quarter of the update's rows: 768 x 1052 = 768 x 1024 in 256 x 256 tiles + a 28-column strip
+    ([(768, 1052), (512, 616), (256, 768), (256, 512), (128, 256), (128, 256)], 15360, 0),
+    # humanoid_ppo's input layers (708 / 220 wide), few slots: several slices per workgroup round and edge tiles in both directions
+    ([(512, 708), (768, 220), (256, 512)], 4096, 64),
+    # ragged everything: out not a multiple of 128, widths that leave 4 and 36 columns over
+    ([(100, 260), (36, 36), (132, 1060)], 1024, 40),
+])
+def test_wgrad_one_workgroup_per_cu(hxlib, layers, rows, slots):
+    """hx_wgrad_multi_kernel + hx_wgrad_plan.h + the 2-D slab reduction against numpy float64: dW_l = dZ_l^T X_l and the bias
+    gradient (column sums of dZ_l), every layer of a launch group in its own tile shape and slice count.  The slabs are poisoned
+    with NaN before the launches, so an element no workgroup writes fails the comparison."""
+    import ctypes as C
+    rng = np.random.default_rng(rows + len(layers))
+    nl = len(layers)
+    dZ = [rng.standard_normal((rows, o)).astype(np.float32) for o, _ in layers]
+    X = [rng.standard_normal((rows, i)).astype(np.float32) for _, i in layers]
+    bz = [capi.DeviceBuffer.from_host(a) for a in dZ]
+    bx = [capi.DeviceBuffer.from_host(a) for a in X]
+    bw = [capi.DeviceBuffer(o * i * 4) for o, i in layers]
+    bb = [capi.DeviceBuffer(o * 4) for o, _ in layers]
+    arr = lambda bufs: (C.c_void_p * nl)(*[b.ptr for b in bufs])
+    ints = lambda v: (C.c_int * nl)(*v)
+    nlaunch = C.c_int(0)
+    capi.check(hxlib.hx_ppo_wgrad_multi_test(nl, ints([o for o, _ in layers]), ints([i for _, i in layers]), rows, arr(bz), arr(bx), arr(bw), arr(bb),
+                                             slots, C.byref(nlaunch), None), "wgrad_multi_test")
+    assert 1 <= nlaunch.value <= 2
+    for l, (o, i) in enumerate(layers):
+        ref = dZ[l].astype(np.float64).T @ X[l].astype(np.float64)
+        out = bw[l].download(np.float32, (o, i))
+        assert np.isfinite(out).all(), l
+        err = np.abs(out - ref).max()
+        assert err <= 5e-5 * (np.abs(ref).max() + 1.0) * max(1.0, np.sqrt(rows) / 16), (l, err)
+        np.testing.assert_allclose(bb[l].download(np.float32, (o,)), dZ[l].astype(np.float64).sum(0), rtol=1e-4, atol=1e-3 * np.sqrt(rows))

@@ -234,7 +234,7 @@ def test_grouped_launches_change_scheduling_only(hxlib, monkeypatch):
     perm = np.random.default_rng(1).permutation(T * N).astype(np.int32)
 
     def run(env):
-        for k in ("HX_GEMM_PAIR", "HX_WGRAD_GROUP", "HX_HEAD_MFMA"):
+        for k in ("HX_GEMM_PAIR", "HX_WGRAD_GROUP", "HX_WGRAD_MULTI", "HX_HEAD_MFMA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -255,13 +255,15 @@ def test_grouped_launches_change_scheduling_only(hxlib, monkeypatch):
         np.testing.assert_array_equal(base[2][k], unpaired[2][k], err_msg=k)
     # the same for the loss head on the matrix cores (hx_loss_head_mfma_kernel) against the VALU kernel it replaces for
     # hector-shaped heads: the dot products, the sum over actions and the head's weight gradients are associated differently
-    for other in ({"HX_WGRAD_GROUP": "0"}, {"HX_HEAD_MFMA": "0"}):
+    # ... and for the weight gradients: one workgroup per CU with per-product tile shapes (default), the grouped split-K launches of
+    # round 3 (HX_WGRAD_MULTI=0), one launch per layer (HX_WGRAD_MULTI=0 HX_WGRAD_GROUP=0): three ways to cut the same reductions
+    for other in ({"HX_WGRAD_MULTI": "0"}, {"HX_WGRAD_MULTI": "0", "HX_WGRAD_GROUP": "0"}, {"HX_HEAD_MFMA": "0"}):
         alt = run(other)
         assert abs(base[0][0] - alt[0][0]) < 1e-5 * max(1.0, abs(base[0][0])) and abs(base[0][1] - alt[0][1]) < 1e-5, other
         assert base[1] == alt[1], other
         for k in base[2]:
             d = np.abs(base[2][k] - alt[2][k])
-            assert d.max() < 2e-6 and np.mean(d > 2e-7) < 1e-2, (other, k, float(d.max()), float(np.mean(d > 2e-7)))
+            assert d.max() < 5e-6 and np.mean(d > 2e-7) < 1e-2, (other, k, float(d.max()), float(np.mean(d > 2e-7)))
 
 
 def test_launch_profiler_rows_and_sampling(hxlib):
@@ -283,8 +285,8 @@ def test_launch_profiler_rows_and_sampling(hxlib):
     alg.prof_begin()
     iteration()
     full = {k["name"]: k for k in alg.prof_end()["kernels"]}
-    grouped = [n for n in full if n.startswith("hx_gemm_group_kernel<") and n.endswith(", 2, true>")]
-    assert len(grouped) == 1, sorted(full)                      # the weight-gradient groups: 2 epochs x 4 minibatches, >= 1 launch each
+    grouped = [n for n in full if n == "hx_wgrad_multi_kernel"]
+    assert len(grouped) == 1, sorted(full)                      # the weight gradients: 2 epochs x 4 minibatches, >= 1 launch each
     sym = grouped[0]
     total = full[sym]["launches"]
     assert total >= 8 and full[sym]["flops"] > 0 and full[sym]["ms"] > 0
