@@ -151,7 +151,7 @@ def cpu_baseline(sample_envs=4096, sample_steps=60, terrain="trimesh", update_ro
     def run(code, threads, **extra):
         env = dict(os.environ, OMP_WAIT_POLICY="passive", **extra)
         env["OMP_NUM_THREADS"] = str(threads if threads else ncpu)          # "all cores" = all this job may use (host_cpus)
-        out = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True, timeout=240)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
         if out.returncode != 0:
             raise RuntimeError(out.stderr[-600:])
         return json.loads(out.stdout.strip().splitlines()[-1])
@@ -179,16 +179,40 @@ def spawn_ranks(n):
     initialises HIP (no capi / build call has happened yet).  Rank 0's stdout -- the one JSON line -- is relayed to ours,
     every other stream goes to stderr.  A rank that dies takes the job down: the others are given 20 s to notice (their
     collectives time out by themselves, include/hx_ppo.h) and are then terminated.  Exit code = the first non-zero one."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # Build once, here: hipcc / make only -- nothing in isaac_amd.build or oracle.host.build touches HIP -- so the ranks find
+    # current binaries and skip their own build (ISAAC_BENCH_PREBUILT).
+    from isaac_amd import build as hx_build
+    hx_build.build()
+    try:
+        import shutil
+        if shutil.which("g++") and shutil.which("make"):
+            from oracle.host import build as build_host
+            build_host()
+    except Exception as e:
+        print(f"warning: host build of the oracle failed ({e!r})", file=sys.stderr)
+    # The rendezvous store lives in this process for the whole job (a launcher-style agent store, as under
+    # torch.distributed.run): port 0 = the kernel picks a free port and this process keeps it, so no rank can lose a race for it.
+    # Importing torch.distributed initialises no GPU.
+    port, store = None, None
+    if os.environ.get("HX_BENCH_CHILD_PROBE", "store") == "store":
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        store = TCPStore("127.0.0.1", 0, n, True, timeout=timedelta(seconds=300), wait_for_workers=False)
+        port = store.port
+    else:                                   # the CPU probe test needs no store (and no torch import)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)         # no launcher agent here: rank 0 serves the rendezvous store
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ISAAC_BENCH_PREBUILT="1")
+        if store is not None:
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "True"     # every rank is a client of the store above (isaac_amd/parallel.py exchange_unique_id)
+        else:
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
     out0 = []
@@ -245,8 +269,13 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))          # launcher mode: nothing below runs in this process
-    if os.environ.get("HX_BENCH_CHILD_PROBE"):            # tests/test_host_logic.py: what a spawned rank sees, without a GPU
-        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}), flush=True)
+    if os.environ.get("HX_BENCH_CHILD_PROBE"):            # tests/test_parallel_cpu.py: what a spawned rank sees, without a GPU
+        seen = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ISAAC_BENCH_PREBUILT", "TORCHELASTIC_USE_AGENT_STORE")}
+        if os.environ.get("HX_BENCH_CHILD_PROBE") == "store":          # the unique-id rendezvous against the launcher's store, as HxComm does it
+            from isaac_amd.parallel import exchange_unique_id
+            rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+            seen["ID"] = exchange_unique_id(rank, world, lambda: bytes([7 + rank]) * 128, "probe_uid").hex()[:8]
+        print(json.dumps(seen), flush=True)
         if os.environ.get("HX_BENCH_CHILD_PROBE") == "fail" + os.environ.get("RANK", ""):
             raise SystemExit(3)
         if os.environ.get("HX_BENCH_CHILD_PROBE", "").startswith("fail"):
@@ -261,8 +290,9 @@ def main():
     os.dup2(2, 1)
     real_stdout = os.fdopen(real_fd, "w")
     sys.stdout = sys.stderr
-    import __graft_entry__
-    __graft_entry__.build()
+    if os.environ.get("ISAAC_BENCH_PREBUILT") != "1":        # a rank started by spawn_ranks: the parent has built everything
+        import __graft_entry__
+        __graft_entry__.build()
     from isaac_amd import capi
     from isaac_amd.parallel import init_comm
     from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO, HectorFullCfg, HectorFullCfgPPO, XBotLCfg, XBotLCfgPPO
@@ -341,6 +371,8 @@ def main():
     env.sync()
     comm.barrier()
     elapsed = time.perf_counter() - t0
+    # per-iteration times as the runner's own clock saw them (collection + learning): the median beside the mean
+    iter_s = sorted(getattr(runner, "iteration_times", [])[-args.steps:])
     prof = None if args.no_prof else runner.alg.prof_end()
     if time_env:
         env_step_ms = np.zeros(2, np.float64)
@@ -354,6 +386,7 @@ def main():
         dims = lambda d: "[" + ",".join(str(x) for x in d) + "]"
         out = {"metric": f"env-steps/sec (whole node), {args.task} {args.envs} envs/GPU", "value": value, "unit": "env-steps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+               "ms_per_step_median": (1e3 * iter_s[len(iter_s) // 2]) if iter_s else None,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": f"{args.task} {args.envs} envs/GPU, 1 iteration = 60 env steps (10 x 1 ms substeps) + PPO "
                                       f"update {train_cfg.algorithm.num_learning_epochs} epochs x {train_cfg.algorithm.num_mini_batches} minibatches, fp32 HIP sim + MLP actor {dims(train_cfg.policy.actor_hidden_dims)} / "

@@ -85,6 +85,7 @@ class OnPolicyRunner:
         self.tot_time = 0
         self.current_learning_iteration = 0
         self.last_perf = {}
+        self.iteration_times = []       # collection + learning seconds of every iteration run so far (bench.py: median beside the mean)
         self.env.reset()
 
     # ------------------------------------------------------------------ training loop
@@ -131,6 +132,7 @@ class OnPolicyRunner:
             learn_time = stop - start
             self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
                                   fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
+            self.iteration_times.append(collection_time + learn_time)
             if self.collect_stats:
                 ep_info, n_ep = self._episode_stats_all_ranks()
                 self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,
@@ -165,6 +167,7 @@ class OnPolicyRunner:
             learn_time = stop - start
             self.last_perf = dict(collection_time=collection_time, learn_time=learn_time,
                                   fps=self.num_steps_per_env * env.num_envs / (collection_time + learn_time))
+            self.iteration_times.append(collection_time + learn_time)
             if self.collect_stats:
                 ep_info, n_ep = self._episode_stats_all_ranks()
                 self.log(dict(it=it, tot_iter=tot_iter, collection_time=collection_time, learn_time=learn_time,

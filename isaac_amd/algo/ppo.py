@@ -282,11 +282,20 @@ class PPO:
             e.common_step_counter += steps
             e._refresh_views()
 
+    def _sync(self, stream):
+        """Host wait on a stream that may carry this learner's collectives: through the communicator's deadline when RCCL runs
+        inside the library (hx_comm_wait aborts after HX_COMM_TIMEOUT_S), a plain stream synchronisation otherwise."""
+        h = getattr(self.comm, "_h", None) if getattr(self.comm, "in_library", False) else None
+        if h:
+            capi.check(self._L.hx_comm_wait(h, stream, 0.0), "hx_comm_wait")
+        else:
+            capi.check(self._L.hx_sync(stream), "sync")
+
     def compute_returns_shards(self, shard_priv):
         """shard_priv: list of (critic_obs, env0, count, stream)."""
         for priv, env0, count, stream in shard_priv:
             capi.check(self._L.hx_ppo_last_values_range(self._h, device_pointer(priv)[0], env0, count, stream), "last_values_range")
-            capi.check(self._L.hx_sync(stream), "sync")
+            self._sync(stream)
         capi.check(self._L.hx_ppo_compute_returns(self._h, None), "hx_ppo_compute_returns")
         if self._distributed() and not getattr(self.comm, "in_library", False):
             m = capi.C.c_void_p()

@@ -12,7 +12,31 @@
 // carries collectives) after HX_COMM_TIMEOUT_S, both with an error string and a non-zero return.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>      // types, enums and NCCL_VERSION_CODE of the RCCL this library was compiled against (no link dependency)
+#else
+// A ROCm install without the RCCL development headers still builds the (default, single-GPU) library: the slice of the NCCL 2.x
+// API used below, as published in rccl.h (stable within the major version, which load_rccl() checks at run time).
+#define NCCL_MAJOR 2
+#define NCCL_VERSION_CODE 20000
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5,
+               ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+extern "C" {
+ncclResult_t ncclGetVersion(int*);
+ncclResult_t ncclGetUniqueId(ncclUniqueId*);
+ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclCommAbort(ncclComm_t);
+ncclResult_t ncclCommGetAsyncError(ncclComm_t, ncclResult_t*);
+ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclBroadcast(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+const char* ncclGetErrorString(ncclResult_t);
+}
+#endif
 #include <unistd.h>
 #include <atomic>
 #include <chrono>
@@ -176,6 +200,8 @@ extern "C" int hx_comm_broadcast(hx_comm* c, void* buf, size_t count_f32, int ro
 extern "C" int hx_comm_wait(hx_comm* c, void* stream, double timeout_s) {
   hipStream_t st = (hipStream_t)stream;
   if (!c) { HX_CHECK(hipStreamSynchronize(st)); return 0; }
+  // an aborted communicator has no handle left to query or to abort again: every later wait on it fails at once
+  if (c->dead || !c->comm) { hx_set_error("hx_comm_wait: communicator was aborted after a time-out or an RCCL error (rank " + std::to_string(c->rank) + ")"); return -12; }
   const double limit = timeout_s > 0.0 ? timeout_s : c->timeout_s;
   const auto t0 = std::chrono::steady_clock::now();
   long spins = 0;

@@ -79,8 +79,11 @@ __device__ __forceinline__ void hx_pause_poll(const int* p, int& seen) {
   while (seen > 0 && budget > 0) { --budget; __builtin_amdgcn_s_sleep(64); seen = *reinterpret_cast<const volatile int*>(p); }
   seen = (budget > 0) ? hx_pause_load(p) : -1;
 }
+// `paused_io` (POLL instantiations): the workgroup's pause state, kept by the persistent kernel ACROSS its tiles -- a workgroup that
+// ran out of its sleep budget once (-1) never waits again, in this tile or any later one, so a lost decrement of the flag costs
+// one bounded wait per workgroup and launch, not one per tile
 template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL, bool GA = false, bool GB = false, bool POLL = false>
-__device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logical, float* __restrict__ lds) {
+__device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logical, float* __restrict__ lds, int* paused_io = nullptr) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // per-wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
   constexpr int A_ELEMS = GemmLds<BM, BN, HX_BK, A_KM, B_KM>::A_ELEMS;
@@ -304,7 +307,7 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
     if (nk > 1) load_tile(1);
     __syncthreads();
     read_frags(0, 0, f0);
-    int paused = 0;
+    int paused = (POLL && paused_io) ? *paused_io : 0;
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (POLL && g.pause != nullptr) hx_pause_poll(g.pause, paused);
@@ -317,6 +320,7 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
       if (kt + 1 < nk) read_frags(cur ^ 1, 0, f0);
       mfma_half(f1);
     }
+    if (POLL && paused_io) *paused_io = paused;
   }
 
   auto compute = [&](int buf, int kt) {
@@ -366,7 +370,7 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
     load_tile(0);
     store_tile(0);
     __syncthreads();
-    int paused = 0;
+    int paused = (POLL && paused_io) ? *paused_io : 0;
     for (int kt = 0; kt < nk; ++kt) {
       const bool more = (kt + 1 < nk);
       if (POLL && g.pause != nullptr) hx_pause_poll(g.pause, paused);
@@ -375,6 +379,7 @@ __device__ __forceinline__ void hx_gemm_tile(const GemmArgs& g, const int logica
       if (more) store_tile((kt + 1) & 1);
       __syncthreads();
     }
+    if (POLL && paused_io) *paused_io = paused;
   }
 
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -520,8 +525,9 @@ __global__ void __launch_bounds__(256) HX_GEMM_OCC hx_gemm_group_kernel(GemmGrou
 template <int BM, int BN, int HX_BK, bool A_KM, bool B_KM, int EPI, bool KFULL = false, bool GA = false, bool GB = false>
 __global__ void __launch_bounds__(256) hx_gemm_persistent_kernel(GemmArgs g, int total_tiles) {
   __shared__ __attribute__((aligned(16))) float lds[GemmLds<BM, BN, HX_BK, A_KM, B_KM>::FLOATS];
+  int paused = 0;
   for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB, true>(g, t, lds);
+    hx_gemm_tile<BM, BN, HX_BK, A_KM, B_KM, EPI, KFULL, GA, GB, true>(g, t, lds, &paused);
     __syncthreads();          // the next tile's first LDS stores must not overtake this tile's last fragment reads
   }
 }

@@ -1161,6 +1161,14 @@ struct hx_ppo {
   std::vector<void*> allocs;
 };
 
+// every host wait on the learner's stream: with a communicator the stream may carry a collective whose peer is gone, so the wait
+// has the communicator's deadline (hx_comm_wait: abort + error after HX_COMM_TIMEOUT_S), never an unbounded hipStreamSynchronize
+static int learner_sync(hx_ppo* s) {
+  if (s->comm) return hx_comm_wait(s->comm, s->stream, 0.0);
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
 template <typename T> static int palloc(hx_ppo* s, T** ptr, size_t count) {
   HX_CHECK(hipMalloc((void**)ptr, count * sizeof(T)));
   HX_CHECK(hipMemsetAsync(*ptr, 0, count * sizeof(T), s->stream));
@@ -1413,7 +1421,7 @@ static int wgrad_plan_for(hx_ppo* s, const WgradLayerDesc* wl, int M, const Wgra
   }
   const WgradPlan& p = it->second;
   if (p.slab_floats > s->wslab_floats || p.bslab_floats > s->wbslab_floats) {
-    HX_CHECK(hipStreamSynchronize(s->stream));
+    if (int rc = learner_sync(s)) return rc;
     if (s->wslab) (void)hipFree(s->wslab);
     if (s->wbslab) (void)hipFree(s->wbslab);
     s->wslab = s->wbslab = nullptr; s->wslab_floats = s->wbslab_floats = 0;
@@ -1790,6 +1798,9 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     if (cfg->obs_frame * cfg->obs_stack != cfg->num_obs || cfg->priv_frame * cfg->priv_stack != cfg->num_priv || cfg->obs_frame < 1 || cfg->priv_frame < 1) {
       hx_set_error("hx_ppo_create: frame storage needs obs_frame * obs_stack == num_obs and priv_frame * priv_stack == num_priv"); return -2;
     }
+    // the per-row "frames since reset" count saturates at obs_stack and the privileged rows' zero prefix is derived from the same
+    // count (hx_env.h env_glue, hx_stack_io_kernel): a longer privileged stack would keep its oldest frames masked for ever
+    if (cfg->priv_stack > cfg->obs_stack) { hx_set_error("hx_ppo_create: frame storage needs priv_stack <= obs_stack (the reset age is counted up to obs_stack)"); return -2; }
     s->fo = cfg->obs_frame; s->fp = cfg->priv_frame; s->So = cfg->obs_stack; s->Sp = cfg->priv_stack; s->Po = T + s->So; s->Pp = T + s->Sp;
     const size_t no = (size_t)N * s->Po * s->fo, np = (size_t)N * s->Pp * s->fp;
     if (no + 64 >= (1ull << 31) || np + 64 >= (1ull << 31)) { hx_set_error("hx_ppo_create: frame rings beyond 2^31 floats (row starts are 32-bit offsets)"); return -2; }
@@ -1982,13 +1993,13 @@ static void unpack_padded(hx_ppo* s, const std::vector<float>& pad, float* flat)
 }
 static int upload_flat(hx_ppo* s, float* dst, const float* flat) {
   std::vector<float> pad; pack_padded(s, flat, pad);
-  HX_CHECK(hipStreamSynchronize(s->stream));
+  if (int rc = learner_sync(s)) return rc;
   HX_CHECK(hipMemcpy(dst, pad.data(), s->padded * sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }
 static int download_flat(hx_ppo* s, const float* src, float* flat) {
   std::vector<float> pad(s->padded);
-  HX_CHECK(hipStreamSynchronize(s->stream));
+  if (int rc = learner_sync(s)) return rc;
   HX_CHECK(hipMemcpy(pad.data(), src, s->padded * sizeof(float), hipMemcpyDeviceToHost));
   unpack_padded(s, pad, flat);
   return 0;
@@ -2567,7 +2578,7 @@ extern "C" int hx_ppo_get_lr(hx_ppo* s, float* lr) {
 }
 extern "C" int hx_ppo_set_lr(hx_ppo* s, float lr) {
   HX_CHECK(hipMemcpyAsync(&s->sched->lr, &lr, sizeof(float), hipMemcpyHostToDevice, s->stream));
-  HX_CHECK(hipStreamSynchronize(s->stream));
+  if (int rc = learner_sync(s)) return rc;
   return 0;
 }
 
@@ -2613,7 +2624,7 @@ extern "C" int hx_ppo_prof_begin(hx_ppo* s, const char* only_symbol, int sample_
 extern "C" int hx_ppo_prof_end(hx_ppo* s, hx_prof_row* rows, int max_rows, int* n_rows) {
   if (!s || !n_rows) { hx_set_error("hx_ppo_prof_end: null argument"); return -2; }
   s->prof = false;
-  HX_CHECK(hipStreamSynchronize(s->stream));
+  if (int rc = learner_sync(s)) return rc;
   std::vector<double> ms(prof_names().size(), 0.0);
   for (size_t i = 0; i + 1 < s->ev_used; i += 2) { float t = 0; HX_CHECK(hipEventElapsedTime(&t, s->ev[i], s->ev[i + 1])); if ((size_t)s->ev_kid[i] < ms.size()) ms[s->ev_kid[i]] += t; }
   int n = 0;
@@ -2681,6 +2692,9 @@ static int rollout_frames(hx_ppo* p, hx_sim* sim, int steps) {
 
 extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const int32_t* count, int nshards, int steps) {
   const int N = p->cfg.num_envs, T = p->cfg.num_steps;
+  // the count of fused-actor workgroups in flight starts every rollout at zero: a decrement lost to an aborted launch cannot
+  // outlive the iteration (the background critic's bounded wait, hx_pause_poll, would otherwise be paid again every flush)
+  if (p->pause_flag && p->step == 0) HX_CHECK(hipMemsetAsync(p->pause_flag, 0, sizeof(int), p->stream));
   if (p->frames) {
     if (nshards != 1 || count[0] != N) { hx_set_error("hx_rollout: single-frame storage takes one simulator with all of the learner's robots"); return -2; }
     return rollout_frames(p, sims[0], steps);

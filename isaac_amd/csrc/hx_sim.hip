@@ -365,6 +365,8 @@ static int sim_create_impl(const hx_sim_cfg* cfg, const float* friction_h, const
   s->L = SLay(s->nd);
   s->obs_f = 11 + 3 * s->nd; s->priv_f = (s->nd == HX_XBOT_DOF ? 37 : 40) + 3 * s->nd;
   s->priv_stack = (s->nd == HX_XBOT_DOF) ? 3 : HX_FRAME_STACK;
+  static_assert(HX_FRAME_STACK >= 3, "the privileged stack (15 or 3 frames) never exceeds the observation stack: the reset age saturates at HX_FRAME_STACK");
+  if (s->priv_stack > HX_FRAME_STACK) { hx_set_error("hx_sim_create: priv_stack > HX_FRAME_STACK"); return -2; }
   s->obs_ld = (HX_FRAME_STACK * s->obs_f + 3) / 4 * 4; s->priv_ld = (s->priv_stack * s->priv_f + 3) / 4 * 4;
   s->seed = seed;
   s->step_counter = 0;

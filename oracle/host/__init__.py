@@ -15,8 +15,16 @@ _libs = {}
 
 
 def build(asan=False):
+    """Serialised across processes (flock): every rank of a job started by a launcher may call this at the same time."""
+    import fcntl
     target = "asan" if asan else "all"
-    subprocess.check_call(["make", "-s", "-C", _HERE, target])
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-s", "-C", _HERE, target])
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return os.path.join(OUT_DIR, "libhx_host_asan.so" if asan else "libhx_host.so")
 
 

@@ -4,7 +4,10 @@ import numpy as np
 # Tolerances of one teacher-forced env step (10 substeps of the fp32 articulated-body algorithm against the float64
 # joint-space oracle), per (step, robot) pair.
 #   tight  : holds for every pair except a COUNTED handful per fixture (OVER_TIGHT below: the measured count + a margin of 3);
-#   loose  : holds for every pair, set just above the worst value measured on any fixture.
+#   loose  : holds for every pair: PER FIXTURE, 1.5 x the worst pair measured on it (WORST below), and never under 3 x the tight
+#            bound -- the band in which the MARGIN pairs that another box may push over the tight bound have to stay.
+#            A fixture or quantity that is not listed has no measured exception: its worst pair is held to that band.
+#            (STEP_TOL's second entries are the round-3 global loose tier, kept as the cap for labels measured elsewhere.)
 # Since round 3 the contact model has no activation jump (a point inside the contact offset is damped on the part of its
 # approach speed that would carry it through the surface: force and its onset are continuous in the state), so the former
 # "a contact switched one substep earlier in fp32" pairs -- up to 1 % of all pairs, with errors of 0.1-0.3 in observations,
@@ -29,6 +32,25 @@ OVER_TIGHT = {
 }
 MARGIN = 3
 
+# worst (step, robot) pair measured per fixture and quantity, where it exceeds the tight bound (round 4: gpurun_out/r04_j/01_gputests.log
+# for the HIP kernel on MI355X, `pytest tests/test_host_build.py -s` in the build container for the host build)
+WORST = {
+    "env_rollout_a host build": dict(obs=1.9e-1, priv=1.9e-1, tau=2.3),
+    "env_rollout_c host build": dict(obs=2.2e-4, rew=3.0e-5),
+    "env_rollout_h host build": dict(rew=2.5e-3),
+    "env_rollout_a HIP kernel": dict(obs=1.9e-1, priv=1.9e-1, tau=2.3),
+    "env_rollout_c HIP kernel": dict(obs=3.9e-3, priv=3.9e-3, rew=3.1e-5, tau=1.8e-1, contact=2.0),
+    "env_rollout_d HIP kernel": dict(obs=6.4e-4),
+    "env_rollout_h HIP kernel": dict(rew=2.5e-3),
+    "terrain contact, HIP kernel vs oracle": dict(obs=3.8e-2, priv=3.8e-2, rew=3.8e-4, tau=1.9, contact=18.0),
+}
+LOOSE_FACTOR = 1.5
+
+
+def loose_bound(label, k, tol=STEP_TOL):
+    tight, cap = tol[k]
+    return min(cap, max(3.0 * tight, LOOSE_FACTOR * WORST.get(label, {}).get(k, 0.0)))
+
 
 def check_step_errors(label, errs, tol=STEP_TOL, over_tight=None):
     """errs[k]: list over steps of per-robot errors.  Asserts the COUNT of (step, robot) pairs over the tight bound against
@@ -44,4 +66,5 @@ def check_step_errors(label, errs, tol=STEP_TOL, over_tight=None):
         e = np.concatenate([np.asarray(x, np.float64).reshape(-1) for x in errs[k]])
         over = int((e > tight).sum())
         assert over <= allowed.get(k, 0) + MARGIN, f"{label}: {k}: {report[k]} (allowed {allowed.get(k, 0)} + {MARGIN})"
-        assert e.max() <= loose, f"{label}: {k}: {report[k]}"
+        lb = loose if over_tight is not None else loose_bound(label, k, tol)
+        assert e.max() <= lb, f"{label}: {k}: {report[k]} (bound for the worst pair {lb:.3g})"

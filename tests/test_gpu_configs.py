@@ -79,11 +79,13 @@ def test_config1_64_envs_full_iteration_against_oracle(hxlib):
     print("config 1 per-pair errors: worst", worst, "pairs over the tight bound", over, "of", e["obs"].size)
     # measured on MI355X: 23 / 30 / 3 of 3840 pairs (a full 615-wide row keeps an event for 15 steps), worst 1.2e-4 / 6.1e-3 / 2.3e-4
     assert over["act"] <= 28 and over["obs"] <= 35 and over["rew"] <= 8, (over, worst)
-    assert worst["act"] < 1e-3 and worst["obs"] < 0.4 and worst["rew"] < 5e-3, worst
+    # the worst pair: 1.5 x the measured worst (round 3's 1e-3 / 0.4 / 5e-3 were the global loose tier)
+    assert worst["act"] < 1.8e-4 and worst["obs"] < 9.2e-3 and worst["rew"] < 3.6e-4, worst
     alg.compute_returns(priv)
     ref.compute_returns(p2)
-    np.testing.assert_allclose(alg.buffer(4, (T, n)).numpy(), ref.rewards, rtol=0, atol=3e-3)        # incl. the (stale) time-out bootstrap
-    np.testing.assert_allclose(alg.buffer(6, (T, n)).numpy(), ref.advantages, rtol=0, atol=3e-2)
+    # whole arrays at 1.5 x the measured maximum (2.35e-4 / 9.9e-4 on MI355X; printed below); rewards include the (stale) time-out bootstrap
+    np.testing.assert_allclose(alg.buffer(4, (T, n)).numpy(), ref.rewards, rtol=0, atol=3.6e-4)
+    np.testing.assert_allclose(alg.buffer(6, (T, n)).numpy(), ref.advantages, rtol=0, atol=1.5e-3)
     perm = rng.permutation(n * T).astype(np.int32)
     vl, sl = alg.update(perm=perm)
     vl2, sl2 = ref.update(perm)

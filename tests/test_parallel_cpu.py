@@ -157,3 +157,20 @@ def test_bench_self_spawn_relays_rank0_and_propagates_failure():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 3 and time.time() - t0 < 60
+
+
+def test_bench_launcher_serves_the_rendezvous_store_for_eight_ranks():
+    """The self-spawning parent builds once (children see ISAAC_BENCH_PREBUILT), keeps the rendezvous port for the whole job (it
+    serves the TCPStore itself, so no rank can lose a bind race) and every one of 8 children reads rank 0's unique id from it."""
+    import json
+    env = dict(os.environ, HX_BENCH_CHILD_PROBE="store")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(l) for l in (r.stdout + r.stderr).splitlines() if l.startswith("{") and '"RANK"' in l]
+    assert sorted(int(d["RANK"]) for d in rows) == list(range(8))
+    assert all(d["ISAAC_BENCH_PREBUILT"] == "1" and d["TORCHELASTIC_USE_AGENT_STORE"] == "True" for d in rows)
+    assert len({d["MASTER_PORT"] for d in rows}) == 1
+    assert all(d["ID"] == "07070707" for d in rows)          # rank 0's bytes reached every rank
