@@ -44,7 +44,12 @@ int hx_mfma_probe(int mode, int blocks, int n, float* tflops_out);
 int hx_sim_time(hx_sim* s, int which, double* out_h /*[2]*/);
 /* per-phase shader-clock cycles of the env-step kernel, summed over waves and launches; meaningful only in a library
  * built with -DHX_STEP_PROF (tools/step_prof.py), all zeros otherwise.  which = 1 start / clear, 0 read. */
-int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[15]: 9 phase timers, then shape-visit counts*/);
+int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[18]: 9 phase timers, shape-visit counts [9..14], unused, then the sums over waves of the shader-clock
+                                                           and of the 100 MHz wall-clock ticks a wave lived: their ratio x 0.1 = the kernel's clock in GHz*/);
+
+/* lifetimes of the first n env-step waves (wave w = robots 8w .. 8w+7), 100 MHz ticks summed over the launches since hx_sim_prof(s, 1, ..);
+ * -DHX_STEP_PROF builds (tools/env_clock.py: which waves make a launch as long as it is) */
+int hx_sim_prof_waves(hx_sim* s, long long* out_h, int n);
 
 #ifdef __cplusplus
 }

@@ -189,11 +189,22 @@ HXD SV rb_bias(const SI& in, V3 hh, float m, SV v) {
 // vertices the reference moved under the high ones (slope_treshold, utils/terrain.py:70-73): the low ground continues
 // flat through the cell and a vertical wall stands on the high vertices' grid line.  Such a cell returns its low level
 // here; the wall itself is handled by wall_push() for points that have crossed it.
-HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls) {
+#ifndef HX_PT_GROUP
+#define HX_PT_GROUP 2      // points of a shape that a lane takes through the contact stages together
+#endif
+struct TerrainCell { float h00, h01, h10, h11, fu, fw; };
+// the four corner heights of the cell under (u, w) and the position inside it: the LDS reads of a query, apart from its arithmetic
+HXD TerrainCell terrain_fetch(const DynParams& P, float u, float w) {
   const int i = hx_imin(hx_imax((int)floorf(u), 0), HX_PATCH - 2), j = hx_imin(hx_imax((int)floorf(w), 0), HX_PATCH - 2);
-  const float fu = fminf(fmaxf(u - (float)i, 0.f), 1.f), fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
-  const float* c = P.patch + i * HX_PATCH + j;
-  float h00 = c[0], h01 = c[1], h10 = c[HX_PATCH], h11 = c[HX_PATCH + 1];
+  TerrainCell c;
+  c.fu = fminf(fmaxf(u - (float)i, 0.f), 1.f); c.fw = fminf(fmaxf(w - (float)j, 0.f), 1.f);
+  const float* g = P.patch + i * HX_PATCH + j;
+  c.h00 = g[0]; c.h01 = g[1]; c.h10 = g[HX_PATCH]; c.h11 = g[HX_PATCH + 1];
+  return c;
+}
+HXD float terrain_eval(const DynParams& P, const TerrainCell& c, V3& nw, bool walls) {
+  float h00 = c.h00, h01 = c.h01, h10 = c.h10, h11 = c.h11;
+  const float fu = c.fu, fw = c.fw;
   if (hx_any(walls) && !(P.tflags & 1)) {
     const float lo = fminf(fminf(h00, h01), fminf(h10, h11));
     if (fmaxf(fmaxf(h00, h01), fmaxf(h10, h11)) - lo > P.wall) {
@@ -210,6 +221,10 @@ HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls
   const float inv = 1.0f / sqrtf(nx * nx + ny * ny + 1.0f);
   nw = mk(nx * inv, ny * inv, inv);
   return h00 + fu * gu + fw * gw;
+}
+HXD float terrain_query(const DynParams& P, float u, float w, V3& nw, bool walls) {
+  const TerrainCell c = terrain_fetch(P, u, w);
+  return terrain_eval(P, c, nw, walls);
 }
 
 // A point below the surface of a plateau may have entered it sideways through a wall.  If one of the four sides of its
@@ -326,55 +341,88 @@ HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const Con
   float Axx = 0.f, Axy = 0.f, Axz = 0.f, Ayy = 0.f, Ayz = 0.f, Azz = 0.f, Mxx = 0.f, Mxy = 0.f, Mxz = 0.f, Myy = 0.f, Myz = 0.f, Mzz = 0.f;
   M3 H = m3zero();
   float any_on = 0.f;
+  // The lane's points in groups of HX_PT_GROUP (device: a lane owns <= 3 of a shape's points, i.e. one or two groups), every group in
+  // STAGES that each issue the LDS reads of all its points before anything waits for one of them: point coordinates -> pooled
+  // bounds and cliff flags -> one ballot -> corner heights -> forces.  One point at a time (round 3) made every link of that chain
+  // an exposed LDS round trip per point: 9 per foot shape and lane instead of 3 (profiles/r03_n_env_step_stalls.txt).  The
+  // ballots only skip work nobody needs, so the sums -- taken in point order as before -- are the same.
 #pragma unroll 1
-  for (int k = P.pt0; k < npts; k += P.ptstep) {
-    const V3 r = ld3(pts + 3 * k);
-    const float z = pb.z + dot(zb, r);
-    V3 nb = zb;
-    float pen = -z;
-    if (P.patch != nullptr) {
-      const float u = (pb.x + dot(row(Rb, 0), r) - P.px0) * P.inv_hs, w = (pb.y + dot(row(Rb, 1), r) - P.py0) * P.inv_hs;
-      const int pi = terrain_pool_index(u, w);
-      if (!hx_any(z < P.pool[pi] + P.coff)) continue;
-      const bool walls = P.poolw[pi] != 0.f;         // never set without walls (P.wall = 0)
-      V3 nw;
-      const float h = terrain_query(P, u, w, nw, walls);
-      pen = (h - z) * nw.z;
-      if (hx_any(walls && pen > 0.f) && !(P.tflags & 2)) {
-        float wp = pen; V3 wn = nw;
-        if (walls && pen > 0.f && wall_push(P, u, w, z, wp, wn)) { pen = wp; nw = wn; }
+  for (int k0 = P.pt0; k0 < npts; k0 += HX_PT_GROUP * P.ptstep) {
+    V3 r[HX_PT_GROUP]; float z[HX_PT_GROUP], u[HX_PT_GROUP], w[HX_PT_GROUP]; int pi[HX_PT_GROUP]; bool valid[HX_PT_GROUP], near_[HX_PT_GROUP];
+#pragma unroll
+    for (int j = 0; j < HX_PT_GROUP; ++j) {
+      const int k = k0 + j * P.ptstep;
+      valid[j] = k < npts;
+      r[j] = ld3(pts + 3 * (valid[j] ? k : k0));
+    }
+#pragma unroll
+    for (int j = 0; j < HX_PT_GROUP; ++j) {
+      z[j] = pb.z + dot(zb, r[j]);
+      u[j] = 0.f; w[j] = 0.f; pi[j] = 0;
+      if (P.patch != nullptr) {
+        u[j] = (pb.x + dot(row(Rb, 0), r[j]) - P.px0) * P.inv_hs; w[j] = (pb.y + dot(row(Rb, 1), r[j]) - P.py0) * P.inv_hs;
+        pi[j] = terrain_pool_index(u[j], w[j]);
       }
-      nb = mulT(Rb, nw);
-    } else if (!hx_any(z < P.coff)) continue;
-    const V3 vp = v.v + cross(v.w, r);
-    const float vn = dot(vp, nb);
-    // normal force = capped spring on the penetration - damper on the closing speed; outside the surface but inside the
-    // contact offset only the speed in excess of gap / dt is damped (DynParams::coff, ::vdep)
-    pen += P.roff;
-    const float spring = P.kn * fmaxf(pen, 0.f);
-    const float fn0 = ((P.vdep > 0.f) ? fminf(spring, c_n * P.vdep) : spring) - c_n * (vn + fmaxf(-pen, 0.f) * P.inv_dt);
-    const bool act = (pen > -P.coff) && (fn0 > 0.f);
-    if (!hx_any(act)) continue;
-    const V3 vt = vp - vn * nb;
-    const float vtn = sqrtf(dot(vt, vt));
-    const float c_t = P.mu * fn0 / fmaxf(vtn, P.veps);
-    const float on = act ? 1.f : 0.f;
-    any_on = fmaxf(any_on, on);
-    const V3 f = on * (fn0 * nb - c_t * vt);
-    const float alpha = on * P.dt * c_t, beta = on * P.dt * (c_n - c_t);
-    f0.v = f0.v + f;
-    f0.w = f0.w + cross(r, f);
-    const V3 m = cross(r, nb);
-    const float rr = dot(r, r);
-    // A += alpha (|r|^2 1 - r r^T) + beta m m^T ; H += alpha rx + beta m n^T ; M += alpha 1 + beta n n^T
-    Axx += alpha * (rr - r.x * r.x) + beta * m.x * m.x; Axy += -alpha * r.x * r.y + beta * m.x * m.y; Axz += -alpha * r.x * r.z + beta * m.x * m.z;
-    Ayy += alpha * (rr - r.y * r.y) + beta * m.y * m.y; Ayz += -alpha * r.y * r.z + beta * m.y * m.z; Azz += alpha * (rr - r.z * r.z) + beta * m.z * m.z;
-    H.m[1] += -alpha * r.z; H.m[2] += alpha * r.y;
-    H.m[3] += alpha * r.z;  H.m[5] += -alpha * r.x;
-    H.m[6] += -alpha * r.y; H.m[7] += alpha * r.x;
-    addouter(H, beta, m, nb);
-    Mxx += alpha + beta * nb.x * nb.x; Mxy += beta * nb.x * nb.y; Mxz += beta * nb.x * nb.z;
-    Myy += alpha + beta * nb.y * nb.y; Myz += beta * nb.y * nb.z; Mzz += alpha + beta * nb.z * nb.z;
+    }
+    float bound[HX_PT_GROUP], cliff[HX_PT_GROUP];
+    bool any_near = false;
+#pragma unroll
+    for (int j = 0; j < HX_PT_GROUP; ++j) { bound[j] = 0.f; cliff[j] = 0.f; if (P.patch != nullptr) { bound[j] = P.pool[pi[j]]; cliff[j] = P.poolw[pi[j]]; } }
+#pragma unroll
+    for (int j = 0; j < HX_PT_GROUP; ++j) { near_[j] = valid[j] && (z[j] < bound[j] + P.coff); any_near = any_near || near_[j]; }
+    if (!hx_any(any_near)) continue;
+    TerrainCell cell[HX_PT_GROUP];
+    if (P.patch != nullptr) {
+#pragma unroll
+      for (int j = 0; j < HX_PT_GROUP; ++j) cell[j] = terrain_fetch(P, u[j], w[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < HX_PT_GROUP; ++j) {
+      if (!hx_any(near_[j])) continue;            // nobody's point j is inside its bound (uniform)
+      V3 nb = zb;
+      float pen = -z[j];
+      if (P.patch != nullptr) {
+        const bool walls = cliff[j] != 0.f;         // never set without walls (P.wall = 0)
+        V3 nw;
+        const float h = terrain_eval(P, cell[j], nw, walls);
+        pen = (h - z[j]) * nw.z;
+        if (hx_any(valid[j] && walls && pen > 0.f) && !(P.tflags & 2)) {
+          float wp = pen; V3 wn = nw;
+          if (valid[j] && walls && pen > 0.f && wall_push(P, u[j], w[j], z[j], wp, wn)) { pen = wp; nw = wn; }
+        }
+        nb = mulT(Rb, nw);
+      }
+      const V3 rj = r[j];
+      const V3 vp = v.v + cross(v.w, rj);
+      const float vn = dot(vp, nb);
+      // normal force = capped spring on the penetration - damper on the closing speed; outside the surface but inside the
+      // contact offset only the speed in excess of gap / dt is damped (DynParams::coff, ::vdep)
+      pen += P.roff;
+      const float spring = P.kn * fmaxf(pen, 0.f);
+      const float fn0 = ((P.vdep > 0.f) ? fminf(spring, c_n * P.vdep) : spring) - c_n * (vn + fmaxf(-pen, 0.f) * P.inv_dt);
+      const bool act = valid[j] && (pen > -P.coff) && (fn0 > 0.f);      // as before: a point visited because SOME lane's is near takes part on its own merits
+      if (!hx_any(act)) continue;
+      const V3 vt = vp - vn * nb;
+      const float vtn = sqrtf(dot(vt, vt));
+      const float c_t = P.mu * fn0 / fmaxf(vtn, P.veps);
+      const float on = act ? 1.f : 0.f;
+      any_on = fmaxf(any_on, on);
+      const V3 f = on * (fn0 * nb - c_t * vt);
+      const float alpha = on * P.dt * c_t, beta = on * P.dt * (c_n - c_t);
+      f0.v = f0.v + f;
+      f0.w = f0.w + cross(rj, f);
+      const V3 m = cross(rj, nb);
+      const float rr = dot(rj, rj);
+      // A += alpha (|r|^2 1 - r r^T) + beta m m^T ; H += alpha rx + beta m n^T ; M += alpha 1 + beta n n^T
+      Axx += alpha * (rr - rj.x * rj.x) + beta * m.x * m.x; Axy += -alpha * rj.x * rj.y + beta * m.x * m.y; Axz += -alpha * rj.x * rj.z + beta * m.x * m.z;
+      Ayy += alpha * (rr - rj.y * rj.y) + beta * m.y * m.y; Ayz += -alpha * rj.y * rj.z + beta * m.y * m.z; Azz += alpha * (rr - rj.z * rj.z) + beta * m.z * m.z;
+      H.m[1] += -alpha * rj.z; H.m[2] += alpha * rj.y;
+      H.m[3] += alpha * rj.z;  H.m[5] += -alpha * rj.x;
+      H.m[6] += -alpha * rj.y; H.m[7] += alpha * rj.x;
+      addouter(H, beta, m, nb);
+      Mxx += alpha + beta * nb.x * nb.x; Mxy += beta * nb.x * nb.y; Mxz += beta * nb.x * nb.z;
+      Myy += alpha + beta * nb.y * nb.y; Myz += beta * nb.y * nb.z; Mzz += alpha + beta * nb.z * nb.z;
+    }
   }
   if (!hx_any(any_on != 0.f)) return false;
   // the four lanes of the side add their partial sums (afterwards they agree bitwise).  The first shape to touch a slot in

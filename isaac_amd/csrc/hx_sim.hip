@@ -26,6 +26,7 @@
 #ifndef HX_ENV_WPB
 #define HX_ENV_WPB 1                          /* waves per workgroup (each wave is self-contained: own LDS region, own robots) */
 #endif
+#define HX_PROF_WAVES 8192
 template <class M> __host__ __device__ static constexpr size_t env_step_lds_bytes() {
   return sizeof(float) * ((ModelInfo<M>::LDS_FLOATS + 3) / 4 * 4 + HX_RPW * HX_PATCH_LD + 2 * HX_RPW * HX_POOL_LD + 2 * HX_RPW + (size_t)ModelInfo<M>::NSLOT * HX_CB_FIELDS * (64 / HX_LANES_PER_SIDE) + HX_RPW * 80);
 }
@@ -52,10 +53,12 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
   int (*lds_patch_org)[2] = reinterpret_cast<int (*)[2]>(lds_poolw + HX_RPW * HX_POOL_LD);
   float* lds_cb = lds_poolw + HX_RPW * HX_POOL_LD + 2 * HX_RPW;
 #if defined(HX_STEP_PROF)
-  __shared__ long long lds_prof[16];
-  if (tidx < 16) lds_prof[tidx] = 0;
+  __shared__ long long lds_prof[18];
+  if (tidx < 18) lds_prof[tidx] = 0;
   __syncthreads();
-  if (tidx == 0) lds_prof[15] = clock64();
+  // [15]: shader clock at the start (phase timers); [16], [17]: shader-clock and 100 MHz wall-clock stamps of the whole wave -> the
+  // clock the kernel ran at (MI355X_MICROARCH.md "DVFS give-back" item 6: d s_memtime / d s_memrealtime x 100 MHz)
+  if (tidx == 0) { lds_prof[15] = clock64(); lds_prof[16] = -(long long)clock64(); lds_prof[17] = -(long long)wall_clock64(); }
   long long* const prof = (p.prof != nullptr) ? lds_prof : nullptr;
 #else
   long long* const prof = nullptr;
@@ -194,7 +197,11 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
   env_glue<M>(p, cfg, A, n, e, writer, rng, R);
   HX_T(prof, 8);
 #if defined(HX_STEP_PROF)
-  if (prof != nullptr && tidx == 0) for (int k = 0; k < 15; ++k) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
+  if (prof != nullptr && tidx == 0) {
+    lds_prof[16] += (long long)clock64(); lds_prof[17] += (long long)wall_clock64();
+    for (int k = 0; k < 18; ++k) if (k != 15) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
+    if (blockIdx.x < HX_PROF_WAVES) p.prof[20 + blockIdx.x] += lds_prof[17];        // per-wave lifetime (100 MHz ticks), summed over launches
+  }
 #endif
 }
 
@@ -779,16 +786,23 @@ extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }
 // measurement hook (tools/step_prof.py; library built with -DHX_STEP_PROF): which = 1 starts / clears, 0 reads the cycle
 // counters summed over all waves and launches since: {window fetch + pooling, action processing, kinematics, contact
 // phase, articulated inertias, exchange + base solve, accelerations + forces + integration, guard + gather, glue}
-extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[15]*/) {
+extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[18]*/) {
   if (!s) { hx_set_error("hx_sim_prof: null sim"); return -2; }
   if (which == 1) {
-    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 16)) return -3; s->p.prof = d; }
+    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 20 + HX_PROF_WAVES)) return -3; s->p.prof = d; }
     HX_CHECK(hipStreamSynchronize(s->stream));
-    HX_CHECK(hipMemset(s->p.prof, 0, 16 * sizeof(long long)));
+    HX_CHECK(hipMemset(s->p.prof, 0, (20 + HX_PROF_WAVES) * sizeof(long long)));
     return 0;
   }
   if (!s->p.prof || !out_h) { hx_set_error("hx_sim_prof: not started"); return -2; }
   HX_CHECK(hipStreamSynchronize(s->stream));
-  HX_CHECK(hipMemcpy(out_h, s->p.prof, 15 * sizeof(long long), hipMemcpyDeviceToHost));
+  HX_CHECK(hipMemcpy(out_h, s->p.prof, 18 * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+// lifetimes of the first `n` env-step waves (100 MHz ticks, summed over the launches since hx_sim_prof(s, 1, ..)); -DHX_STEP_PROF builds
+extern "C" int hx_sim_prof_waves(hx_sim* s, long long* out_h, int n) {
+  if (!s || !s->p.prof || !out_h || n < 1 || n > HX_PROF_WAVES) { hx_set_error("hx_sim_prof_waves: not started or bad count"); return -2; }
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(out_h, s->p.prof + 20, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }

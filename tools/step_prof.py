@@ -32,15 +32,17 @@ for _ in range(20):
 capi.check(L.hx_sim_prof(env._h, 1, None), "prof")
 for _ in range(steps):
     L.hx_sim_step(env._h, act.ptr, None)
-out = np.zeros(15, np.int64)
+out = np.zeros(18, np.int64)
 capi.check(L.hx_sim_prof(env._h, 0, out.ctypes.data), "prof")
 waves = (n + 7) // 8
 names = ["window fetch + pooling", "action processing", "kinematics (x10)", "contact phase (x10)", "articulated inertias (x10)",
          "exchange + base solve (x10)", "accelerations, forces, integration (x10)", "guard + gather", "glue"]
 per = out[:9] / (waves * steps)
-visits = out[9:] / (waves * steps * 2 * 10)       # lane 0 of each wave counts once per side_up; 10 substeps
+visits = out[9:15] / (waves * steps * 2 * 10)       # lane 0 of each wave counts once per side_up; 10 substeps
 print(f"N={n} {task} {mesh}: cycles per wave and env step (shader clock), {steps} steps, timers themselves included")
 for nm, c in zip(names, per):
     print(f"  {nm:45s} {c:10.0f} cycles  {100 * c / per.sum():5.1f} %")
 print(f"  {'total':45s} {per.sum():10.0f} cycles")
 print("  contact-loop entries visited per substep (wave-level: any of the wave's 8 robots): %.2f of the lane's entries; first five entries: %s" % (visits[0] * 2, np.round(visits[1:6] * 2, 2)))
+if out[17] > 0:
+    print("  in-kernel clock (sum over waves of d s_memtime / d s_memrealtime x 100 MHz): %.3f GHz; a wave lives %.1f us on average" % (0.1 * out[16] / out[17], out[17] / (waves * steps) / 100.0))
