@@ -519,22 +519,60 @@ struct MbTableArgs {
   const float* actions; const float* mu; const float* values; const float* returns; const float* logp; const float* adv;
   int A; float* row_mb;
 };
+// one thread per OUTPUT element (2A + 4 scalars + 4 table entries per row): coalesced stores, the scattered side is the 4-byte loads
 __global__ void __launch_bounds__(256) hx_mb_tables_kernel(MbTableArgs g) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = 2 * g.A + 8;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(idx / W), j = (int)(idx % W);
   if (i >= g.TN) return;
   const int src = g.perm[i];
-  g.mb_off_obs[i] = g.off_obs[src]; g.mb_off_priv[i] = g.off_priv[src]; g.mb_kz_obs[i] = g.kz_obs[src]; g.mb_kz_priv[i] = g.kz_priv[src];
-  float* r = g.row_mb + (size_t)i * (2 * g.A + 4);
-  for (int j = 0; j < g.A; ++j) { r[j] = g.actions[(size_t)src * g.A + j]; r[g.A + j] = g.mu[(size_t)src * g.A + j]; }
-  r[2 * g.A] = g.values[src]; r[2 * g.A + 1] = g.returns[src]; r[2 * g.A + 2] = g.logp[src]; r[2 * g.A + 3] = g.adv[src];
+  const int A = g.A, nf = 2 * A + 4;
+  if (j < nf) {
+    float v;
+    if (j < A) v = g.actions[(size_t)src * A + j];
+    else if (j < 2 * A) v = g.mu[(size_t)src * A + j - A];
+    else if (j == 2 * A) v = g.values[src];
+    else if (j == 2 * A + 1) v = g.returns[src];
+    else if (j == 2 * A + 2) v = g.logp[src];
+    else v = g.adv[src];
+    g.row_mb[(size_t)i * nf + j] = v;
+  } else if (j == nf) g.mb_off_obs[i] = g.off_obs[src];
+  else if (j == nf + 1) g.mb_off_priv[i] = g.off_priv[src];
+  else if (j == nf + 2) g.mb_kz_obs[i] = g.kz_obs[src];
+  else g.mb_kz_priv[i] = g.kz_priv[src];
 }
-// rows [count][ld] of a frame-stored stream, expanded (hx_ppo_storage_rows): one workgroup per row
+// rows [count][ld] of a frame-stored stream, expanded (hx_ppo_storage_rows; the deferred critic's batches): the workgroups walk the
+// rows; a wave's lanes take consecutive elements (row starts are only float-aligned: 4-byte accesses, whole 256-byte segments per
+// wave and instruction on both sides)
 __global__ void __launch_bounds__(256) hx_expand_rows_kernel(const float* __restrict__ base, const int* __restrict__ off, const int* __restrict__ kz, int klim, int ld,
-                                                             float* __restrict__ dst) {
+                                                             float* __restrict__ dst, int count) {
+  for (int r = blockIdx.x; r < count; r += gridDim.x) {
+    const float* src = base + off[r];
+    const int z = kz[r];
+    for (int k = threadIdx.x; k < ld; k += blockDim.x) dst[(size_t)r * ld + k] = (k >= z && k < klim) ? src[k] : 0.f;
+  }
+}
+
+// One minibatch of rows of BOTH streams, expanded from the frame rings through the permutation-ordered tables of hx_mb_tables_kernel
+// into ordinary matrices (the row starts are only float-aligned: 4-byte accesses, coalesced along the row; the loads hit the L2 -- the
+// 15-frame windows of consecutive steps of a robot overlap in 14 frames).  One workgroup per row.  What the gather launch is to row storage;
+// kept per minibatch across the epochs like the gathered rows (the reference reuses one permutation, rollout_storage.py:149).
+struct ExpandMbArgs { const float* obs; const float* priv; const int* off_o; const int* kz_o; const int* off_p; const int* kz_p; int klim_o, klim_p, ld_o, ld_p; float* dst_o; float* dst_p; };
+__global__ void __launch_bounds__(256) hx_expand_mb_kernel(ExpandMbArgs g) {
   const int r = blockIdx.x;
-  const float* src = base + off[r];
-  const int z = kz[r];
-  for (int k = threadIdx.x; k < ld; k += blockDim.x) dst[(size_t)r * ld + k] = (k >= z && k < klim) ? src[k] : 0.f;
+  const float* so = g.obs + g.off_o[r]; const float* sp = g.priv + g.off_p[r];
+  const int zo = g.kz_o[r], zp = g.kz_p[r];
+  const int no = g.ld_o >> 2, np = g.ld_p >> 2;
+  for (int q = threadIdx.x; q < no + np; q += 256) {          // 16-byte stores; four scalar loads each (measured 157 us per minibatch against 199 us with 4-byte stores)
+    const bool ob = q < no;
+    const int k = 4 * (ob ? q : q - no);
+    const float* src = ob ? so : sp;
+    const int z = ob ? zo : zp, lim = ob ? g.klim_o : g.klim_p;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (k + j >= z && k + j < lim) ? src[k + j] : 0.f;
+    *reinterpret_cast<f32x4*>((ob ? g.dst_o + (size_t)r * g.ld_o : g.dst_p + (size_t)r * g.ld_p) + k) = v;
+  }
 }
 
 // Loss head (ppo.py:128-166 forward of the last layers, all loss terms, and their backward down to the
@@ -1128,6 +1166,8 @@ struct hx_ppo {
   int wgrad_multi;               // 1: ... at one workgroup per CU with per-product tile shapes (hx_wgrad_multi_kernel, HX_WGRAD_MULTI)
   std::map<int, WgradPlan> wplans;          // per minibatch row count
   float *wslab = nullptr, *wbslab = nullptr; size_t wslab_floats = 0, wbslab_floats = 0;
+  int frames_gather;             // 1: frame storage feeds the first-layer products through gathered loaders (round 3); 0: rows expanded once per minibatch and update (HX_FRAMES_GATHER)
+  int gemm_sp;                   // 1: long-K hidden-layer pairs of the update through the slot-placed loop (HX_GEMM_SP)
   int gemm_pair;                 // 1: layer l of the actor and of the critic share one launch in the update (HX_GEMM_PAIR)
   int head_mfma;                 // 1: hector-shaped loss heads run on the matrix cores (HX_HEAD_MFMA)
   int* pause_flag = nullptr;     // count of fused-actor workgroups in flight; the background critic sleeps while it is up (HX_CRITIC_YIELD)
@@ -1370,6 +1410,23 @@ template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, bool KFULL> stati
   G.first[G.n] = blocks;
   ProfScope ps(s, gemm_group_kid<BM, BN, BKT, AK, BK_, EPI, KFULL>(), st, flops);
   hipLaunchKernelGGL((hx_gemm_group_kernel<BM, BN, BKT, AK, BK_, EPI, KFULL>), dim3(hx_group_grid(G)), dim3(256), 0, st, G);
+}
+// the same group through the slot-placed loop (hx_gemm_sp.h): bit-identical results; measured faster where the K loop is long enough
+// for the loop to matter and the tile count fills the chip several times (profiles/r04_b_gemm_lab.txt: hidden-layer forward pair
+// +1.7 %, first input-gradient pair +3.7 %; the 256 -> 128 products and the input layers' pair are not)
+template <int BM, int BN, int BKT, bool AK, bool BK_, int EPI, int WM, int WN, bool KFULL> static void launch_gemm_sp_group(hx_ppo* s, GemmGroup& G, hipStream_t st) {
+  int blocks = 0; double flops = 0.0;
+  for (int i = 0; i < G.n; ++i) {
+    GemmArgs& g = G.p[i];
+    g.tiles_m = (g.M + BM - 1) / BM; g.tiles_n = (g.N + BN - 1) / BN;
+    G.first[i] = blocks; blocks += g.tiles_m * g.tiles_n * (EPI == EPI_SLAB ? g.splits : 1);
+    flops += 2.0 * g.M * g.N * g.K;
+  }
+  G.first[G.n] = blocks;
+  static const int kid = prof_register("hx_gemm_sp_group_kernel<" + std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(BKT) + ", " + tf(AK) + ", " +
+                                       tf(BK_) + ", " + std::to_string(EPI) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " + tf(KFULL) + ">");
+  ProfScope ps(s, kid, st, flops);
+  hipLaunchKernelGGL((hx_gemm_sp_group_kernel<BM, BN, BKT, AK, BK_, EPI, WM, WN, KFULL>), dim3(hx_group_grid(G)), dim3(64 * WM * WN), 0, st, G);
 }
 // Cuts `jobs` into groups whose tiles fill one wave of workgroups (>= 95 % of the 3-per-CU slots at a whole number of
 // slices per tile), peeling off the largest product while they do not, and launches each group.  splits_out[i] /
@@ -1733,6 +1790,10 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_WGRAD_GROUP", 1, 0, 1, &s->wgrad_group)) return rc;
   if (int rc = hx_knob_int("HX_WGRAD_MULTI", 1, 0, 1, &s->wgrad_multi)) return rc;
   if (int rc = hx_knob_int("HX_GEMM_PAIR", 1, 0, 1, &s->gemm_pair)) return rc;
+  if (int rc = hx_knob_int("HX_GEMM_SP", 1, 0, 1, &s->gemm_sp)) return rc;
+  if (int rc = hx_knob_int("HX_FRAMES_GATHER", -1, 0, 1, &s->frames_gather)) return rc;
+  // by measurement (profiles/r04_o_frames.txt): expanded minibatch rows up to 8192 robots, gathered loaders above (no expanded copy: 6.6 GB at 16 384)
+  if (s->frames_gather < 0) s->frames_gather = (cfg->num_envs >= 16384) ? 1 : 0;
   if (int rc = hx_knob_int("HX_HEAD_MFMA", 1, 0, 1, &s->head_mfma)) return rc;
   int knob_yield = 1;
   if (int rc = hx_knob_int("HX_CRITIC_YIELD", 1, 0, 1, &knob_yield)) return rc;
@@ -1835,7 +1896,12 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   // minibatch i holds the same rows in each epoch: with more than one epoch the gathered rows are kept per minibatch
   // (a permuted copy of the rollout, 1.6 GB at 4096 envs) and gathered once per update instead of once per epoch.
   s->mb_slots = (cfg->num_learning_epochs > 1 && cfg->num_mini_batches <= 64 && mbs >= N) ? cfg->num_mini_batches : 1;
-  if (s->frames) {        // no permuted copy of the rollout: tables in permutation order (hx_mb_tables_kernel) + one minibatch of rows
+  if (s->frames && !s->frames_gather) {
+    // rows of a minibatch expanded once per update and kept across the epochs (hx_expand_mb_kernel): the permuted copy row storage
+    // keeps, without the unpermuted one; everything after the expansion is the plain path
+    rc |= palloc(s, &s->obs_mb_all, (size_t)s->mb_slots * Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, (size_t)s->mb_slots * Mm * cfg->priv_ld);
+    rc |= palloc(s, &s->row_mb_all, TN * (2 * A + 4));
+  } else if (s->frames) {        // no permuted copy of the rollout: tables in permutation order (hx_mb_tables_kernel) + one minibatch of rows
     s->mb_slots = 1;
     rc |= palloc(s, &s->obs_mb_all, Mm * cfg->obs_ld); rc |= palloc(s, &s->priv_mb_all, Mm * cfg->priv_ld);
     rc |= palloc(s, &s->row_mb_all, TN * (2 * A + 4));
@@ -2065,7 +2131,8 @@ static void mlp_hidden_fwd_pair(hx_ppo* s, int l0, const float* Xa, int ldxa, co
       g.B = s->params + Ly.w; g.ldb = Ly.in_ld; g.C = act[l]; g.ldc = Ly.out; g.M = M; g.N = Ly.out; g.K = Ly.in_ld; g.bias = s->params + Ly.b;
       kfull = kfull && (g.K % 32 == 0);
     }
-    if (kfull) launch_gemm_group<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, G, st);
+    if (kfull && s->gemm_sp && M >= 16384 && G.p[0].K >= 512 && G.p[1].K >= 512) launch_gemm_sp_group<128, 128, 32, true, true, EPI_BIAS_ELU, 2, 2, true>(s, G, st);
+    else if (kfull) launch_gemm_group<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, G, st);
     else launch_gemm_group<128, 128, 16, true, true, EPI_BIAS_ELU, false>(s, G, st);
   }
 }
@@ -2083,7 +2150,8 @@ static void gemm_dgrad_pair(hx_ppo* s, int l, int M, hipStream_t st) {
     g.H = act[l - 1]; g.ldh = Ly.in_ld;
     kfull = kfull && (g.K % 32 == 0);
   }
-  if (kfull) launch_gemm_group<64, 128, 32, true, false, EPI_ELU_GRAD, true>(s, G, st);
+  if (kfull && s->gemm_sp && M >= 16384 && G.p[0].K >= 256 && G.p[1].K >= 256) launch_gemm_sp_group<128, 128, 32, true, false, EPI_ELU_GRAD, 2, 2, true>(s, G, st);
+  else if (kfull) launch_gemm_group<64, 128, 32, true, false, EPI_ELU_GRAD, true>(s, G, st);
   else launch_gemm_group<64, 128, 32, true, false, EPI_ELU_GRAD, false>(s, G, st);
 }
 
@@ -2097,6 +2165,9 @@ static int critic_flush(hx_ppo* s, int upto, bool after_rollout = false) {
     const int rows = slots * N;
     HX_CHECK(hipStreamWaitEvent(s->stream2, s->ev_priv, 0));   // the newest slot's rows have been copied
     if (s->frames) {
+      // the gathered first layer on the persistent grid.  Expanding the batch's rows first and running the plain layer was measured
+      // and is worse at every grid size of the expansion (profiles/r04_o_frames.txt): a launch beside the fused actor delays it and
+      // the critic's own GEMMs more than the gathered loader costs (421 against 344 us per batch)
       const RowTable rt{s->off_priv + (size_t)s->crit_done * N, s->kz_priv + (size_t)s->crit_done * N, s->cfg.num_priv};
       mlp_hidden_fwd(s, 1, s->s_priv, 0, rows, s->act_c, s->stream2, false, &rt, after_rollout);
     } else {
@@ -2326,7 +2397,7 @@ extern "C" int hx_ppo_update_begin(hx_ppo* s, const int32_t* perm) {
     g.mb_off_obs = s->mb_off_obs; g.mb_off_priv = s->mb_off_priv; g.mb_kz_obs = s->mb_kz_obs; g.mb_kz_priv = s->mb_kz_priv;
     g.actions = s->s_actions; g.mu = s->s_mu; g.values = s->s_values; g.returns = s->s_returns; g.logp = s->s_logp; g.adv = s->s_adv;
     g.A = s->cfg.num_actions; g.row_mb = s->row_mb_all;
-    hipLaunchKernelGGL(hx_mb_tables_kernel, dim3((TN + 255) / 256), dim3(256), 0, s->stream, g);
+    hipLaunchKernelGGL(hx_mb_tables_kernel, dim3((unsigned)(((long long)TN * (2 * g.A + 8) + 255) / 256)), dim3(256), 0, s->stream, g);
     HX_CHECK(hipGetLastError());
   }
   SchedState z{};
@@ -2348,11 +2419,11 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   hipStream_t st = s->stream;
   const int slot = (s->mb_slots > 1) ? mb : 0;
   RowTable rt_obs{}, rt_priv{};
-  if (s->frames) {
-    // The first-layer forward products read the minibatch's rows in place through the permutation-ordered tables of
-    // hx_ppo_update_begin and, as a side effect, leave the assembled rows in a one-minibatch workspace (obs_mb / priv_mb),
-    // from which the first-layer weight-gradient products read them with the plain loader: the gather is fused into the
-    // forward GEMM, there is no gather launch and no permuted copy of the rollout.
+  const bool gathered_loaders = s->frames && s->frames_gather;
+  if (gathered_loaders) {
+    // HX_FRAMES_GATHER=1 (round 3): the first-layer forward products read the minibatch's rows in place through the permutation-
+    // ordered tables of hx_ppo_update_begin and, as a side effect, leave the assembled rows in a one-minibatch workspace (obs_mb /
+    // priv_mb), from which the first-layer weight-gradient products read them with the plain loader
     s->obs_mb = s->obs_mb_all; s->priv_mb = s->priv_mb_all;
     s->row_mb = s->row_mb_all + (size_t)mb * M * (2 * A + 4);
     rt_obs = RowTable{s->mb_off_obs + (size_t)mb * M, s->mb_kz_obs + (size_t)mb * M, c.num_obs, s->obs_mb, c.obs_ld};
@@ -2360,7 +2431,14 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   } else {
     s->obs_mb = s->obs_mb_all + (size_t)slot * s->Mmax * c.obs_ld;
     s->priv_mb = s->priv_mb_all + (size_t)slot * s->Mmax * c.priv_ld;
-    s->row_mb = s->row_mb_all + (size_t)slot * s->Mmax * (2 * A + 4);
+    s->row_mb = s->frames ? s->row_mb_all + (size_t)mb * M * (2 * A + 4) : s->row_mb_all + (size_t)slot * s->Mmax * (2 * A + 4);
+  }
+  if (s->frames && !gathered_loaders && (s->mb_slots == 1 || !((s->mb_gathered >> mb) & 1ull))) {
+    // frame storage: the minibatch's rows expanded from the rings, once per update (the epochs share the permutation)
+    ExpandMbArgs ea{s->s_obs, s->s_priv, s->mb_off_obs + (size_t)mb * M, s->mb_kz_obs + (size_t)mb * M, s->mb_off_priv + (size_t)mb * M, s->mb_kz_priv + (size_t)mb * M,
+                    c.num_obs, c.num_priv, c.obs_ld, c.priv_ld, s->obs_mb, s->priv_mb};
+    hipLaunchKernelGGL(hx_expand_mb_kernel, dim3(M), dim3(256), 0, st, ea);
+    s->mb_gathered |= (1ull << mb);
   }
   if (!s->frames && (s->mb_slots == 1 || !((s->mb_gathered >> mb) & 1ull))) {
     GatherArgs ga{};
@@ -2380,15 +2458,15 @@ extern "C" int hx_ppo_minibatch_backward(hx_ppo* s, int mb_index, void** grad_bu
   // HX_GEMM_PAIR: layer l of both networks in one launch (fp32, update size, one stream); with single-frame storage the two
   // gathered input layers keep their own launches
   const bool pair = s->gemm_pair && !s->bf16 && !s->stream_b && M >= 16384 && s->fwd_in_tile == 128;
-  if (pair && !s->frames) mlp_hidden_fwd_pair(s, 0, s->obs_mb, c.obs_ld, s->priv_mb, c.priv_ld, M, st);
+  if (pair && !gathered_loaders) mlp_hidden_fwd_pair(s, 0, s->obs_mb, c.obs_ld, s->priv_mb, c.priv_ld, M, st);
   else if (pair) {
     const Layer* La = s->L; const Layer* Lc = s->L + 4;
     gemm_fwd(s, st, s->s_obs, c.obs_ld, s->params + La[0].w, La[0].in_ld, s->params + La[0].b, s->act_a[0], M, La[0].out, La[0].in_ld, false, false, &rt_obs);
     gemm_fwd(s, st, s->s_priv, c.priv_ld, s->params + Lc[0].w, Lc[0].in_ld, s->params + Lc[0].b, s->act_c[0], M, Lc[0].out, Lc[0].in_ld, false, false, &rt_priv);
     mlp_hidden_fwd_pair(s, 1, nullptr, 0, nullptr, 0, M, st);
   } else {
-    mlp_hidden_fwd(s, 0, s->frames ? s->s_obs : s->obs_mb, c.obs_ld, M, s->act_a, st, false, s->frames ? &rt_obs : nullptr);
-    mlp_hidden_fwd(s, 1, s->frames ? s->s_priv : s->priv_mb, c.priv_ld, M, s->act_c, sb, false, s->frames ? &rt_priv : nullptr);
+    mlp_hidden_fwd(s, 0, gathered_loaders ? s->s_obs : s->obs_mb, c.obs_ld, M, s->act_a, st, false, gathered_loaders ? &rt_obs : nullptr);
+    mlp_hidden_fwd(s, 1, gathered_loaders ? s->s_priv : s->priv_mb, c.priv_ld, M, s->act_c, sb, false, gathered_loaders ? &rt_priv : nullptr);
   }
   if (s->stream_b) { HX_CHECK(hipEventRecord(s->ev_b1, sb)); HX_CHECK(hipStreamWaitEvent(st, s->ev_b1, 0)); }
   // heads: losses + gradient into the third hidden layer
@@ -2565,7 +2643,7 @@ extern "C" int hx_ppo_storage_rows(hx_ppo* s, int which, int t0, int t1, float* 
     return 0;
   }
   hipLaunchKernelGGL(hx_expand_rows_kernel, dim3((unsigned)((t1 - t0) * N)), dim3(256), 0, s->stream, ob ? s->s_obs : s->s_priv,
-                     (ob ? s->off_obs : s->off_priv) + (size_t)t0 * N, (ob ? s->kz_obs : s->kz_priv) + (size_t)t0 * N, ob ? s->cfg.num_obs : s->cfg.num_priv, ld, dst);
+                     (ob ? s->off_obs : s->off_priv) + (size_t)t0 * N, (ob ? s->kz_obs : s->kz_priv) + (size_t)t0 * N, ob ? s->cfg.num_obs : s->cfg.num_priv, ld, dst, (t1 - t0) * N);
   HX_CHECK(hipGetLastError());
   return 0;
 }
