@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(256) hx_actor_head_kernel(const float* __restr
 // v_mfma_f32_16x16x4_f32: lane l holds A[row l&15][k = l>>4], B[k = l>>4][col l&15]; with the k-permutation used by
 // hx_gemm.h a float4 per lane (k = 4*(l>>4) .. +3 of a 16-deep block) feeds 4 MFMAs.  C/D: col = l&15, row = 4*(l>>4)+reg.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-#define FA_ROWS 16
+#define FA_ROWS 16      // rows of a fused-actor workgroup with one row tile (hx_actor_fused_kernel RT = 1)
 // rows that live as windows of per-robot frame rings (single-frame observation storage): row r = base + off[r], elements
 // [0, kz[r]) and [klim, ..) read as zero.  base == nullptr: ordinary rows.
 struct FrameSrc { const float* base; const int* off; const int* kz; int klim; };
@@ -212,14 +212,17 @@ __device__ __forceinline__ void fa_prefetch(const float* __restrict__ W, int K, 
   for (int t = 0; t < NT; ++t) { b0[t] = Wp[((size_t)t * nkb) * 64]; b1[t] = Wp[((size_t)t * nkb + min(1, nkb - 1)) * 64]; }
 }
 
-template <int NT, bool BF, bool ROUND_OUT>   // NT = 16-column tiles per wave; BF: round the weight operand; ROUND_OUT: round what is stored
+// RT = 16-row tiles of the workgroup (1 or 2): every weight fragment streamed from L2 feeds RT MFMAs
+template <int NT, bool BF, bool ROUND_OUT, int RT = 1>   // NT = 16-column tiles per wave; BF: round the weight operand; ROUND_OUT: round what is stored
 __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, int ldw,
                                          const float* __restrict__ bias, float* __restrict__ Hs, int ldh, int n_wave0, int lane,
                                          f32x4v* b0, f32x4v* b1) {      // b0 / b1: blocks 0 and 1, already requested (fa_prefetch)
   const int r16 = lane & 15, kq = lane >> 4;
-  f32x4v acc[NT];
+  f32x4v acc[RT][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[q][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
   const int nkb = (K + 15) / 16;
   // weights are streamed from L2 with TWO k-blocks in flight per wave (one was L2-latency bound: 80 us per call).
   // The loop is written out for three named buffers on purpose: a generic register-ring version of the same
@@ -245,12 +248,15 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
   auto step = [&](int kb, f32x4v* bc) {
     roundB(bc);
     const int k = kb * 16 + 4 * kq;
-    f32x4v a = {0.f, 0.f, 0.f, 0.f};
-    if (k < K) a = *reinterpret_cast<const f32x4v*>(Xs + r16 * ldx + k);
+    f32x4v a[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) { a[q] = (f32x4v){0.f, 0.f, 0.f, 0.f}; if (k < K) a[q] = *reinterpret_cast<const f32x4v*>(Xs + (q * 16 + r16) * ldx + k); }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bc[t][i], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < RT; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][i], bc[t][i], acc[q][t], 0, 0, 0);
   };
   int kb = 0;
   for (; kb + 2 < nkb; kb += 3) {
@@ -265,14 +271,19 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
     const int col = n_wave0 + t * 16 + r16;
     const float bv = bias[col];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float o = hx_elu(acc[t][r] + bv);
-      Hs[(kq * 4 + r) * ldh + col] = ROUND_OUT ? hx_bf16r(o) : o;
-    }
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float o = hx_elu(acc[q][t][r] + bv);
+        Hs[(q * 16 + kq * 4 + r) * ldh + col] = ROUND_OUT ? hx_bf16r(o) : o;
+      }
   }
 }
 
-template <bool BF, int NW>   // NW waves per workgroup (4 or 8): each owns 1/NW of a layer's output columns
+// RT = 16-row tiles per workgroup.  RT = 2 (32 rows, HX_ACTOR_ROWS=32, an experiment): half as many workgroups stream the 1.9 MB of
+// weights out of the L2 and every fragment feeds two MFMAs; measured slower (fa_row_tiles).  The activations then share two LDS
+// buffers: X and H2 in one, H1 and H3 in the other (a layer's input is dead once its output is complete).
+template <bool BF, int NW, int RT = 1>   // NW waves per workgroup (4 or 8): each owns 1/NW of a layer's output columns
 __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __restrict__ obs, int obs_ld, int n,
                                                              const float* __restrict__ W1, const float* __restrict__ b1, int K1, int N1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int N2,
@@ -287,12 +298,13 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   // the rollout's critical path and shares half the CUs with them
   if (pause != nullptr && threadIdx.x == 0) atomicAdd(pause, 1);
   const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
+  constexpr int ROWS = 16 * RT;
   float* Xs = fsm;
-  float* H1 = Xs + FA_ROWS * ldx;
-  float* H2 = H1 + FA_ROWS * ld1;
-  float* H3 = H2 + FA_ROWS * ld2;
+  float* H1 = Xs + ROWS * (ldx > ld2 ? ldx : ld2);
+  float* H2 = (RT == 1) ? H1 + ROWS * ld1 : Xs;              // RT = 2: H2 over X, H3 over H1
+  float* H3 = (RT == 1) ? H2 + ROWS * ld2 : H1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * FA_ROWS;
+  const int row0 = blockIdx.x * ROWS;
   f32x4v p1a[32 / NW], p1b[32 / NW], p2a[16 / NW], p2b[16 / NW], p3a[8 / NW], p3b[8 / NW];
   fa_prefetch<32 / NW>(W1, K1, wave * (512 / NW), lane, p1a, p1b);
   if (fsrc.base != nullptr) {
@@ -303,7 +315,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     // row start rounded down -- covering elements -m .. K1 + 3 - m of the row, m = the start's misalignment in floats -- and
     // scatters the four values to their columns in LDS: a quarter of the load instructions of an element-wise copy, no split
     // 16-byte accesses, no index division.  All loads of a thread are independent of each other.
-    constexpr int TPR = 64 * NW / FA_ROWS;
+    constexpr int TPR = 64 * NW / ROWS;
     const int r = tid / TPR, q0 = tid % TPR, gr = min(row0 + r, n - 1);
     const int off = fsrc.off[gr], kz = fsrc.kz[gr], m = off & 3;
     const f32x4v* src = reinterpret_cast<const f32x4v*>(fsrc.base + (off - m));
@@ -318,12 +330,12 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     }
     // bookkeeping of the env step that produced these rows (it needs that launch's total reset count, hx_common.h)
     if (book_valid) {
-      if (tid < FA_ROWS && row0 + tid < n) hx_step_book_row(book, row0 + tid);
+      if (tid < ROWS && row0 + tid < n) hx_step_book_row(book, row0 + tid);
       if (blockIdx.x == 0 && tid >= 64 && tid < 128) hx_step_book_global(book, tid - 64);
     }
   } else {
     // stage the 16 observation rows (coalesced float4; rows past n read row n-1 and are discarded at the end)
-    for (int i = tid; i < FA_ROWS * (K1 / 4); i += 64 * NW) {
+    for (int i = tid; i < ROWS * (K1 / 4); i += 64 * NW) {
       const int r = i / (K1 / 4), c4 = i % (K1 / 4);
       const int gr = min(row0 + r, n - 1);
       const f32x4v v = *reinterpret_cast<const f32x4v*>(obs + (size_t)gr * obs_ld + c4 * 4);
@@ -332,17 +344,17 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   }
   __syncthreads();
   fa_prefetch<16 / NW>(W2, N1, wave * (256 / NW), lane, p2a, p2b);
-  fa_layer<32 / NW, BF, BF>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane, p1a, p1b);      // 615(616) -> 512
+  fa_layer<32 / NW, BF, BF, RT>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane, p1a, p1b);      // 615(616) -> 512
   __syncthreads();
   fa_prefetch<8 / NW>(W3, N2, wave * (128 / NW), lane, p3a, p3b);
-  fa_layer<16 / NW, BF, BF>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * (256 / NW), lane, p2a, p2b);      // 512 -> 256
+  fa_layer<16 / NW, BF, BF, RT>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * (256 / NW), lane, p2a, p2b);      // 512 -> 256
   __syncthreads();
-  fa_layer<8 / NW, BF, false>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane, p3a, p3b);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
+  fa_layer<8 / NW, BF, false, RT>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane, p3a, p3b);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
   __syncthreads();
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]; one thread per (row, action) also samples its action and leaves its
   // log-prob term in LDS; the row's thread then adds the terms in action order (the order of the serial loop it replaces)
-  float* sTerm = H1;                         // layer-1 activations are dead by now
-  for (int i = tid; i < FA_ROWS * A; i += 64 * NW) {
+  float* sTerm = (RT == 1) ? H1 : Xs;       // dead by now: layer-1 activations (RT = 1); X / H2 (RT = 2, where H1's place holds H3)
+  for (int i = tid; i < ROWS * A; i += 64 * NW) {
     const int r = i / A, j = i % A;
     float m = 0.f;
     for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4[j * N3 + k], m);
@@ -367,7 +379,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     }
   }
   __syncthreads();
-  if (tid < FA_ROWS && row0 + tid < n) {
+  if (tid < ROWS && row0 + tid < n) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) lp += sTerm[tid * MAX_A + j];
     logp[row0 + tid] = lp;
@@ -1192,6 +1204,7 @@ struct hx_ppo {
   int prof_every = 1; long prof_seen = 0;      // bracket every prof_every-th launch of the selected symbols
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
+  int actor_rows;                // rows per workgroup of the fused rollout actor: 0 = by batch size, 16, 32 (HX_ACTOR_ROWS)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
   uint32_t seed_lo, seed_hi, act_counter, perm_counter, perm_key;
   uint32_t row_base = 0;         // global index of this learner's first env row (hx_ppo_set_row_base): counter word of the action-noise stream
@@ -1779,6 +1792,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_UPDATE_STREAMS", 1, 1, 2, &knob_streams)) return rc;
   if (int rc = hx_knob_int("HX_ACTOR_WAVES", 8, 4, 8, &s->actor_waves)) return rc;
   if (s->actor_waves != 4 && s->actor_waves != 8) { hx_set_error("HX_ACTOR_WAVES: 4 or 8"); return -2; }
+  if (int rc = hx_knob_int("HX_ACTOR_ROWS", 0, 0, 32, &s->actor_rows)) return rc;
+  if (s->actor_rows != 0 && s->actor_rows != 16 && s->actor_rows != 32) { hx_set_error("HX_ACTOR_ROWS: 0 (by batch size), 16 or 32"); return -2; }
   if (int rc = hx_knob_int("HX_CRITIC_LATE", 0, 0, 1, &s->critic_late)) return rc;
   if (int rc = hx_knob_int("HX_BG_PERSIST", -1, 0, 4096, &knob_bg_persist)) return rc;
   if (int rc = hx_knob_int("HX_FWD_IN_TILE", 128, 64, 128, &s->fwd_in_tile)) return rc;
@@ -1949,6 +1964,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   // 8 waves (each streams 1/8 of a layer's weight rows) keep twice the bytes in flight per CU: 68 us per call against
   // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
   for (int l = 0; l < 3; ++l) s->apack[l] = nullptr;
@@ -2155,6 +2172,19 @@ static void gemm_dgrad_pair(hx_ppo* s, int l, int M, hipStream_t st) {
   else launch_gemm_group<64, 128, 32, true, false, EPI_ELU_GRAD, false>(s, G, st);
 }
 
+// dynamic LDS of the fused actor: rt = 1: X, H1, H2, H3 side by side; rt = 2: two shared buffers (max(X, H2) and max(H1, H3) wide)
+static size_t fa_lds_bytes(int in_ld, int rt) {
+  if (rt == 1) return (size_t)(FA_ROWS * (in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
+  const int wa = (in_ld + 4 > 256 + 4) ? in_ld + 4 : 256 + 4;
+  return (size_t)(32 * (wa + 512 + 4)) * sizeof(float);
+}
+// 16-row workgroups; HX_ACTOR_ROWS=32 selects the 32-row form (measured SLOWER at 4096 rows: collection 18.3 against 16.9 ms per
+// iteration, profiles/r04_t_actor_rows.txt -- with 128 workgroups of 8 waves the per-wave MFMA chain, not the L2 stream, sets the time)
+static int fa_row_tiles(hx_ppo* s, int rows) {
+  (void)rows;
+  if (s->actor_rows == 32) return (s->actor_waves == 8 && fa_lds_bytes(s->L[0].in_ld, 2) <= 150 * 1024) ? 2 : 1;
+  return 1;
+}
 // values for rollout slots [crit_done, upto) on the second stream: one critic forward over (slots * N) rows
 static int critic_flush(hx_ppo* s, int upto, bool after_rollout = false) {
   const int N = s->cfg.num_envs;
@@ -2222,15 +2252,19 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
         }
         s->apack_dirty = false;
       }
-      const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
+      const int rt = fa_row_tiles(s, count);
+      const size_t shm = fa_lds_bytes(La[0].in_ld, rt);
 #define HX_FA_ARGS so, s->cfg.obs_ld, count, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                        \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, eps, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts,        \
                    s->s_mu + ((size_t)t * N + env0) * A, s->s_logp + (size_t)t * N + env0, FrameSrc{nullptr, nullptr, nullptr, 0}, hx_step_book{}, 0, s->pause_flag
       // bf16 mode: the rollout actor rounds its operands exactly like the update's bf16 forward, otherwise the importance
       // ratio of the first epoch is not 1 (with fp32 here training plateaued 36 % lower, profiles/r01_k_bf16.txt)
-      const dim3 fgrid((count + FA_ROWS - 1) / FA_ROWS);
-      if (s->actor_waves == 8) {
+      const dim3 fgrid((count + 16 * rt - 1) / (16 * rt));
+      if (s->actor_waves == 8 && rt == 2) {
+        if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 8, 2>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+        else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 2>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+      } else if (s->actor_waves == 8) {
         if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
         else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
       } else {
@@ -2297,14 +2331,16 @@ static int act_frames(hx_ppo* s, const hx_step_book* book, float** actions_out) 
       }
       s->apack_dirty = false;
     }
-    const size_t shm = (size_t)(FA_ROWS * (La[0].in_ld + 4 + 512 + 4 + 256 + 4 + 128 + 4) + FA_ROWS * MAX_A) * sizeof(float);
+    const int rt = fa_row_tiles(s, N);
+    const size_t shm = fa_lds_bytes(La[0].in_ld, rt);
     hx_step_book bk{}; if (book) bk = *book;
 #define HX_FA_ARGS (const float*)nullptr, 0, N, s->apack[0], s->params + La[0].b, La[0].in_ld, La[0].out, s->apack[1],                       \
                    s->params + La[1].b, La[1].out, s->apack[2], s->params + La[2].b, La[2].out, s->params + La[3].w,                      \
                    s->params + La[3].b, s->params + s->std_off, (const float*)nullptr, A, s->seed_lo, s->seed_hi, s->act_counter, s->row_base, acts, \
                    s->s_mu + (size_t)t * N * A, s->s_logp + (size_t)t * N, fsrc, bk, book ? 1 : 0, s->pause_flag
-    const dim3 fgrid((N + FA_ROWS - 1) / FA_ROWS);
-    if (s->actor_waves == 8) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+    const dim3 fgrid((N + 16 * rt - 1) / (16 * rt));
+    if (s->actor_waves == 8 && rt == 2) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 2>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+    else if (s->actor_waves == 8) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
     else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
 #undef HX_FA_ARGS
   } else {
