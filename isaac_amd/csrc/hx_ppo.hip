@@ -280,10 +280,72 @@ __device__ __forceinline__ void fa_layer(const float* __restrict__ Xs, int ldx, 
   }
 }
 
+// The same layer with D weight blocks in flight per wave (HX_ACTOR_DEPTH; fa_layer above is D = 2 written out by hand): a ring of
+// D + 1 block buffers with STATIC indices only (the k loop advances D + 1 blocks per trip and its body is unrolled), blocks past the
+// end re-read the last one and meet a zero A operand.
+template <int NT, int D>
+__device__ __forceinline__ void fa_prefetch_d(const float* __restrict__ W, int K, int n_wave0, int lane, f32x4v (*buf)[NT]) {
+  const int nkb = (K + 15) / 16;
+  const f32x4v* __restrict__ Wp = reinterpret_cast<const f32x4v*>(W) + (size_t)(n_wave0 >> 4) * nkb * 64 + lane;
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) buf[d][t] = Wp[((size_t)t * nkb + min(d, nkb - 1)) * 64];
+}
+template <int NT, bool BF, bool ROUND_OUT, int RT, int D>
+__device__ __forceinline__ void fa_layer_d(const float* __restrict__ Xs, int ldx, int K, const float* __restrict__ W, const float* __restrict__ bias,
+                                           float* __restrict__ Hs, int ldh, int n_wave0, int lane, f32x4v (*buf)[NT]) {
+  const int r16 = lane & 15, kq = lane >> 4;
+  f32x4v acc[RT][NT];
+#pragma unroll
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[q][t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+  const int nkb = (K + 15) / 16;
+  const f32x4v* __restrict__ Wp = reinterpret_cast<const f32x4v*>(W) + (size_t)(n_wave0 >> 4) * nkb * 64 + lane;
+  for (int kb = 0; kb < nkb; kb += D + 1) {
+#pragma unroll
+    for (int u = 0; u <= D; ++u) {
+      {                                               // request block kb + u + D into the buffer that block kb + u - 1 has left
+        const int kc = min(kb + u + D, nkb - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) buf[(u + D) % (D + 1)][t] = Wp[((size_t)t * nkb + kc) * 64];
+      }
+      f32x4v* bc = buf[u];
+      if (BF) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bc[t] = hx_bf16r4(bc[t]);
+      }
+      const int k = (kb + u) * 16 + 4 * kq;
+      f32x4v a[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) { a[q] = (f32x4v){0.f, 0.f, 0.f, 0.f}; if (k < K) a[q] = *reinterpret_cast<const f32x4v*>(Xs + (q * 16 + r16) * ldx + k); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int q = 0; q < RT; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][i], bc[t][i], acc[q][t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = n_wave0 + t * 16 + r16;
+    const float bv = bias[col];
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float o = hx_elu(acc[q][t][r] + bv);
+        Hs[(q * 16 + kq * 4 + r) * ldh + col] = ROUND_OUT ? hx_bf16r(o) : o;
+      }
+  }
+}
+
 // RT = 16-row tiles per workgroup.  RT = 2 (32 rows, HX_ACTOR_ROWS=32, an experiment): half as many workgroups stream the 1.9 MB of
 // weights out of the L2 and every fragment feeds two MFMAs; measured slower (fa_row_tiles).  The activations then share two LDS
 // buffers: X and H2 in one, H1 and H3 in the other (a layer's input is dead once its output is complete).
-template <bool BF, int NW, int RT = 1>   // NW waves per workgroup (4 or 8): each owns 1/NW of a layer's output columns
+template <bool BF, int NW, int RT = 1, int D = 0>   // NW waves per workgroup (4 or 8): each owns 1/NW of a layer's output columns; D > 0: fa_layer_d
 __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __restrict__ obs, int obs_ld, int n,
                                                              const float* __restrict__ W1, const float* __restrict__ b1, int K1, int N1,
                                                              const float* __restrict__ W2, const float* __restrict__ b2, int N2,
@@ -306,7 +368,10 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * ROWS;
   f32x4v p1a[32 / NW], p1b[32 / NW], p2a[16 / NW], p2b[16 / NW], p3a[8 / NW], p3b[8 / NW];
-  fa_prefetch<32 / NW>(W1, K1, wave * (512 / NW), lane, p1a, p1b);
+  constexpr int DD = D > 0 ? D : 1;
+  f32x4v q1[DD + 1][32 / NW], q2[DD + 1][16 / NW], q3[DD + 1][8 / NW];
+  if (D > 0) fa_prefetch_d<32 / NW, DD>(W1, K1, wave * (512 / NW), lane, q1);
+  else fa_prefetch<32 / NW>(W1, K1, wave * (512 / NW), lane, p1a, p1b);
   if (fsrc.base != nullptr) {
     // Single-frame storage (include/hx_sim.h): the 16 rows are windows of the robots' frame rings.  Row start and first valid
     // element come from the tables; elements before it (frames older than the robot's last reset) and the padding read as
@@ -343,6 +408,16 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     }
   }
   __syncthreads();
+  if (D > 0) {
+    fa_prefetch_d<16 / NW, DD>(W2, N1, wave * (256 / NW), lane, q2);
+    fa_layer_d<32 / NW, BF, BF, RT, DD>(Xs, ldx, K1, W1, b1, H1, ld1, wave * (512 / NW), lane, q1);
+    __syncthreads();
+    fa_prefetch_d<8 / NW, DD>(W3, N2, wave * (128 / NW), lane, q3);
+    fa_layer_d<16 / NW, BF, BF, RT, DD>(H1, ld1, N1, W2, b2, H2, ld2, wave * (256 / NW), lane, q2);
+    __syncthreads();
+    fa_layer_d<8 / NW, BF, false, RT, DD>(H2, ld2, N2, W3, b3, H3, ld3, wave * (128 / NW), lane, q3);
+    __syncthreads();
+  } else {
   fa_prefetch<16 / NW>(W2, N1, wave * (256 / NW), lane, p2a, p2b);
   fa_layer<32 / NW, BF, BF, RT>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane, p1a, p1b);      // 615(616) -> 512
   __syncthreads();
@@ -351,6 +426,7 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   __syncthreads();
   fa_layer<8 / NW, BF, false, RT>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane, p3a, p3b);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
   __syncthreads();
+  }
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]; one thread per (row, action) also samples its action and leaves its
   // log-prob term in LDS; the row's thread then adds the terms in action order (the order of the serial loop it replaces)
   float* sTerm = (RT == 1) ? H1 : Xs;       // dead by now: layer-1 activations (RT = 1); X / H2 (RT = 2, where H1's place holds H3)
@@ -1204,6 +1280,7 @@ struct hx_ppo {
   int prof_every = 1; long prof_seen = 0;      // bracket every prof_every-th launch of the selected symbols
   bool bf16;                     // forward / dgrad products on the bf16 matrix cores (hx_gemm_bf16.h)
   int actor_waves;               // waves per workgroup of the fused rollout actor (8; 4 with HX_ACTOR_WAVES=4)
+  int actor_depth;               // weight blocks in flight per wave of the fused actor: 2 (hand-written loop), 3, 4, 6 (HX_ACTOR_DEPTH)
   int actor_rows;                // rows per workgroup of the fused rollout actor: 0 = by batch size, 16, 32 (HX_ACTOR_ROWS)
   float* wT[8];                  // fp32 transposed copies W^T[in][out] of the hidden weights the dgrads need (bf16 mode)
   uint32_t seed_lo, seed_hi, act_counter, perm_counter, perm_key;
@@ -1792,6 +1869,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_UPDATE_STREAMS", 1, 1, 2, &knob_streams)) return rc;
   if (int rc = hx_knob_int("HX_ACTOR_WAVES", 8, 4, 8, &s->actor_waves)) return rc;
   if (s->actor_waves != 4 && s->actor_waves != 8) { hx_set_error("HX_ACTOR_WAVES: 4 or 8"); return -2; }
+  if (int rc = hx_knob_int("HX_ACTOR_DEPTH", 2, 2, 6, &s->actor_depth)) return rc;
+  if (s->actor_depth == 5) { hx_set_error("HX_ACTOR_DEPTH: 2, 3, 4 or 6"); return -2; }
   if (int rc = hx_knob_int("HX_ACTOR_ROWS", 0, 0, 32, &s->actor_rows)) return rc;
   if (s->actor_rows != 0 && s->actor_rows != 16 && s->actor_rows != 32) { hx_set_error("HX_ACTOR_ROWS: 0 (by batch size), 16 or 32"); return -2; }
   if (int rc = hx_knob_int("HX_CRITIC_LATE", 0, 0, 1, &s->critic_late)) return rc;
@@ -1965,6 +2044,9 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8, 1, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   // 8 waves (each streams 1/8 of a layer's weight rows) keep twice the bytes in flight per CU: 68 us per call against
   // 74 us with 4 waves at 4096 rows (profiles/r01_g_actor_ring.txt); results are bitwise the same.  HX_ACTOR_WAVES=4 for A/B runs.
@@ -2266,6 +2348,9 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
         else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 2>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
       } else if (s->actor_waves == 8) {
         if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+        else if (s->actor_depth == 3) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 1, 3>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+        else if (s->actor_depth == 4) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 1, 4>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+        else if (s->actor_depth == 6) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 1, 6>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
         else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
       } else {
         if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
