@@ -49,20 +49,21 @@ template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int WM, int WN> struct 
 // iteration kinds of the K loop (the steady state carries no conditional code)
 enum { SP_STEADY = 0, SP_LASTLOAD = 1, SP_WRITEONLY = 2, SP_FINAL = 3 };
 
+// what a call does with its accumulators (stream-K segments, hx_gemm_sk_kernel): SP_WHOLE the product's epilogue; SP_PART_OUT no
+// epilogue, the raw accumulators go to `partial` ([register][thread], coalesced); SP_PART_IN `partial` (another workgroup's part of the
+// same tile, same layout) is added to them before the epilogue
+enum { SP_WHOLE = 0, SP_PART_OUT = 1, SP_PART_IN = 2 };
+
+// One tile over the reduction range [k_begin, k_end) (k_begin a multiple of the K tile; only the reduction's last K tile may be partial).
 template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL>
-__device__ __forceinline__ void hx_gemm_tile_sp(const GemmArgs& g, const int logical, float* __restrict__ lds) {
+__device__ __forceinline__ void hx_gemm_tile_sp_ex(const GemmArgs& g, const int tile_m, const int tile_n, const int split, const int k_begin, const int k_end,
+                                                   float* __restrict__ lds, const int mode = SP_WHOLE, float* __restrict__ partial = nullptr) {
   using P = GemmSp<BM, BN, BKT, A_KM, B_KM, WM, WN>;
   constexpr int NT = P::NT, WTM = P::WTM, WTN = P::WTN, TM = P::TM, TN = P::TN;
   constexpr int A_ELEMS = P::A_ELEMS, STAGE = P::STAGE, A_LOADS = P::A_LOADS, B_LOADS = P::B_LOADS, NW = P::NW;
   constexpr int NB = P::NB, MF = P::MF, RA = P::RA, R = P::R;
   constexpr int BARRIER_SLOT = 2;
-  const int tiles_mn = g.tiles_m * g.tiles_n;
-  const int split = logical / tiles_mn;
-  const int t = logical % tiles_mn;
-  const int tile_m = t / g.tiles_n, tile_n = t % g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  int k_begin = 0, k_end = g.K;
-  if (EPI == EPI_SLAB) { k_begin = split * g.kchunk; k_end = min(g.K, k_begin + g.kchunk); }
   const int nk = (k_end - k_begin + BKT - 1) / BKT;
 
   const int tid = threadIdx.x;
@@ -247,6 +248,23 @@ __device__ __forceinline__ void hx_gemm_tile_sp(const GemmArgs& g, const int log
     tile_iter(std::integral_constant<int, SP_FINAL>{}, kt);
   }
 
+  if (mode == SP_PART_OUT) {             // uniform
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) partial[(size_t)((i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+    return;
+  }
+  if (mode == SP_PART_IN) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] += partial[(size_t)((i * TN + j) * 16 + e) * NT + tid];
+  }
   // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   float* Cb = g.C;
   if (EPI == EPI_SLAB) Cb += (size_t)split * g.M * g.ldc;
@@ -339,6 +357,16 @@ __device__ __forceinline__ void hx_gemm_tile_sp(const GemmArgs& g, const int log
 }
 
 template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL>
+__device__ __forceinline__ void hx_gemm_tile_sp(const GemmArgs& g, const int logical, float* __restrict__ lds) {
+  const int tiles_mn = g.tiles_m * g.tiles_n;
+  const int split = logical / tiles_mn;
+  const int t = logical % tiles_mn;
+  int k_begin = 0, k_end = g.K;
+  if (EPI == EPI_SLAB) { k_begin = split * g.kchunk; k_end = min(g.K, k_begin + g.kchunk); }
+  hx_gemm_tile_sp_ex<BM, BN, BKT, A_KM, B_KM, EPI, WM, WN, KFULL>(g, t / g.tiles_n, t % g.tiles_n, split, k_begin, k_end, lds);
+}
+
+template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL>
 __global__ void __launch_bounds__(64 * WM * WN) hx_gemm_sp_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[GemmSp<BM, BN, BKT, A_KM, B_KM, WM, WN>::FLOATS];
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -358,6 +386,79 @@ __global__ void __launch_bounds__(64 * WM * WN) hx_gemm_sp_group_kernel(GemmGrou
 #pragma unroll
   for (int i = 1; i < HX_GROUP_MAX; ++i) if (pi == i) g = G.p[i];
   hx_gemm_tile_sp<BM, BN, BKT, A_KM, B_KM, EPI, WM, WN, KFULL>(g, logical, lds);
+}
+
+// ---- forward / input-gradient products at ONE workgroup per CU: a stream-K cut ---------------------------------
+// 256 x 256 tiles at one wave per SIMD run the K loop at 0.95 of the pipe (above), but 61 440 rows x {768, 512} columns are 1200 such
+// tiles of two lengths on 256 CUs: 4.7 rounds, and a launch ends with the last round's slowest tile (measured 1136 us against 1075 us
+// for the 128 x 128 kernel at three workgroups per CU).  So the launch is cut by WORK, not by tiles: the K tiles of all output tiles of
+// all members form one sequence (member-major, tile-major, k-minor) and workgroup b of G takes the b-th G-th of it.  A range covers a
+// few whole tiles plus, at most, the TAIL of a tile at its start and the HEAD of one at its end (a range is never shorter than a
+// tile's K loop: the host checks).  The workgroup that computes a tile's head owns the tile: it does that segment LAST in its range,
+// adds the partial sums the next workgroup left for it -- computed FIRST in that workgroup's range, so they are long there -- and runs
+// the epilogue.  Hand-over: cdna_hip_programming.md Guideline 16 (every storing wave drains, barrier, one lane's agent-scope release,
+// a relaxed flag store; the owner's lane polls relaxed with s_sleep and a bound, one agent-scope acquire, barrier, plain loads).  A
+// flag holds the launch's epoch (a counter the host increments per launch), so nothing is re-zeroed between launches.  Sums: a split
+// tile adds (head partial) + (tail partial) instead of one chain over k -- fixed by the shapes alone, so results are reproducible run to
+// run, and equal to hx_gemm.h's to fp32 round-off on the ~G split tiles and bit for bit on all others.
+struct GemmSk {
+  GemmGroup G;                        // members (tiles_m / tiles_n filled; first[] unused)
+  int nk[HX_GROUP_MAX];               // K tiles per output tile of a member
+  long long it0[HX_GROUP_MAX + 1];    // first K tile of a member in the launch's sequence
+  float* partial;                     // [workgroups][accumulator registers][threads]
+  unsigned* flags;                    // [workgroups]: epoch of the last launch in which workgroup b published its partial tile
+  unsigned epoch;
+  int* err;                           // set to 1 if a wait ran out of its budget (the result is then wrong; the host checks)
+};
+template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL>
+__global__ void __launch_bounds__(64 * WM * WN) hx_gemm_sk_kernel(GemmSk S) {
+  using P = GemmSp<BM, BN, BKT, A_KM, B_KM, WM, WN>;
+  __shared__ __attribute__((aligned(16))) float lds[P::FLOATS];
+  constexpr size_t SLOT = (size_t)P::TM * P::TN * 16 * P::NT;          // floats of one workgroup's partial tile
+  const int b = blockIdx.x, nwg = gridDim.x, tid = threadIdx.x;
+  const long long total = S.it0[S.G.n];
+  const long long begin = total * b / nwg, end = total * (b + 1) / nwg;
+  long long it = begin;
+  while (it < end) {
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < HX_GROUP_MAX; ++i) if (i < S.G.n && it >= S.it0[i]) m = i;
+    GemmArgs g = S.G.p[0]; int nk = S.nk[0]; long long base = S.it0[0];
+#pragma unroll
+    for (int i = 1; i < HX_GROUP_MAX; ++i) if (m == i) { g = S.G.p[i]; nk = S.nk[i]; base = S.it0[i]; }
+    const long long rel = it - base;
+    const int tile = (int)(rel / nk), ks = (int)(rel % nk);
+    const int ke = (int)((long long)nk < ks + (end - it) ? (long long)nk : ks + (end - it));
+    const int tile_m = tile / g.tiles_n, tile_n = tile % g.tiles_n;
+    const int k_begin = ks * BKT, k_end = min(g.K, ke * BKT);
+    int mode = SP_WHOLE;
+    float* part = nullptr;
+    if (ks > 0) { mode = SP_PART_OUT; part = S.partial + (size_t)b * SLOT; }
+    else if (ke < nk) {
+      // owner of a tile whose tail the next workgroup computed at the start of its range
+      mode = SP_PART_IN; part = S.partial + (size_t)(b + 1) * SLOT;
+      if (tid == 0) {
+        int budget = 1 << 22;                    // x s_sleep(32): seconds; never reached unless the next workgroup never ran
+        while (__hip_atomic_load(S.flags + b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != S.epoch && --budget > 0) __builtin_amdgcn_s_sleep(32);
+        if (budget <= 0) atomicExch(S.err, 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    hx_gemm_tile_sp_ex<BM, BN, BKT, A_KM, B_KM, EPI, WM, WN, KFULL>(g, tile_m, tile_n, 0, k_begin, k_end, lds, mode, part);
+    if (mode == SP_PART_OUT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(S.flags + b, S.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();          // the next segment's first LDS stores must not overtake this one's last fragment reads
+    it += ke - ks;
+  }
 }
 
 // ---- the weight gradients of a minibatch at ONE workgroup per CU ---------------------------------------------
