@@ -2232,6 +2232,8 @@ static void mlp_hidden_fwd_pair(hx_ppo* s, int l0, const float* Xa, int ldxa, co
     }
     if (kfull && s->gemm_sp && M >= 16384 && G.p[0].K >= 512 && G.p[1].K >= 512) launch_gemm_sp_group<128, 128, 32, true, true, EPI_BIAS_ELU, 2, 2, true>(s, G, st);
     else if (kfull) launch_gemm_group<128, 128, 32, true, true, EPI_BIAS_ELU, true>(s, G, st);
+    // the two input layers (K = 616 / 1052): 256 x 256 tiles on eight waves, one workgroup per CU, +1.5 % (profiles/r04_b_gemm_lab.txt, r04_w)
+    else if (s->gemm_sp && M >= 16384 && l == 0) launch_gemm_sp_group<256, 256, 16, true, true, EPI_BIAS_ELU, 2, 4, false>(s, G, st);
     else launch_gemm_group<128, 128, 16, true, true, EPI_BIAS_ELU, false>(s, G, st);
   }
 }

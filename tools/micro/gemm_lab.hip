@@ -171,6 +171,8 @@ int main(int argc, char** argv) {
     c.v.push_back({"sp  256x256x16 4w", launch_sp<256, 256, 16, true, true, EPI_BIAS_ELU, 2, 2, false>, 256, 256});
     c.v.push_back({"sp  256x256x16 8w", launch_sp<256, 256, 16, true, true, EPI_BIAS_ELU, 2, 4, false>, 256, 256});
     c.v.push_back({"sk  256x256x16 4w", launch_sk<256, 256, 16, true, true, EPI_BIAS_ELU, 2, 2, false>, 256, 256});
+    c.v.push_back({"sk  256x128x16 4w", launch_sk<256, 128, 16, true, true, EPI_BIAS_ELU, 2, 2, false>, 256, 128});
+    c.v.push_back({"sk  128x256x16 4w", launch_sk<128, 256, 16, true, true, EPI_BIAS_ELU, 2, 2, false>, 128, 256});
     cases.push_back(c);
   }
   for (int l = 1; l < 3; ++l) {
