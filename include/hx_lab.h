@@ -32,6 +32,10 @@ int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, int lda, con
  * reduction).  The pointer tables are HOST arrays of DEVICE pointers; slots <= 0: one workgroup per CU. */
 int hx_ppo_wgrad_multi_test(int nl, const int* out_h, const int* in_ld_h, int rows, const float* const* dZ_h, const float* const* X_h,
                             float* const* dW_h, float* const* db_h, int slots, int* nlaunch_h, void* hip_stream);
+/* the plan behind it, computed on the host only (no GPU call): 12 numbers per piece -- layer, first column, columns, shape id, tile rows, tile
+ * columns, tiles, slices, rows per slice, launch, slab offset (floats), bias-slab offset or -1 */
+int hx_wgrad_plan_describe(int nl, const int* out_h, const int* in_ld_h, int rows, int slots, long long* pieces_h, int max_pieces, int* n_pieces,
+                           int* nlaunch_h, long long* slab_floats_h);
 /* timing hook: mean ms per launch of one learner GEMM (kind 0 fwd, 1 dgrad, 2 wgrad split-K; bk 16 or 32) */
 int hx_ppo_gemm_bench(int kind, int bk, int rows, int out, int in_ld, int iters, float* ms_out);
 /* measurement hook: TFLOP/s of 256-thread workgroups whose waves issue n v_mfma_f32_32x32x2_f32 each with, by mode,

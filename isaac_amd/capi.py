@@ -177,6 +177,8 @@ def lib():
     L.hx_ppo_inference.argtypes = [vp, vp, C.c_int, vp]
     L.hx_ppo_prof_begin.argtypes = [vp, C.c_char_p, C.c_int]
     L.hx_ppo_prof_end.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
+    L.hx_wgrad_plan_describe.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.hx_sim_prof_waves.argtypes = [vp, vp, C.c_int]
     L.hx_ppo_gemm_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.hx_ppo_gemm_test.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]

@@ -1632,6 +1632,27 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   return 0;
 }
 
+// the planner's output for `nl` layers, without touching the GPU (tests/test_host_logic.py): rows of
+// {layer, col0, ncols, shape, tile rows, tile cols, tiles, splits, kchunk, launch, slab offset (floats), bias slab offset or -1}
+extern "C" int hx_wgrad_plan_describe(int nl, const int* out_h, const int* in_ld_h, int rows, int slots, long long* pieces_h, int max_pieces, int* n_pieces,
+                                      int* nlaunch_h, long long* slab_floats_h) {
+  if (nl < 1 || nl > 6 || !pieces_h || !n_pieces || slots < 1) { hx_set_error("hx_wgrad_plan_describe: bad argument"); return -2; }
+  WgradLayerDesc wl[6];
+  for (int l = 0; l < nl; ++l) wl[l] = WgradLayerDesc{out_h[l], in_ld_h[l]};
+  const WgradPlan plan = hx_wgrad_plan(wl, nl, rows, slots);
+  if ((int)plan.pieces.size() > max_pieces) { hx_set_error("hx_wgrad_plan_describe: more pieces than room"); return -2; }
+  int k = 0;
+  for (const WgradPiece& p : plan.pieces) {
+    long long* r = pieces_h + 12 * k++;
+    r[0] = p.layer; r[1] = p.col0; r[2] = p.ncols; r[3] = p.shape; r[4] = HX_WSHAPE[p.shape].bm; r[5] = HX_WSHAPE[p.shape].bn; r[6] = p.tiles; r[7] = p.splits;
+    r[8] = p.kchunk; r[9] = p.launch; r[10] = (long long)p.slab_off; r[11] = p.bias ? (long long)p.bslab_off : -1;
+  }
+  *n_pieces = k;
+  if (nlaunch_h) *nlaunch_h = plan.nlaunch;
+  if (slab_floats_h) *slab_floats_h = (long long)plan.slab_floats;
+  return 0;
+}
+
 // unit-test hook (tests/test_gpu_gemm.py): the weight gradients of `nl` layers over `rows` rows through the planner, the
 // multi-shape kernel and the slab reduction, on caller-supplied device buffers; slots = 0: one workgroup per CU of this device
 extern "C" int hx_ppo_wgrad_multi_test(int nl, const int* out_h, const int* in_ld_h, int rows, const float* const* dZ_h, const float* const* X_h,

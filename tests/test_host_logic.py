@@ -51,3 +51,57 @@ def test_actor_critic_state_dict_layout():
     assert ac.num_params() == 1_517_973
     sd = ac.state_dict()
     assert sd["actor.0.weight"].shape == (512, 615) and abs(sd["actor.0.weight"]).max() <= 1 / np.sqrt(615) + 1e-6
+
+
+def _wgrad_plan(layers, rows, slots):
+    import ctypes as C
+    from isaac_amd import capi
+    L = capi.lib()
+    nl = len(layers)
+    buf = (C.c_longlong * (12 * 16))()
+    n, nlaunch, slab = C.c_int(0), C.c_int(0), C.c_longlong(0)
+    capi.check(L.hx_wgrad_plan_describe(nl, (C.c_int * nl)(*[o for o, _ in layers]), (C.c_int * nl)(*[i for _, i in layers]), rows, slots, buf, 16,
+                                        C.byref(n), C.byref(nlaunch), C.byref(slab)), "plan")
+    keys = ("layer", "col0", "ncols", "shape", "bm", "bn", "tiles", "splits", "kchunk", "launch", "slab_off", "bslab_off")
+    return [dict(zip(keys, buf[12 * k:12 * k + 12])) for k in range(n.value)], nlaunch.value, slab.value
+
+
+def test_weight_gradient_plan_properties():
+    """The host planner of the one-workgroup-per-CU weight gradients (isaac_amd/csrc/hx_wgrad_plan.h), no GPU needed: every column of
+    every layer belongs to exactly one piece, the pieces of a launch fit the CUs, slices cover the rows in whole K tiles, slab regions
+    do not overlap, and the workgroups of a launch are balanced (the point of the planner)."""
+    import numpy as np
+    hector = [(512, 616), (256, 512), (128, 256), (768, 1052), (256, 768), (128, 256)]          # actor then critic, as the learner orders them
+    for layers, rows, slots in ((hector, 61440, 256), (hector, 61440, 304), (hector, 16384, 256), (hector, 960, 256),
+                                ([(512, 708), (256, 512), (128, 256), (768, 220), (256, 768), (128, 256)], 61440, 256),
+                                ([(100, 260), (36, 36), (132, 1060)], 1024, 40)):
+        pieces, nlaunch, slab = _wgrad_plan(layers, rows, slots)
+        assert 1 <= nlaunch <= 2 and 1 <= len(pieces) <= 12
+        for l, (out, ind) in enumerate(layers):
+            cover = np.zeros(ind, int)
+            mine = [p for p in pieces if p["layer"] == l]
+            for p in mine:
+                cover[p["col0"]:p["col0"] + p["ncols"]] += 1
+                assert p["col0"] % 4 == 0 and p["ncols"] % 4 == 0 and p["ncols"] > 0
+                assert p["tiles"] == -(-out // p["bm"]) * -(-p["ncols"] // p["bn"])
+            assert (cover == 1).all(), (l, cover)
+            assert sum(1 for p in mine if p["bslab_off"] >= 0) == 1          # one piece per layer carries the bias gradient
+        for q in range(nlaunch):
+            wgs = sum(p["tiles"] * p["splits"] for p in pieces if p["launch"] == q)
+            assert 0 < wgs <= slots, (q, wgs)
+        for p in pieces:
+            assert p["kchunk"] % 32 == 0 and p["splits"] * p["kchunk"] >= rows > (p["splits"] - 1) * p["kchunk"]
+        spans = sorted((p["slab_off"], p["slab_off"] + p["splits"] * layers[p["layer"]][0] * p["ncols"]) for p in pieces)
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] == slab
+    # the headline configuration: two launches of exactly one workgroup per CU, the critic's 1052-wide layer as 1024 + 28 columns, and
+    # every workgroup's K loop (MFMA tiles per wave x rows per slice, the strip's weighted by its slower loop) within 12 % of the longest
+    pieces, nlaunch, _ = _wgrad_plan(hector, 61440, 256)
+    assert nlaunch == 2
+    crit = sorted((p["col0"], p["ncols"], p["bm"], p["bn"]) for p in pieces if p["layer"] == 3)
+    assert crit == [(0, 1024, 256, 256), (1024, 28, 512, 32)], crit
+    units = {(256, 256): 16, (512, 128): 16 * 1.07, (128, 256): 8 * 1.10, (128, 128): 4 * 1.16, (512, 32): 4 * 1.30}
+    for q in range(nlaunch):
+        mine = [p for p in pieces if p["launch"] == q]
+        assert sum(p["tiles"] * p["splits"] for p in mine) >= 250
+        cost = [units[(p["bm"], p["bn"])] * (p["kchunk"] + 150) for p in mine]
+        assert min(cost) > 0.88 * max(cost), (q, cost)
