@@ -327,7 +327,7 @@ __device__ __forceinline__ void hx_gemm_tile_sp_ex(const GemmArgs& g, const int 
           vecT o;
 #pragma unroll
           for (int b = 0; b < TN; ++b) o[b] = apply(acc[a][b][e], bv[b], EPI == EPI_ELU_GRAD ? hv[e][b] : 0.f);
-          *reinterpret_cast<vecT*>(Cb + (size_t)out_row(a, e) * g.ldc + col0) = o;
+          *reinterpret_cast<vecT*>(Cb + (size_t)out_row(a, e) * g.ldc + col0) = o;      // (non-temporal slab stores: no difference, profiles/r04_b_gemm_lab.txt)
         }
       } else if (col0 < g.N) {     // N is a multiple of 4 and TN divides 4: a vector is inside or outside as a whole
 #pragma unroll
