@@ -55,9 +55,11 @@ enum { SP_STEADY = 0, SP_LASTLOAD = 1, SP_WRITEONLY = 2, SP_FINAL = 3 };
 enum { SP_WHOLE = 0, SP_PART_OUT = 1, SP_PART_IN = 2 };
 
 // One tile over the reduction range [k_begin, k_end) (k_begin a multiple of the K tile; only the reduction's last K tile may be partial).
-template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL>
+// POLL (the rollout's background critic): while *g.pause > 0 the workgroup sleeps between K tiles (hx_pause_poll, hx_gemm.h); the
+// gave-up state lives in *paused_io across the tiles of a persistent workgroup.
+template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL, bool POLL = false>
 __device__ __forceinline__ void hx_gemm_tile_sp_ex(const GemmArgs& g, const int tile_m, const int tile_n, const int split, const int k_begin, const int k_end,
-                                                   float* __restrict__ lds, const int mode = SP_WHOLE, float* __restrict__ partial = nullptr) {
+                                                   float* __restrict__ lds, const int mode = SP_WHOLE, float* __restrict__ partial = nullptr, int* paused_io = nullptr) {
   using P = GemmSp<BM, BN, BKT, A_KM, B_KM, WM, WN>;
   constexpr int NT = P::NT, WTM = P::WTM, WTN = P::WTN, TM = P::TM, TN = P::TN;
   constexpr int A_ELEMS = P::A_ELEMS, STAGE = P::STAGE, A_LOADS = P::A_LOADS, B_LOADS = P::B_LOADS, NW = P::NW;
@@ -205,10 +207,12 @@ __device__ __forceinline__ void hx_gemm_tile_sp_ex(const GemmArgs& g, const int 
 
   // One K tile.  On entry: fragments of (kt, block 0) are in fa[0] / fb[0] (read behind the previous barrier); ra / rb hold
   // tile kt+1 (loads in flight).  KIND says what exists beyond this tile.
+  int paused = (POLL && paused_io) ? *paused_io : 0;
   auto tile_iter = [&](auto kind_c, int kt) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr bool WRITE = (KIND != SP_FINAL), LOAD = (KIND == SP_STEADY || KIND == SP_LASTLOAD);
     const int cur = kt & 1;
+    if (POLL && g.pause != nullptr) hx_pause_poll(g.pause, paused);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int p = b & 1;
@@ -247,6 +251,7 @@ __device__ __forceinline__ void hx_gemm_tile_sp_ex(const GemmArgs& g, const int 
     if (kt + 2 == nk) { tile_iter(std::integral_constant<int, SP_WRITEONLY>{}, kt); ++kt; }
     tile_iter(std::integral_constant<int, SP_FINAL>{}, kt);
   }
+  if (POLL && paused_io) *paused_io = paused;
 
   if (mode == SP_PART_OUT) {             // uniform
 #pragma unroll
@@ -373,6 +378,20 @@ __global__ void __launch_bounds__(64 * WM * WN) hx_gemm_sp_kernel(GemmArgs g) {
   const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
   const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   hx_gemm_tile_sp<BM, BN, BKT, A_KM, B_KM, EPI, WM, WN, KFULL>(g, logical, lds);
+}
+
+// The product on a SMALL fixed grid whose workgroups walk the tiles -- the rollout's background critic (hx_gemm_persistent_kernel of
+// hx_gemm.h) on the slot-placed loop.  With WM x WN = 1 x 2 (two waves) and one workgroup per CU its waves take two SIMDs of every CU and
+// leave the other two free: the env step's 512-register waves then sit two per CU as when they have the chip to themselves, instead
+// of four per CU on the half of the chip that four-wave critic workgroups leave.
+template <int BM, int BN, int BKT, bool A_KM, bool B_KM, int EPI, int WM, int WN, bool KFULL>
+__global__ void __launch_bounds__(64 * WM * WN) hx_gemm_sp_persistent_kernel(GemmArgs g, int total_tiles) {
+  __shared__ __attribute__((aligned(16))) float lds[GemmSp<BM, BN, BKT, A_KM, B_KM, WM, WN>::FLOATS];
+  int paused = 0;
+  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    hx_gemm_tile_sp_ex<BM, BN, BKT, A_KM, B_KM, EPI, WM, WN, KFULL, true>(g, t / g.tiles_n, t % g.tiles_n, 0, 0, g.K, lds, SP_WHOLE, nullptr, &paused);
+    __syncthreads();
+  }
 }
 
 // several products in one launch: see hx_gemm_group_kernel (same block -> work map)

@@ -359,9 +359,18 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   // the background critic's persistent workgroups sleep while this count is up (hx_gemm.h GemmArgs::pause): the actor is on
   // the rollout's critical path and shares half the CUs with them
   if (pause != nullptr && threadIdx.x == 0) atomicAdd(pause, 1);
+#ifdef HX_ACTOR_PROF
+  // phase stamps of workgroup b (100 MHz ticks): pause[16 + 16 b + i]; tools/actor_prof.py
+#define HX_AST(i) do { if (pause != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) reinterpret_cast<long long*>(pause + 16)[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
+#else
+#define HX_AST(i) do { } while (0)
+#endif
+  HX_AST(0);
   const int ldx = K1 + 4, ld1 = N1 + 4, ld2 = N2 + 4, ld3 = N3 + 4;
   constexpr int ROWS = 16 * RT;
+  constexpr int W4_PER = (MAX_A * 128 + 64 * NW - 1) / (64 * NW);      // head weights per thread (A <= MAX_A actions x N3 = 128 inputs)
   float* Xs = fsm;
+  float* W4s = fsm;                          // RT = 1: over X, which is dead once layer 1 is complete
   float* H1 = Xs + ROWS * (ldx > ld2 ? ldx : ld2);
   float* H2 = (RT == 1) ? H1 + ROWS * ld1 : Xs;              // RT = 2: H2 over X, H3 over H1
   float* H3 = (RT == 1) ? H2 + ROWS * ld2 : H1;
@@ -408,6 +417,9 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     }
   }
   __syncthreads();
+  HX_AST(1);
+  // this thread's head bias and sigma, fetched behind the layers (thread i of the head owns (row i / A, action i % A))
+  const float hb4 = (tid < ROWS * A) ? b4[tid % A] : 0.f, hsg = (tid < ROWS * A) ? stdp[tid % A] : 0.f;
   if (D > 0) {
     fa_prefetch_d<16 / NW, DD>(W2, N1, wave * (256 / NW), lane, q2);
     fa_layer_d<32 / NW, BF, BF, RT, DD>(Xs, ldx, K1, W1, b1, H1, ld1, wave * (512 / NW), lane, q1);
@@ -421,11 +433,25 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   fa_prefetch<16 / NW>(W2, N1, wave * (256 / NW), lane, p2a, p2b);
   fa_layer<32 / NW, BF, BF, RT>(Xs, ldx, K1, W1, K1, b1, H1, ld1, wave * (512 / NW), lane, p1a, p1b);      // 615(616) -> 512
   __syncthreads();
+  HX_AST(2);
   fa_prefetch<8 / NW>(W3, N2, wave * (128 / NW), lane, p3a, p3b);
+  // the head's weights (A x N3 floats) on their way to LDS behind layer 2: the head then reads both operands of its dot products from
+  // LDS.  With W4 read from global memory inside the head's serial k loop the head took 5.9 us on average and up to 17 us in the
+  // slowest workgroup -- and a launch ends with its slowest workgroup (profiles/r04_t_actor_rows.txt, tools/actor_prof.py)
+  float w4r[W4_PER];
+#pragma unroll
+  for (int q = 0; q < W4_PER; ++q) { const int i = tid + q * 64 * NW; w4r[q] = (i < A * N3) ? W4[i] : 0.f; }
+
   fa_layer<16 / NW, BF, BF, RT>(H1, ld1, N1, W2, N1, b2, H2, ld2, wave * (256 / NW), lane, p2a, p2b);      // 512 -> 256
+  if (RT == 1) {
+#pragma unroll
+    for (int q = 0; q < W4_PER; ++q) { const int i = tid + q * 64 * NW; if (i < A * N3) W4s[i] = w4r[q]; }
+  }
   __syncthreads();
+  HX_AST(3);
   fa_layer<8 / NW, BF, false, RT>(H2, ld2, N2, W3, N2, b3, H3, ld3, wave * (128 / NW), lane, p3a, p3b);    // 256 -> 128; the head reads H3 unrounded, like the update's fp32 loss head
   __syncthreads();
+  HX_AST(4);
   }
   // head: mu[r][j] = W4[j] . H3[r] + b4[j]; one thread per (row, action) also samples its action and leaves its
   // log-prob term in LDS; the row's thread then adds the terms in action order (the order of the serial loop it replaces)
@@ -433,11 +459,13 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   for (int i = tid; i < ROWS * A; i += 64 * NW) {
     const int r = i / A, j = i % A;
     float m = 0.f;
-    for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4[j * N3 + k], m);
-    m += b4[j];
+    if (RT == 1 && D == 0) { for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4s[j * N3 + k], m); }
+    else { for (int k = 0; k < N3; ++k) m = fmaf(H3[r * ld3 + k], W4[j * N3 + k], m); }
+    const bool pre = (RT == 1 && D == 0 && ROWS * A <= 64 * NW);      // one pass: i == tid, bias and sigma were fetched behind layer 1
+    m += pre ? hb4 : b4[j];
     const int e = row0 + r;
     if (e < n) {
-      const float sg = m * 0.f + stdp[j];
+      const float sg = m * 0.f + (pre ? hsg : stdp[j]);
       float z;
       if (eps) z = eps[(size_t)e * A + j];
       else {
@@ -455,11 +483,13 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
     }
   }
   __syncthreads();
+  HX_AST(5);
   if (tid < ROWS && row0 + tid < n) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) lp += sTerm[tid * MAX_A + j];
     logp[row0 + tid] = lp;
   }
+  HX_AST(6);
   if (pause != nullptr && tid == 0) atomicSub(pause, 1);
 }
 
@@ -1260,6 +1290,7 @@ struct hx_ppo {
   int head_mfma;                 // 1: hector-shaped loss heads run on the matrix cores (HX_HEAD_MFMA)
   int* pause_flag = nullptr;     // count of fused-actor workgroups in flight; the background critic sleeps while it is up (HX_CRITIC_YIELD)
   int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
+  int bg_waves;                  // 4: hx_gemm_persistent_kernel (four waves per workgroup, half the CUs); 2: hx_gemm_sp_persistent_kernel (two waves, every CU) (HX_BG_WAVES)
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
   int step;
@@ -1396,6 +1427,12 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   // the env-step kernel waited for LDS (440 us instead of 200 us on the steps a critic burst overlaps,
   // profiles/r01_j_rollout_interference.txt).
   if (s->bf16 && !fp32_only) launch_gemm_bf16<EPI_BIAS_ELU>(s, g, st);   // every hidden-layer forward product in bf16 mode
+  else if (background && s->bg_persist > 0 && s->bg_waves == 2) {
+    // two-wave workgroups of the slot-placed loop, one per CU (hx_gemm_sp_persistent_kernel): two SIMDs of every CU stay free
+    g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 127) / 128;
+    if (K % 16 == 0) hipLaunchKernelGGL((hx_gemm_sp_persistent_kernel<64, 128, 16, true, true, EPI_BIAS_ELU, 1, 2, true>), dim3(s->bg_persist), dim3(128), 0, st, g, g.tiles_m * g.tiles_n);
+    else hipLaunchKernelGGL((hx_gemm_sp_persistent_kernel<64, 128, 16, true, true, EPI_BIAS_ELU, 1, 2, false>), dim3(s->bg_persist), dim3(128), 0, st, g, g.tiles_m * g.tiles_n);
+  }
   else if (background && s->bg_persist > 0) {
     // the rollout's background critic on a small fixed grid: see hx_gemm_persistent_kernel
     if (s->bg_tile != 128) {        // 64-row tiles: 31 KB of LDS beside the actor's 99 KB, and measured better (profiles/r02_e)
@@ -1630,6 +1667,18 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
 #undef HX_DISPATCH
   HX_CHECK(hipGetLastError());
   return 0;
+}
+
+// phase stamps of the fused actor's last launch (-DHX_ACTOR_PROF builds, tools/actor_prof.py): [blocks][8] 100 MHz ticks
+extern "C" int hx_ppo_actor_stamps(hx_ppo* s, long long* out_h, int blocks) {
+#ifdef HX_ACTOR_PROF
+  if (!s || !s->pause_flag || !out_h || blocks < 1 || blocks > 4096) { hx_set_error("hx_ppo_actor_stamps: bad argument"); return -2; }
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  HX_CHECK(hipMemcpy(out_h, s->pause_flag + 16, (size_t)blocks * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+#else
+  (void)s; (void)out_h; (void)blocks; hx_set_error("hx_ppo_actor_stamps: library built without -DHX_ACTOR_PROF"); return -2;
+#endif
 }
 
 // the planner's output for `nl` layers, without touching the GPU (tests/test_host_logic.py): rows of
@@ -1888,8 +1937,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   bool cu_set = false; unsigned cu_word = 0;
   if (int rc = hx_knob_hex32("HX_CRITIC_CU_WORD", &cu_set, &cu_word)) return rc;
   if (int rc = hx_knob_int("HX_UPDATE_STREAMS", 1, 1, 2, &knob_streams)) return rc;
-  if (int rc = hx_knob_int("HX_ACTOR_WAVES", 8, 4, 8, &s->actor_waves)) return rc;
-  if (s->actor_waves != 4 && s->actor_waves != 8) { hx_set_error("HX_ACTOR_WAVES: 4 or 8"); return -2; }
+  if (int rc = hx_knob_int("HX_ACTOR_WAVES", 8, 2, 8, &s->actor_waves)) return rc;
+  if (s->actor_waves != 2 && s->actor_waves != 4 && s->actor_waves != 8) { hx_set_error("HX_ACTOR_WAVES: 2 (probe, fp32 rows only), 4 or 8"); return -2; }
   if (int rc = hx_knob_int("HX_ACTOR_DEPTH", 2, 2, 6, &s->actor_depth)) return rc;
   if (s->actor_depth == 5) { hx_set_error("HX_ACTOR_DEPTH: 2, 3, 4 or 6"); return -2; }
   if (int rc = hx_knob_int("HX_ACTOR_ROWS", 0, 0, 32, &s->actor_rows)) return rc;
@@ -1899,6 +1948,8 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_FWD_IN_TILE", 128, 64, 128, &s->fwd_in_tile)) return rc;
   if (s->fwd_in_tile != 64 && s->fwd_in_tile != 128) { hx_set_error("HX_FWD_IN_TILE: 64 or 128"); return -2; }
   if (int rc = hx_knob_int("HX_BG_TILE", 0, 0, 128, &s->bg_tile)) return rc;
+  if (int rc = hx_knob_int("HX_BG_WAVES", 4, 2, 4, &s->bg_waves)) return rc;
+  if (s->bg_waves == 3) { hx_set_error("HX_BG_WAVES: 2 or 4"); return -2; }
   if (s->bg_tile != 0 && s->bg_tile != 64 && s->bg_tile != 128) { hx_set_error("HX_BG_TILE: 0 (by batch size), 64 or 128"); return -2; }
   if (int rc = hx_knob_int("HX_CRITIC_CHUNK", HX_CRITIC_CHUNK, 1, 4096, &s->critic_chunk)) return rc;
   if (int rc = hx_knob_int("HX_WGRAD_BLOCKS", 0, 1, 65536, &knob_wgrad)) return rc;
@@ -2050,7 +2101,11 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   rc |= palloc(s, &s->head_slab, (size_t)s->head_blocks_max * s->head_slab_w);
   rc |= palloc(s, &s->head_slab2, (size_t)((s->head_blocks_max + 31) / 32) * s->head_slab_w);
   rc |= palloc(s, &s->perm, TN);
+#ifdef HX_ACTOR_PROF
+  if (knob_yield) rc |= palloc(s, &s->pause_flag, 16 + 4096 * 16);      // + phase stamps of the fused actor's workgroups
+#else
   if (knob_yield) rc |= palloc(s, &s->pause_flag, 16);      // zeroed; only element 0 is used
+#endif
   rc |= palloc(s, &s->sumsq, 1); rc |= palloc(s, &s->sched, 1);
   if (rc) return -3;
   SchedState st0{cfg->learning_rate, 0.f, 0.f, 0.f};
@@ -2061,6 +2116,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   HX_CHECK(hipMemcpyAsync(s->params + s->std_off, sd.data(), sd.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
   HX_CHECK(hipStreamSynchronize(s->stream));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   HX_CHECK(hipFuncSetAttribute((const void*)hx_actor_fused_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -2079,7 +2135,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
     // the SIMDs of the other half.  More robots than that need every CU for the env step itself: ordinary launches then.
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    s->bg_persist = knob_bg_persist >= 0 ? knob_bg_persist : ((cfg->num_envs <= 16 * cus) ? cus / 2 : 0);
+    s->bg_persist = knob_bg_persist >= 0 ? knob_bg_persist : ((cfg->num_envs <= 16 * cus) ? (s->bg_waves == 2 ? cus : cus / 2) : 0);
   }
   {
     const int ha_ = cfg->actor_hidden[2], hc_ = cfg->critic_hidden[2];
@@ -2375,6 +2431,8 @@ static int act_impl(hx_ppo* s, const float* obs, const float* priv, const float*
         else if (s->actor_depth == 4) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 1, 4>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
         else if (s->actor_depth == 6) hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8, 1, 6>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
         else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 8>), fgrid, dim3(512), shm, st, HX_FA_ARGS);
+      } else if (s->actor_waves == 2) {
+        hipLaunchKernelGGL((hx_actor_fused_kernel<false, 2>), fgrid, dim3(128), shm, st, HX_FA_ARGS);      // probe of a two-wave actor
       } else {
         if (s->bf16) hipLaunchKernelGGL((hx_actor_fused_kernel<true, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);
         else hipLaunchKernelGGL((hx_actor_fused_kernel<false, 4>), fgrid, dim3(256), shm, st, HX_FA_ARGS);

@@ -272,7 +272,7 @@ void hx_set_error(const std::string& s) { g_err = s; }
 extern char** environ;
 int hx_knobs_check(void) {
   // library knobs, then the names the Python host / tools / tests of this repository read themselves
-  static const char* known[] = {"HX_CRITIC_CHUNK", "HX_BG_PERSIST", "HX_BG_TILE", "HX_CRITIC_LATE", "HX_CRITIC_CU_WORD", "HX_ACTOR_WAVES", "HX_ACTOR_ROWS", "HX_ACTOR_DEPTH", "HX_FWD_IN_TILE",
+  static const char* known[] = {"HX_CRITIC_CHUNK", "HX_BG_PERSIST", "HX_BG_TILE", "HX_BG_WAVES", "HX_CRITIC_LATE", "HX_CRITIC_CU_WORD", "HX_ACTOR_WAVES", "HX_ACTOR_ROWS", "HX_ACTOR_DEPTH", "HX_FWD_IN_TILE",
                                 "HX_UPDATE_STREAMS", "HX_WGRAD_BLOCKS", "HX_WGRAD_GROUP", "HX_WGRAD_MULTI", "HX_GEMM_SP", "HX_FRAMES_GATHER", "HX_GEMM_PAIR", "HX_HEAD_MFMA", "HX_CRITIC_YIELD", "HX_WGRAD_FLOOR", "HX_BENCH_LD0", "HX_BENCH_NODB", "HX_BENCH_NOKFULL", "HX_SIM_CU_WORD",
                                 "HX_COMM_TIMEOUT_S", "HX_COMM_INIT_TIMEOUT_S",
                                 "HX_DIST_BACKEND", "HX_DP_FORCE_RCCL", "HX_BENCH_CHILD_PROBE", "HX_STEP_PROF", "HX_STEP_PROF_CHILD", "HX_REFERENCE_ROOT"};
