@@ -181,6 +181,7 @@ def lib():
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.hx_ppo_actor_stamps.argtypes = [vp, vp, C.c_int]
     L.hx_sim_prof_waves.argtypes = [vp, vp, C.c_int]
+    L.hx_sim_prof_last.argtypes = [vp, vp, C.c_int]
     L.hx_ppo_gemm_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     L.hx_ppo_gemm_test.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.hx_ppo_wgrad_multi_test.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),

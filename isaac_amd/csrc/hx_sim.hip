@@ -200,7 +200,14 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
   if (prof != nullptr && tidx == 0) {
     lds_prof[16] += (long long)clock64(); lds_prof[17] += (long long)wall_clock64();
     for (int k = 0; k < 18; ++k) if (k != 15) atomicAdd((unsigned long long*)&p.prof[k], (unsigned long long)lds_prof[k]);
-    if (blockIdx.x < HX_PROF_WAVES) p.prof[20 + blockIdx.x] += lds_prof[17];        // per-wave lifetime (100 MHz ticks), summed over launches
+    if (blockIdx.x < HX_PROF_WAVES) {
+      p.prof[20 + blockIdx.x] += lds_prof[17];        // per-wave lifetime (100 MHz ticks), summed over launches
+      // of the LAST launch: start and end stamps (the 100 MHz counter is common to the whole device) and where the wave ran
+      const long long t_end = (long long)wall_clock64();
+      p.prof[20 + HX_PROF_WAVES + blockIdx.x] = t_end - lds_prof[17];
+      p.prof[20 + 2 * HX_PROF_WAVES + blockIdx.x] = t_end;
+      p.prof[20 + 3 * HX_PROF_WAVES + blockIdx.x] = ((long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);
+    }
   }
 #endif
 }
@@ -222,31 +229,55 @@ struct StackArgs {
   int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, 65 / 94 with arms, 47 / 73 for XBot-L) and row strides
   int priv_stack;                          // frames in a privileged row: 15, or c_frame_stack = 3 for XBot-L
 };
+// one row:  d[0 : keep) = rst ? 0 : s[F : F + keep),  d[keep : keep + F) = clip(frame[:, e]),  d[keep + F : ld) = 0.
+// Rows start 16-byte aligned and ld is a multiple of 4: every store is 16 bytes wide; the shifted source is misaligned by F % 4
+// floats, so a store's four values come from two aligned 16-byte loads (the second one hits the line the first one fetched).
+// Only the few 16-byte groups that touch the new frame or the padding are assembled element by element.
+__device__ __forceinline__ void stack_row(const float* __restrict__ s, float* __restrict__ d, const float* __restrict__ frame, const int e, const int n,
+                                          const int F, const int ld, const int keep, const bool rst, const float clip, const int tid, const int nthreads) {
+  const int m = F & 3, q0 = F >> 2, nq = ld >> 2;
+  const float4* s4 = reinterpret_cast<const float4*>(s);
+  float4* d4 = reinterpret_cast<float4*>(d);
+  for (int q = tid; q < nq; q += nthreads) {
+    const int k0 = 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + 3 < keep) {
+      if (!rst) {
+        const float4 a = s4[q + q0];
+        const float4 b = s4[min(q + q0 + 1, nq - 1)];
+        switch (m) {                           // uniform
+          case 0: v = a; break;
+          case 1: v = make_float4(a.y, a.z, a.w, b.x); break;
+          case 2: v = make_float4(a.z, a.w, b.x, b.y); break;
+          default: v = make_float4(a.w, b.x, b.y, b.z); break;
+        }
+      }
+    } else {
+      // clamped addresses, no branch around the loads: the eight of them are in flight together
+      float x[4], fs[4], ff[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        fs[c] = s[min(k + F, ld - 1)];
+        ff[c] = frame[(size_t)min(max(k - keep, 0), F - 1) * n + e];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = k0 + c;
+        x[c] = (k < keep) ? (rst ? 0.f : fs[c]) : (k < keep + F) ? fminf(fmaxf(ff[c], -clip), clip) : 0.f;
+      }
+      v = make_float4(x[0], x[1], x[2], x[3]);
+    }
+    d4[q] = v;
+  }
+}
 __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
   const int e = blockIdx.x;
   const bool rst = a.reset[e] != 0;
-  {
-    const int F = a.obs_f, ld = a.obs_ld, keep = (HX_FRAME_STACK - 1) * F;
-    const float* s = a.obs_src + (size_t)e * ld;
-    float* d = a.obs_dst + (size_t)e * ld;
-    for (int k = threadIdx.x; k < ld; k += blockDim.x) {
-      float v = 0.f;
-      if (k < keep) v = rst ? 0.f : s[k + F];
-      else if (k < keep + F) v = fminf(fmaxf(a.obs_frame[(size_t)(k - keep) * a.n + e], -a.clip), a.clip);
-      d[k] = v;
-    }
-  }
-  {
-    const int F = a.priv_f, ld = a.priv_ld, keep = (a.priv_stack - 1) * F;
-    const float* s = a.priv_src + (size_t)e * ld;
-    float* d = a.priv_dst + (size_t)e * ld;
-    for (int k = threadIdx.x; k < ld; k += blockDim.x) {
-      float v = 0.f;
-      if (k < keep) v = rst ? 0.f : s[k + F];
-      else if (k < keep + F) v = fminf(fmaxf(a.priv_frame[(size_t)(k - keep) * a.n + e], -a.clip), a.clip);
-      d[k] = v;
-    }
-  }
+  stack_row(a.obs_src + (size_t)e * a.obs_ld, a.obs_dst + (size_t)e * a.obs_ld, a.obs_frame, e, a.n, a.obs_f, a.obs_ld, (HX_FRAME_STACK - 1) * a.obs_f,
+            rst, a.clip, (int)threadIdx.x, (int)blockDim.x);
+  stack_row(a.priv_src + (size_t)e * a.priv_ld, a.priv_dst + (size_t)e * a.priv_ld, a.priv_frame, e, a.n, a.priv_f, a.priv_ld, (a.priv_stack - 1) * a.priv_f,
+            rst, a.clip, (int)threadIdx.x, (int)blockDim.x);
   if (threadIdx.x == 0) {
     // extras["time_outs"] is rebound only inside reset_idx, i.e. when at least one env reset this step
     // (legged_robot.py:172-173,208-209)
@@ -621,6 +652,7 @@ extern "C" int hx_sim_step(hx_sim* s, const float* actions, const float* pack) {
 extern "C" int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
                               float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst) {
   if (!actions) { hx_set_error("hx_sim_step_ex: actions is NULL"); return -2; }
+  if ((((uintptr_t)obs_dst) | ((uintptr_t)priv_dst)) & 15) { hx_set_error("hx_sim_step_ex: obs_dst / priv_dst must be 16-byte aligned (the rows are written with 16-byte stores)"); return -2; }
   StepOut o{obs_dst, priv_dst, rew_dst, done_dst, timeout_dst};
   return launch_step(s, actions, pack, 0, &o);
 }
@@ -789,9 +821,9 @@ extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }
 extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[18]*/) {
   if (!s) { hx_set_error("hx_sim_prof: null sim"); return -2; }
   if (which == 1) {
-    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 20 + HX_PROF_WAVES)) return -3; s->p.prof = d; }
+    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 20 + 4 * HX_PROF_WAVES)) return -3; s->p.prof = d; }
     HX_CHECK(hipStreamSynchronize(s->stream));
-    HX_CHECK(hipMemset(s->p.prof, 0, (20 + HX_PROF_WAVES) * sizeof(long long)));
+    HX_CHECK(hipMemset(s->p.prof, 0, (20 + 4 * HX_PROF_WAVES) * sizeof(long long)));
     return 0;
   }
   if (!s->p.prof || !out_h) { hx_set_error("hx_sim_prof: not started"); return -2; }
@@ -804,5 +836,14 @@ extern "C" int hx_sim_prof_waves(hx_sim* s, long long* out_h, int n) {
   if (!s || !s->p.prof || !out_h || n < 1 || n > HX_PROF_WAVES) { hx_set_error("hx_sim_prof_waves: not started or bad count"); return -2; }
   HX_CHECK(hipStreamSynchronize(s->stream));
   HX_CHECK(hipMemcpy(out_h, s->p.prof + 20, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+// of the most recent env-step launch, for its first `n` waves: out_h[0][n] start and [1][n] end (100 MHz ticks of the device-wide
+// counter), [2][n] (XCC_ID << 32) | HW_ID of the SIMD the wave ran on; -DHX_STEP_PROF builds (tools/env_waves.py)
+extern "C" int hx_sim_prof_last(hx_sim* s, long long* out_h, int n) {
+  if (!s || !s->p.prof || !out_h || n < 1 || n > HX_PROF_WAVES) { hx_set_error("hx_sim_prof_last: not started or bad count"); return -2; }
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  for (int k = 0; k < 3; ++k)
+    HX_CHECK(hipMemcpy(out_h + (size_t)k * n, s->p.prof + 20 + (size_t)(k + 1) * HX_PROF_WAVES, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }

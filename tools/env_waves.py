@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""GPU: when the waves of ONE env-step launch start and end, and on which SIMDs they run (-DHX_STEP_PROF build; stamps of the
+device-wide 100 MHz counter, include/hx_lab.h hx_sim_prof_last): (a) alone, back-to-back launches; (b) the last env step of a rollout
+(beside a background-critic batch).  Restores the normal build afterwards.  usage: python tools/env_waves.py [envs]"""
+import os, sys, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if os.environ.get("HX_STEP_PROF_CHILD") != "1":
+    env = dict(os.environ, HX_EXTRA_FLAGS_HX_SIM="-DHX_STEP_PROF", HX_STEP_PROF_CHILD="1")
+    subprocess.check_call([sys.executable, "-c", "from isaac_amd import build; build.build(force=True)"], env=env, cwd=ROOT)
+    rc = subprocess.call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT)
+    subprocess.check_call([sys.executable, "-c", "from isaac_amd import build; build.build(force=True)"], cwd=ROOT)
+    sys.exit(rc)
+import numpy as np
+from collections import Counter
+from isaac_amd import capi
+from isaac_amd.envs.configs import HectorCfg, HectorCfgPPO
+from isaac_amd.envs.hector_env import HectorFreeEnv, class_to_dict
+from isaac_amd.algo.on_policy_runner import OnPolicyRunner
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = HectorCfg(); cfg.env.num_envs = n; cfg.seed = 5
+np.random.seed(5)
+env = HectorFreeEnv(cfg)
+L = capi.lib()
+waves = (n + 7) // 8
+
+
+def last(label):
+    out = np.zeros((3, waves), np.int64)
+    capi.check(L.hx_sim_prof_last(env._h, out.ctypes.data, waves), "prof_last")
+    st, en, hw = out[0] / 100.0, out[1] / 100.0, out[2]
+    t0 = st.min()
+    so, eo, life = st - t0, en - t0, en - st
+    # HW_ID (gfx9 layout): wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13; XCC_ID in the high word
+    cu = ((hw >> 32) << 16) | ((hw & 0xffffffff) >> 8 & 0xff)
+    simd = (cu << 2) | ((hw >> 4) & 3)
+    per_cu = Counter(Counter(cu.tolist()).values())
+    per_simd = Counter(Counter(simd.tolist()).values())
+    q = lambda x: "p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(x, [50, 90, 99, 100]))
+    print(f"{label}: span (last end - first start) {eo.max():.1f} us")
+    print(f"   start after the first wave's, us: {q(so)}     lifetime, us: mean {life.mean():.1f} {q(life)}")
+    print(f"   CUs used {len(set(cu.tolist()))}, waves per CU {dict(sorted(per_cu.items()))}, waves per SIMD {dict(sorted(per_simd.items()))}")
+    late = np.argsort(eo)[-8:][::-1]
+    print("   the 8 waves that end last: " + "; ".join("start +%.0f, lives %.0f" % (so[i], life[i]) for i in late))
+    order = np.argsort(so)
+    print("   lifetime by start rank: " + ", ".join("waves %d-%d: mean %.0f max %.0f" % (a, b - 1, life[order[a:b]].mean(), life[order[a:b]].max())
+                                                   for a, b in ((0, 8), (8, 32), (32, 128), (128, 256), (256, waves))))
+    print("   the 8 that end last: block " + " ".join("%d(xcc %d, hw %#x)" % (i, hw[i] >> 32, hw[i] & 0xffffffff) for i in late))
+    print("   lifetime by block index: " + ", ".join("blocks %d-%d: mean %.0f max %.0f" % (a, b - 1, life[a:b].mean(), life[a:b].max())
+                                                    for a, b in ((0, 8), (8, 32), (32, 128), (128, 256), (256, waves))))
+    second = so > 20.0
+    print(f"   waves that start more than 20 us after the first: {int(second.sum())} (lifetime mean {life[second].mean() if second.any() else 0:.1f} us)")
+
+
+act = capi.DeviceBuffer.from_host((0.3 * np.random.default_rng(0).standard_normal((n, env.num_actions))).astype(np.float32))
+for _ in range(50):
+    L.hx_sim_step(env._h, act.ptr, None)
+capi.check(L.hx_sim_prof(env._h, 1, None), "prof")
+for k in range(3):
+    for _ in range(7):
+        L.hx_sim_step(env._h, act.ptr, None)
+    last("alone, back-to-back launches, sample %d" % k)
+runner = OnPolicyRunner(env, class_to_dict(HectorCfgPPO()), log_dir=None, device="cuda:0")
+runner.learn(2, init_at_random_ep_len=True)
+for k in range(5):
+    runner.learn(1, init_at_random_ep_len=False)
+    env.sync()
+    last("rollout, last env step of iteration %d (beside a critic batch)" % k)
