@@ -26,7 +26,7 @@ waves = (n + 7) // 8
 
 
 def last(label):
-    out = np.zeros((3, waves), np.int64)
+    out = np.zeros((12, waves), np.int64)
     capi.check(L.hx_sim_prof_last(env._h, out.ctypes.data, waves), "prof_last")
     st, en, hw = out[0] / 100.0, out[1] / 100.0, out[2]
     t0 = st.min()
@@ -48,6 +48,11 @@ def last(label):
     print("   the 8 that end last: block " + " ".join("%d(xcc %d, hw %#x)" % (i, hw[i] >> 32, hw[i] & 0xffffffff) for i in late))
     print("   lifetime by block index: " + ", ".join("blocks %d-%d: mean %.0f max %.0f" % (a, b - 1, life[a:b].mean(), life[a:b].max())
                                                     for a, b in ((0, 8), (8, 32), (32, 128), (128, 256), (256, waves))))
+    ph = out[3:12].astype(np.float64) / 1e3        # k cycles per phase
+    names = ["fetch", "action", "kinem", "contact", "inertia", "solve", "accel", "guard", "glue"]
+    slow = np.argsort(life)[-32:]; rest = np.argsort(life)[:-32]
+    print("   phase k-cycles, the 32 slowest waves / the others: " + ", ".join("%s %.1f / %.1f" % (nm, ph[k][slow].mean(), ph[k][rest].mean()) for k, nm in enumerate(names))
+          + "; sum %.0f / %.0f" % (ph[:, slow].sum(0).mean(), ph[:, rest].sum(0).mean()))
     second = so > 20.0
     print(f"   waves that start more than 20 us after the first: {int(second.sum())} (lifetime mean {life[second].mean() if second.any() else 0:.1f} us)")
 
@@ -60,6 +65,28 @@ for k in range(3):
     for _ in range(7):
         L.hx_sim_step(env._h, act.ptr, None)
     last("alone, back-to-back launches, sample %d" % k)
+# (a') the same without the stacking launch between the env steps (hx_sim_step_frames into a scratch frame slot; only the 16-workgroup
+# bookkeeping kernel runs in between): does an L2 that still holds the kernel's code and constants change who is slow?
+import ctypes as C
+
+
+class FrameSlot(C.Structure):
+    _fields_ = [("obs", C.c_void_p), ("obs_env_stride", C.c_int64), ("priv", C.c_void_p), ("priv_env_stride", C.c_int64),
+                ("obs_kz", C.c_void_p), ("priv_kz", C.c_void_p)]
+
+
+fo, fp = env.frame_dims[0], env.frame_dims[1] if hasattr(env, "frame_dims") else (41, 70)
+bo, bp = capi.DeviceBuffer(n * 64 * 4), capi.DeviceBuffer(n * 128 * 4)
+kz1, kz2 = capi.DeviceBuffer(n * 4), capi.DeviceBuffer(n * 4)
+slot = FrameSlot(bo.ptr, 64, bp.ptr, 128, kz1.ptr, kz2.ptr)
+L.hx_sim_step_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+for k in range(3):
+    for _ in range(7):
+        capi.check(L.hx_sim_step_frames(env._h, act.ptr, None, C.byref(slot), None, None, None), "step_frames")
+    last("alone, NO stacking launch between the env steps, sample %d" % k)
+sys.stdout.flush()
+if os.environ.get("ENV_WAVES_ALONE_ONLY") == "1":
+    sys.exit(0)
 runner = OnPolicyRunner(env, class_to_dict(HectorCfgPPO()), log_dir=None, device="cuda:0")
 runner.learn(2, init_at_random_ep_len=True)
 for k in range(5):
