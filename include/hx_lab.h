@@ -57,8 +57,9 @@ int hx_ppo_actor_stamps(hx_ppo* p, long long* out_h, int blocks);
 /* lifetimes of the first n env-step waves (wave w = robots 8w .. 8w+7), 100 MHz ticks summed over the launches since hx_sim_prof(s, 1, ..);
  * -DHX_STEP_PROF builds (tools/env_clock.py: which waves make a launch as long as it is) */
 int hx_sim_prof_waves(hx_sim* s, long long* out_h, int n);
-/* the most recent env-step launch, first n waves: out_h[12][n] = start, end (100 MHz device-wide ticks), (XCC_ID << 32) | HW_ID, then
- * the wave's shader-clock cycles in the nine phases hx_sim_prof reports */
+/* the most recent env-step launch, first n waves: out_h[18][n] = start, end (100 MHz device-wide ticks), (XCC_ID << 32) | HW_ID, the
+ * wave's shader-clock cycles in the nine phases hx_sim_prof reports, the shapes its contact loop visited (all substeps), the visits
+ * of the first five shapes */
 int hx_sim_prof_last(hx_sim* s, long long* out_h, int n);
 
 #ifdef __cplusplus

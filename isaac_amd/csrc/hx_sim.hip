@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
       p.prof[20 + HX_PROF_WAVES + blockIdx.x] = t_end - lds_prof[17];
       p.prof[20 + 2 * HX_PROF_WAVES + blockIdx.x] = t_end;
       p.prof[20 + 3 * HX_PROF_WAVES + blockIdx.x] = ((long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4);
-      for (int k = 0; k < 9; ++k) p.prof[20 + (4 + k) * HX_PROF_WAVES + blockIdx.x] = lds_prof[k];      // this wave's phase cycles in the last launch
+      for (int k = 0; k < 15; ++k) p.prof[20 + (4 + k) * HX_PROF_WAVES + blockIdx.x] = lds_prof[k];     // this wave's phase cycles and contact-loop visits in the last launch
     }
   }
 #endif
@@ -822,9 +822,9 @@ extern "C" void* hx_sim_stream(hx_sim* s) { return (void*)s->stream; }
 extern "C" int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[18]*/) {
   if (!s) { hx_set_error("hx_sim_prof: null sim"); return -2; }
   if (which == 1) {
-    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 20 + 13 * HX_PROF_WAVES)) return -3; s->p.prof = d; }
+    if (!s->p.prof) { long long* d = nullptr; if (dalloc(s, &d, 20 + 19 * HX_PROF_WAVES)) return -3; s->p.prof = d; }
     HX_CHECK(hipStreamSynchronize(s->stream));
-    HX_CHECK(hipMemset(s->p.prof, 0, (20 + 13 * HX_PROF_WAVES) * sizeof(long long)));
+    HX_CHECK(hipMemset(s->p.prof, 0, (20 + 19 * HX_PROF_WAVES) * sizeof(long long)));
     return 0;
   }
   if (!s->p.prof || !out_h) { hx_set_error("hx_sim_prof: not started"); return -2; }
@@ -841,11 +841,12 @@ extern "C" int hx_sim_prof_waves(hx_sim* s, long long* out_h, int n) {
 }
 // of the most recent env-step launch, for its first `n` waves: out_h[0][n] start and [1][n] end (100 MHz ticks of the device-wide
 // counter), [2][n] (XCC_ID << 32) | HW_ID of the SIMD the wave ran on, [3..11][n] the wave's cycles in the nine phases of
-// hx_sim_prof; -DHX_STEP_PROF builds (tools/env_waves.py)
+// hx_sim_prof, [12][n] shapes visited by its contact loop (all substeps), [13..17][n] visits of the first five shapes;
+// -DHX_STEP_PROF builds (tools/env_waves.py)
 extern "C" int hx_sim_prof_last(hx_sim* s, long long* out_h, int n) {
   if (!s || !s->p.prof || !out_h || n < 1 || n > HX_PROF_WAVES) { hx_set_error("hx_sim_prof_last: not started or bad count"); return -2; }
   HX_CHECK(hipStreamSynchronize(s->stream));
-  for (int k = 0; k < 12; ++k)
+  for (int k = 0; k < 18; ++k)
     HX_CHECK(hipMemcpy(out_h + (size_t)k * n, s->p.prof + 20 + (size_t)(k + 1) * HX_PROF_WAVES, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }

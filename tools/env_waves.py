@@ -26,7 +26,7 @@ waves = (n + 7) // 8
 
 
 def last(label):
-    out = np.zeros((12, waves), np.int64)
+    out = np.zeros((18, waves), np.int64)
     capi.check(L.hx_sim_prof_last(env._h, out.ctypes.data, waves), "prof_last")
     st, en, hw = out[0] / 100.0, out[1] / 100.0, out[2]
     t0 = st.min()
@@ -53,6 +53,11 @@ def last(label):
     slow = np.argsort(life)[-32:]; rest = np.argsort(life)[:-32]
     print("   phase k-cycles, the 32 slowest waves / the others: " + ", ".join("%s %.1f / %.1f" % (nm, ph[k][slow].mean(), ph[k][rest].mean()) for k, nm in enumerate(names))
           + "; sum %.0f / %.0f" % (ph[:, slow].sum(0).mean(), ph[:, rest].sum(0).mean()))
+    vis = out[12:18].astype(np.float64)
+    print("   contact-loop visits per env step (10 substeps x 2 sides' loop = wave-level), the 32 slowest / the others: total %.1f / %.1f; shapes 0-4: %s / %s"
+          % (vis[0][slow].mean(), vis[0][rest].mean(), np.round(vis[1:, slow].mean(1), 1).tolist(), np.round(vis[1:, rest].mean(1), 1).tolist()))
+    print("   contact k-cycles per visit: slowest %.1f, others %.1f;  correlation of a wave's lifetime with its visits %.2f, with its start offset %.2f"
+          % (ph[3][slow].sum() / max(vis[0][slow].sum(), 1), ph[3][rest].sum() / max(vis[0][rest].sum(), 1), np.corrcoef(life, vis[0])[0, 1], np.corrcoef(life, so)[0, 1]))
     second = so > 20.0
     print(f"   waves that start more than 20 us after the first: {int(second.sum())} (lifetime mean {life[second].mean() if second.any() else 0:.1f} us)")
 
@@ -65,6 +70,14 @@ for k in range(3):
     for _ in range(7):
         L.hx_sim_step(env._h, act.ptr, None)
     last("alone, back-to-back launches, sample %d" % k)
+if os.environ.get("ENV_WAVES_ALONE_ONLY") == "1":
+    sys.exit(0)
+runner = OnPolicyRunner(env, class_to_dict(HectorCfgPPO()), log_dir=None, device="cuda:0")
+runner.learn(2, init_at_random_ep_len=True)
+for k in range(5):
+    runner.learn(1, init_at_random_ep_len=False)
+    env.sync()
+    last("rollout, last env step of iteration %d (beside a critic batch)" % k)
 # (a') the same without the stacking launch between the env steps (hx_sim_step_frames into a scratch frame slot; only the 16-workgroup
 # bookkeeping kernel runs in between): does an L2 that still holds the kernel's code and constants change who is slow?
 import ctypes as C
@@ -84,12 +97,3 @@ for k in range(3):
     for _ in range(7):
         capi.check(L.hx_sim_step_frames(env._h, act.ptr, None, C.byref(slot), None, None, None), "step_frames")
     last("alone, NO stacking launch between the env steps, sample %d" % k)
-sys.stdout.flush()
-if os.environ.get("ENV_WAVES_ALONE_ONLY") == "1":
-    sys.exit(0)
-runner = OnPolicyRunner(env, class_to_dict(HectorCfgPPO()), log_dir=None, device="cuda:0")
-runner.learn(2, init_at_random_ep_len=True)
-for k in range(5):
-    runner.learn(1, init_at_random_ep_len=False)
-    env.sync()
-    last("rollout, last env step of iteration %d (beside a critic batch)" % k)
