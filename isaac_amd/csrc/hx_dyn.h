@@ -325,6 +325,50 @@ HXD float shape_gap(const DynParams& P, const float* shp, const M3& Rb, V3 pb) {
   }
   return zlow - bound - P.coff;
 }
+// Second stage of that test, for a shape the sphere could not exclude: the geometric part of contact_shape's own activity test
+// (a point takes part only if its penetration exceeds -contact offset), for this lane's points, with the body pose still in
+// registers and the same arithmetic as contact_shape -- position, cell, triangle plane, penetration along the normal.  The pooled
+// bound of the first stage is the highest ground within 0.3 m: next to a stair riser, a kerb or a pit wall it flags every shape
+// of the robot, substep after substep, and every such visit walks its points down to this very test before it finds nothing
+// (profiles/r04_al_env_waves.txt: 2.4 visits per substep, 1.0 of them with a contact; a wave with such a robot: 6 and 1.3).
+// Returns < 0 if one of the lane's points may be active; HX_GAP_MARGIN keeps the decision on the visiting side of rounding.
+#define HX_GAP_MARGIN 1e-4f
+template <int NP>
+HXD float shape_gap_points(const DynParams& P, const float* shp, const M3& Rb, V3 pb) {
+  const float* pts = shp + 4;
+  const V3 zb = row(Rb, 2);
+  float gap = 1.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NJ = (NP + HX_LANES_PER_SIDE - 1) / HX_LANES_PER_SIDE;
+#else
+  constexpr int NJ = NP;
+#endif
+  V3 r[NJ]; bool valid[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { const int k = P.pt0 + j * P.ptstep; valid[j] = k < NP; r[j] = ld3(pts + 3 * (valid[j] ? k : P.pt0)); }
+  float z[NJ], u[NJ], w[NJ], cliff[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    z[j] = pb.z + dot(zb, r[j]);
+    u[j] = 0.f; w[j] = 0.f; cliff[j] = 0.f;
+    if (P.patch != nullptr) {
+      u[j] = (pb.x + dot(row(Rb, 0), r[j]) - P.px0) * P.inv_hs; w[j] = (pb.y + dot(row(Rb, 1), r[j]) - P.py0) * P.inv_hs;
+      cliff[j] = P.poolw[terrain_pool_index(u[j], w[j])];
+    }
+  }
+  TerrainCell cell[NJ];
+  if (P.patch != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cell[j] = terrain_fetch(P, u[j], w[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    float pen = -z[j];
+    if (P.patch != nullptr) { V3 nw; const float h = terrain_eval(P, cell[j], nw, cliff[j] != 0.f); pen = (h - z[j]) * nw.z; }
+    if (valid[j]) gap = fminf(gap, -(pen + P.roff + P.coff) - HX_GAP_MARGIN);
+  }
+  return gap;
+}
 
 // Contact terms of one shape (`shp`: bounding sphere centre xyz + radius, then npts xyz triples; LDS): the body state
 // comes from slot `in` of the buffer, explicit force and implicit 6x6 are ACCUMULATED into slot `out` (several base
@@ -371,6 +415,9 @@ HXD bool contact_shape(const DynParams& P, const float* shp, int npts, const Con
 #pragma unroll
     for (int j = 0; j < HX_PT_GROUP; ++j) { near_[j] = valid[j] && (z[j] < bound[j] + P.coff); any_near = any_near || near_[j]; }
     if (!hx_any(any_near)) continue;
+#if defined(HX_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (P.prof != nullptr && threadIdx.x == 0) P.prof[13] += 1;      // [13] point groups that passed the pooled per-point test (any side)
+#endif
     TerrainCell cell[HX_PT_GROUP];
     if (P.patch != nullptr) {
 #pragma unroll
@@ -569,15 +616,31 @@ HXD void side_kin(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, con
       if (K == 1) W.v[B].w.y += S.qd[B];
       if (K == 2) W.v[B].w.z += S.qd[B];
       for (int i = 0; i < 3; ++i) setrow(Rc, i, rotT<K>(c, s, row(Rc, i)));
-      if constexpr (MI::slot(B) >= 0) { gap[MI::slot(B)] = shape_gap(P, C.shape(B), Rc, pc); cb.put_body(MI::slot(B), W.v[B], Rc, pc); }
+      if constexpr (MI::slot(B) >= 0) {
+        gap[MI::slot(B)] = shape_gap(P, C.shape(B), Rc, pc); cb.put_body(MI::slot(B), W.v[B], Rc, pc);
+        // the foot touches most of the time: a second stage would only repeat what its visit does
+#ifndef HX_NO_GAP2
+        if constexpr (B != M::FOOT) { if (hx_any(gap[MI::slot(B)] < 0.f)) gap[MI::slot(B)] = shape_gap_points<M::NPTS[B]>(P, C.shape(B), Rc, pc); }
+#endif
+      }
     });
   });
-  for (int k = 0; k < M::BASE_NSUB; ++k) gap[MI::NSHAPE + k] = shape_gap(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos);
+  for (int k = 0; k < M::BASE_NSUB; ++k) {
+    gap[MI::NSHAPE + k] = shape_gap(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos);
+#ifndef HX_NO_GAP2
+    if (hx_any(gap[MI::NSHAPE + k] < 0.f)) gap[MI::NSHAPE + k] = shape_gap_points<M::BASE_NP>(P, C.bsub + k * (4 + 3 * M::BASE_NP), W.R0, S.pos);
+#endif
+  }
   cb.put_body(MI::NSHAPE, W.v0, W.R0, S.pos);
   uint32_t maybe = 0u;
   for (int k = 0; k < MI::NENT; ++k) maybe |= hx_any(gap[k] < 0.f) ? (1u << k) : 0u;
 #if defined(HX_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
-  if (P.prof != nullptr && threadIdx.x == 0) { P.prof[9] += __popc(maybe); for (int k = 0; k < MI::NENT && k < 5; ++k) P.prof[10 + k] += (maybe >> k) & 1u; }
+  // [9] shapes visited; [11] sides (of the wave's 16) whose own test asked for the visit, summed; [12] visits that a single side asked for
+  {
+    int sides = 0, single = 0;
+    for (int k = 0; k < MI::NENT; ++k) { const int c = __popcll(__ballot(gap[k] < 0.f)) / HX_LANES_PER_SIDE; sides += c; single += (c == 1); }
+    if (P.prof != nullptr && threadIdx.x == 0) { P.prof[9] += __popc(maybe); P.prof[11] += sides; P.prof[12] += single; }
+  }
 #endif
   HX_T(P.prof, 2);
   // ---- contact phase: one runtime loop over this lane's shapes (its shape bodies, then its share of the base)
@@ -587,7 +650,11 @@ HXD void side_kin(SideWork<M>& W, const DynStateT<M>& S, const DynParams& P, con
     for (int e = 0; e < MI::NENT; ++e) {
       if (!((maybe >> e) & 1u)) continue;
       const int off = C.ent[3 * e], np = C.ent[3 * e + 1], slot = C.ent[3 * e + 2];
-      if (contact_shape(P, C.lds + off, np, cb, slot, slot, (touched >> slot) & 1u)) touched |= (1u << slot);
+      const bool hit = contact_shape(P, C.lds + off, np, cb, slot, slot, (touched >> slot) & 1u);
+      if (hit) touched |= (1u << slot);
+#if defined(HX_STEP_PROF) && defined(__HIP_DEVICE_COMPILE__)
+      if (P.prof != nullptr && threadIdx.x == 0) P.prof[10] += hit ? 1 : 0;      // [10] visits that found a contact (any side)
+#endif
     }
     W.touched = touched;
   }

@@ -1435,7 +1435,10 @@ static void gemm_fwd(hx_ppo* s, hipStream_t st, const float* X, int ldx, const f
   }
   else if (background && s->bg_persist > 0) {
     // the rollout's background critic on a small fixed grid: see hx_gemm_persistent_kernel
-    if (s->bg_tile != 128) {        // 64-row tiles: 31 KB of LDS beside the actor's 99 KB, and measured better (profiles/r02_e)
+    // 128-row tiles since round 4: with the env step 16 us shorter (hx_dyn.h shape_gap_points) the 64-row tiles that round 2 preferred
+    // (profiles/r02_e) no longer finish a two-slot batch inside its two steps and the remainder lands in the update (+2.5 ms);
+    // the 128-row tiles do (profiles/r04_ba_critic_tiles.txt).  HX_BG_TILE=64 restores the old choice.
+    if (s->bg_tile == 64) {
       g.tiles_m = (g.M + 63) / 64; g.tiles_n = (g.N + 127) / 128;
       hipLaunchKernelGGL((hx_gemm_persistent_kernel<64, 128, HX_BK_ROLL, true, true, EPI_BIAS_ELU>), dim3(s->bg_persist), dim3(256), 0, st, g, g.tiles_m * g.tiles_n);
     } else {

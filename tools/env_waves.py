@@ -54,8 +54,9 @@ def last(label):
     print("   phase k-cycles, the 32 slowest waves / the others: " + ", ".join("%s %.1f / %.1f" % (nm, ph[k][slow].mean(), ph[k][rest].mean()) for k, nm in enumerate(names))
           + "; sum %.0f / %.0f" % (ph[:, slow].sum(0).mean(), ph[:, rest].sum(0).mean()))
     vis = out[12:18].astype(np.float64)
-    print("   contact-loop visits per env step (10 substeps x 2 sides' loop = wave-level), the 32 slowest / the others: total %.1f / %.1f; shapes 0-4: %s / %s"
-          % (vis[0][slow].mean(), vis[0][rest].mean(), np.round(vis[1:, slow].mean(1), 1).tolist(), np.round(vis[1:, rest].mean(1), 1).tolist()))
+    print("   contact-loop visits per env step (wave-level), the 32 slowest / the others: %.1f / %.1f; of them with a contact %.1f / %.1f; sides that asked, per visit %.2f / %.2f; visits asked for by ONE side %.1f / %.1f; point groups past the per-point pooled test %.1f / %.1f"
+          % (vis[0][slow].mean(), vis[0][rest].mean(), vis[1][slow].mean(), vis[1][rest].mean(), vis[2][slow].sum() / max(vis[0][slow].sum(), 1), vis[2][rest].sum() / max(vis[0][rest].sum(), 1),
+             vis[3][slow].mean(), vis[3][rest].mean(), vis[4][slow].mean(), vis[4][rest].mean()))
     print("   contact k-cycles per visit: slowest %.1f, others %.1f;  correlation of a wave's lifetime with its visits %.2f, with its start offset %.2f"
           % (ph[3][slow].sum() / max(vis[0][slow].sum(), 1), ph[3][rest].sum() / max(vis[0][rest].sum(), 1), np.corrcoef(life, vis[0])[0, 1], np.corrcoef(life, so)[0, 1]))
     second = so > 20.0

@@ -43,6 +43,7 @@ print(f"N={n} {task} {mesh}: cycles per wave and env step (shader clock), {steps
 for nm, c in zip(names, per):
     print(f"  {nm:45s} {c:10.0f} cycles  {100 * c / per.sum():5.1f} %")
 print(f"  {'total':45s} {per.sum():10.0f} cycles")
-print("  contact-loop entries visited per substep (wave-level: any of the wave's 8 robots): %.2f of the lane's entries; first five entries: %s" % (visits[0] * 2, np.round(visits[1:6] * 2, 2)))
+print("  contact-loop shapes visited per substep (wave-level: any of the wave's 16 sides): %.2f; of them with a contact %.2f; sides that asked, per visit %.2f of 16; visits that ONE side asked for %.2f"
+      % (visits[0] * 2, visits[1] * 2, visits[2] / max(visits[0], 1e-9), visits[3] * 2))
 if out[17] > 0:
     print("  in-kernel clock (sum over waves of d s_memtime / d s_memrealtime x 100 MHz): %.3f GHz; a wave lives %.1f us on average" % (0.1 * out[16] / out[17], out[17] / (waves * steps) / 100.0))
