@@ -239,7 +239,13 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   constexpr SLay SL(ND);
   constexpr int SLOT_THIGH = M::XBOT ? -1 : MI::slot(2), SLOT_TOE = MI::slot(M::FOOT);      // XBot-L: no thigh shape; only 'base_link' terminates / is penalised
 #define LD(f) (p.st[(size_t)(f) * n + e])
-#define ST(f, val) (p.st[(size_t)(f) * n + e] = (val))
+  // the state is stored through an index the compiler cannot tie to the one it was loaded through: otherwise the 64-bit address of
+  // every field read at the start of the kernel is kept (registers, then scratch) for its store at the end (18 DoF: ~60 fields)
+  int e_st = e;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(e_st));
+#endif
+#define ST(f, val) (p.st[(size_t)(f) * n + e_st] = (val))
   float* act = R.act; float* qa = R.qa; float* qda = R.qda; const float* torques = R.torques;
   int ep_len = R.ep_len;
   bool reset = false, time_out = false;
@@ -310,6 +316,32 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
   const V3 foot_pos[2] = {R.bo[1].pos, R.bo[3].pos}, foot_vel[2] = {R.bo[1].linvel, R.bo[3].linvel};
   const V3 knee_pos[2] = {R.bo[0].pos, R.bo[2].pos};
   bool contact[2] = {foot_f[0].z > 5.0f, foot_f[1].z > 5.0f};
+  if (writer) {
+    // stored first: nothing below changes them, and the knee / foot orientations and angular velocities (28 values) and the forces
+    // of the other shape bodies have no other reader -- kept to the end they were spilled around the whole glue (18 DoF)
+    // diagnostic tensors (contact_forces / rigid_state views of the reference)
+    {
+      p.contact[(size_t)0 * n + e] = R.f_base.x; p.contact[(size_t)1 * n + e] = R.f_base.y; p.contact[(size_t)2 * n + e] = R.f_base.z;
+      for (int sd = 0; sd < 2; ++sd)
+        static_for<NL>([&](auto ic) {
+          constexpr int B = decltype(ic)::value;
+          if constexpr (MI::slot(B) >= 0) {
+            const int body = 1 + sd * NL + B;
+            const V3 f = R.side_force[sd][MI::slot(B)];
+            p.contact[(size_t)(body * 3 + 0) * n + e] = f.x;
+            p.contact[(size_t)(body * 3 + 1) * n + e] = f.y;
+            p.contact[(size_t)(body * 3 + 2) * n + e] = f.z;
+          }
+        });
+    }
+    for (int b = 0; b < 4; ++b) {
+      float* o = p.bodies + (size_t)(b * 13) * n + e;
+      o[0] = R.bo[b].pos.x; o[(size_t)1 * n] = R.bo[b].pos.y; o[(size_t)2 * n] = R.bo[b].pos.z;
+      for (int k = 0; k < 4; ++k) o[(size_t)(3 + k) * n] = R.bo[b].quat[k];
+      o[(size_t)7 * n] = R.bo[b].linvel.x; o[(size_t)8 * n] = R.bo[b].linvel.y; o[(size_t)9 * n] = R.bo[b].linvel.z;
+      o[(size_t)10 * n] = R.bo[b].angvel.x; o[(size_t)11 * n] = R.bo[b].angvel.y; o[(size_t)12 * n] = R.bo[b].angvel.z;
+    }
+  }
 
   auto stance_mask = [&](int len, float* sm) {
     const float phase = (float)len * cfg.env_dt / cfg.cycle_time;
@@ -563,9 +595,17 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
       f[5 + ND + j] = qda[j] * cfg.obs_scale_dof_vel;
       f[5 + 2 * ND + j] = act[j];
     }
+    // the privileged frame leaves in two parts (its first PB entries here, the rest below) so that the whole of it, the
+    // observation frame and that frame's noise are never live together (18 DoF: 94 + 65 + 65 values)
+    auto put_priv = [&](int k0, int k1) {
+      if (!writer) return;
+      if (A.frames) { float* d = A.fs.priv + (size_t)e * A.fs.priv_env_stride; for (int k = k0; k < k1; ++k) d[k] = fminf(fmaxf(f[k], -A.clip), A.clip); }
+      else for (int k = k0; k < k1; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+    };
     // obs41 = [cmd5, q10, dq10, a10, ang_vel3, euler3]
     float o[OBSF];
     for (int k = 0; k < PB; ++k) o[k] = f[k];
+    put_priv(0, PB);
     o[PB] = base_ang_vel.x * cfg.obs_scale_ang_vel; o[PB + 1] = base_ang_vel.y * cfg.obs_scale_ang_vel; o[PB + 2] = base_ang_vel.z * cfg.obs_scale_ang_vel;
     o[PB + 3] = euler.x * cfg.obs_scale_quat; o[PB + 4] = euler.y * cfg.obs_scale_quat; o[PB + 5] = euler.z * cfg.obs_scale_quat;
     if (cfg.add_noise) {
@@ -607,10 +647,7 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
       f[PB + 29] = R.friction; f[PB + 30] = R.base_mass / 30.f;
       f[PB + 31] = sm[0]; f[PB + 32] = sm[1]; f[PB + 33] = contact[0] ? 1.f : 0.f; f[PB + 34] = contact[1] ? 1.f : 0.f;
     }
-    if (writer) {
-      if (A.frames) { float* d = A.fs.priv + (size_t)e * A.fs.priv_env_stride; for (int k = 0; k < PRIVF; ++k) d[k] = fminf(fmaxf(f[k], -A.clip), A.clip); }
-      else for (int k = 0; k < PRIVF; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
-    }
+    put_priv(PB, PRIVF);
   }
 
   // ---- bookkeeping (legged_robot.py:146-150) and store
@@ -648,28 +685,6 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
     const int age = reset ? 1 : hx_imin((int)p.age[e] + 1, A.obs_stack);
     p.age[e] = (unsigned char)age;
     if (A.frames) { A.fs.obs_kz[e] = (A.obs_stack - age) * OBSF; A.fs.priv_kz[e] = hx_imax(A.priv_stack - age, 0) * PRIVF; }
-  }
-  // diagnostic tensors (contact_forces / rigid_state views of the reference)
-  {
-    p.contact[(size_t)0 * n + e] = R.f_base.x; p.contact[(size_t)1 * n + e] = R.f_base.y; p.contact[(size_t)2 * n + e] = R.f_base.z;
-    for (int sd = 0; sd < 2; ++sd)
-      static_for<NL>([&](auto ic) {
-        constexpr int B = decltype(ic)::value;
-        if constexpr (MI::slot(B) >= 0) {
-          const int body = 1 + sd * NL + B;
-          const V3 f = R.side_force[sd][MI::slot(B)];
-          p.contact[(size_t)(body * 3 + 0) * n + e] = f.x;
-          p.contact[(size_t)(body * 3 + 1) * n + e] = f.y;
-          p.contact[(size_t)(body * 3 + 2) * n + e] = f.z;
-        }
-      });
-  }
-  for (int b = 0; b < 4; ++b) {
-    float* o = p.bodies + (size_t)(b * 13) * n + e;
-    o[0] = R.bo[b].pos.x; o[(size_t)1 * n] = R.bo[b].pos.y; o[(size_t)2 * n] = R.bo[b].pos.z;
-    for (int k = 0; k < 4; ++k) o[(size_t)(3 + k) * n] = R.bo[b].quat[k];
-    o[(size_t)7 * n] = R.bo[b].linvel.x; o[(size_t)8 * n] = R.bo[b].linvel.y; o[(size_t)9 * n] = R.bo[b].linvel.z;
-    o[(size_t)10 * n] = R.bo[b].angvel.x; o[(size_t)11 * n] = R.bo[b].angvel.y; o[(size_t)12 * n] = R.bo[b].angvel.z;
   }
 #undef LD
 #undef ST

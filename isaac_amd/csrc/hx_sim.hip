@@ -145,9 +145,14 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
     }
     const float mass_scale = R.base_mass / M::MASS0;
     const int decimation = cfg.decimation;
+    // the processed actions are needed again by the glue: over the substeps they wait in the robot's random-number exchange area
+    // (idle here) instead of in registers (18 DoF: 18 of them)
+    float* const park = const_cast<float*>(rng.share);
+    for (int j = 0; j < ND; ++j) park[j] = R.act[j];
 #pragma unroll 1
     for (int sub = 0; sub < decimation; ++sub)
       dyn_substep<M>(S, P, C, cb, target, mass_scale, tau_side, sub == decimation - 1, F);
+    for (int j = 0; j < ND; ++j) R.act[j] = park[j];
     // Blow-up guard (no reference counterpart; PhysX clamps internally).  A non-finite or runaway state would put NaNs
     // into the observations and from there into every weight.  Such a robot is put back on its start pose with zero
     // forces right here, so nothing downstream sees the bad numbers, and the step ends its episode as a fall.
