@@ -1,8 +1,5 @@
-run() { env $2 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-print('$1', round(d['ms_per_step'],2), round(d['ms_per_step_median'],2), round(d['config']['collection_s']*1e3,2), round(d['config']['learn_s']*1e3,2), round(d['value']/1e6,3))"; }
-run mixed ""
-run all128 "HX_BG_TILE=128"
-run mixed ""
-run all128 "HX_BG_TILE=128"
+for g in 2 3 1; do
+HX_EXTRA_FLAGS_HX_SIM="-DHX_PT_GROUP=$g" python -c "from isaac_amd import build; build.build(force=True)" > /dev/null 2>&1
+echo "PT_GROUP=$g"; python tools/sim_bench.py 4096 300 trimesh 2>/dev/null | tail -1; python tools/sim_bench.py 4096 300 plane 2>/dev/null | tail -1
+done
+python -c "from isaac_amd import build; build.build(force=True)" > /dev/null 2>&1
