@@ -193,6 +193,11 @@ int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const flo
  * HX_BUF_OBS / HX_BUF_PRIV then point at obs_dst / priv_dst until the next step. */
 int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
                    float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst);
+/* Scheduling hint for a consumer that runs background work beside the rollout (the learner's deferred critic): while `word` (device
+ * memory, two int32) is set, the stacking launch of every hx_sim_step_ex adds 1 to word[0] when it starts and sets word[1] = 1; the
+ * consumer's next launch takes the 1 back (word[1] tells it to).  Background kernels that sleep while word[0] is up then leave the
+ * memory system to the stacking launch.  NULL (default): off.  Changes scheduling only. */
+int hx_sim_set_pause_word(hx_sim* s, int32_t* word);
 /* Single-frame observation storage (the rollout fast path of hx_rollout; no reference counterpart: it changes WHERE the
  * 15-frame rows of hector_env.py:246-254 live, not what they are).  The reference re-materialises every robot's
  * [15 x 41] / [15 x 70] stack each step and stores all of them (rollout_storage.py:60-61: 1.64 GB per 60-step rollout at 4096

@@ -103,6 +103,7 @@ def lib():
     L.hx_sim_reset_all.argtypes = [vp, vp]
     L.hx_sim_step.argtypes = [vp, vp, vp]
     L.hx_sim_step_ex.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.hx_sim_set_pause_word.argtypes = [vp, vp]
     L.hx_sim_buffer.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.hx_sim_get_state.argtypes = [vp, vp, vp, vp]
     L.hx_sim_set_state.argtypes = [vp, vp, vp, vp]

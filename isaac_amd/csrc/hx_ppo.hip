@@ -358,7 +358,11 @@ __global__ void __launch_bounds__(64 * NW) hx_actor_fused_kernel(const float* __
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   // the background critic's persistent workgroups sleep while this count is up (hx_gemm.h GemmArgs::pause): the actor is on
   // the rollout's critical path and shares half the CUs with them
-  if (pause != nullptr && threadIdx.x == 0) atomicAdd(pause, 1);
+  if (pause != nullptr && threadIdx.x == 0) {
+    atomicAdd(pause, 1);
+    // the stacking launch before this one raised the count for itself (hx_sim_set_pause_word): taken back here, after our own +1
+    if (blockIdx.x == 0 && atomicExch(pause + 1, 0) == 1) atomicSub(pause, 1);
+  }
 #ifdef HX_ACTOR_PROF
   // phase stamps of workgroup b (100 MHz ticks): pause[16 + 16 b + i]; tools/actor_prof.py
 #define HX_AST(i) do { if (pause != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) reinterpret_cast<long long*>(pause + 16)[blockIdx.x * 8 + (i)] = (long long)wall_clock64(); } while (0)
@@ -1291,6 +1295,7 @@ struct hx_ppo {
   int* pause_flag = nullptr;     // count of fused-actor workgroups in flight; the background critic sleeps while it is up (HX_CRITIC_YIELD)
   int bg_persist;                // > 0: the background critic's GEMMs run on this many persistent workgroups (HX_BG_PERSIST)
   int bg_waves;                  // 4: hx_gemm_persistent_kernel (four waves per workgroup, half the CUs); 2: hx_gemm_sp_persistent_kernel (two waves, every CU) (HX_BG_WAVES)
+  int stack_pause;               // HX_STACK_PAUSE: the background critic sleeps through the simulator's stacking launch too
   int bg_tile;                   // experiment knob HX_BG_TILE: rows per tile of the background critic's GEMMs (0 = by batch size)
   float* last_values; double* moments;
   int step;
@@ -1951,6 +1956,7 @@ static int ppo_create_impl(const hx_ppo_cfg* cfg, void* stream, void* ext_grad, 
   if (int rc = hx_knob_int("HX_FWD_IN_TILE", 128, 64, 128, &s->fwd_in_tile)) return rc;
   if (s->fwd_in_tile != 64 && s->fwd_in_tile != 128) { hx_set_error("HX_FWD_IN_TILE: 64 or 128"); return -2; }
   if (int rc = hx_knob_int("HX_BG_TILE", 0, 0, 128, &s->bg_tile)) return rc;
+  if (int rc = hx_knob_int("HX_STACK_PAUSE", 1, 0, 1, &s->stack_pause)) return rc;
   if (int rc = hx_knob_int("HX_BG_WAVES", 4, 2, 4, &s->bg_waves)) return rc;
   if (s->bg_waves == 3) { hx_set_error("HX_BG_WAVES: 2 or 4"); return -2; }
   if (s->bg_tile != 0 && s->bg_tile != 64 && s->bg_tile != 128) { hx_set_error("HX_BG_TILE: 0 (by batch size), 64 or 128"); return -2; }
@@ -2977,7 +2983,11 @@ extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const i
   const int N = p->cfg.num_envs, T = p->cfg.num_steps;
   // the count of fused-actor workgroups in flight starts every rollout at zero: a decrement lost to an aborted launch cannot
   // outlive the iteration (the background critic's bounded wait, hx_pause_poll, would otherwise be paid again every flush)
-  if (p->pause_flag && p->step == 0) HX_CHECK(hipMemsetAsync(p->pause_flag, 0, sizeof(int), p->stream));
+  if (p->pause_flag && p->step == 0) HX_CHECK(hipMemsetAsync(p->pause_flag, 0, 2 * sizeof(int), p->stream));
+  // single-shard row rollouts: the critic also sleeps through the stacking launch (HX_STACK_PAUSE)
+  const bool stack_pause = p->pause_flag && p->stack_pause && !p->frames && nshards == 1 && hx_sim_stream(sims[0]) == (void*)p->stream;
+  struct PauseWordGuard { hx_sim* s; ~PauseWordGuard() { if (s) (void)hx_sim_set_pause_word(s, nullptr); } } pause_guard{nullptr};      // off again on every way out
+  if (stack_pause) { const int rc = hx_sim_set_pause_word(sims[0], p->pause_flag); if (rc) return rc; pause_guard.s = sims[0]; }
   if (p->frames) {
     if (nshards != 1 || count[0] != N) { hx_set_error("hx_rollout: single-frame storage takes one simulator with all of the learner's robots"); return -2; }
     return rollout_frames(p, sims[0], steps);
@@ -3011,6 +3021,7 @@ extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const i
       }
     }
   }
+  if (stack_pause) HX_CHECK(hipMemsetAsync(p->pause_flag, 0, 2 * sizeof(int), p->stream));      // the last stacking launch's count has no actor behind it
   return 0;
 }
 

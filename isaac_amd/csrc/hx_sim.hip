@@ -232,6 +232,7 @@ struct StackArgs {
   float* stat_sum; float* stat_last; float* stat_acc; int* stat_steps;
   const float* rew; float* rew_out; unsigned char* done_out; unsigned char* timeout_out;
   int n; float clip;
+  int* pause;                              // hx_sim_set_pause_word: raised by this launch, lowered by its consumer's next launch
   int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, 65 / 94 with arms, 47 / 73 for XBot-L) and row strides
   int priv_stack;                          // frames in a privileged row: 15, or c_frame_stack = 3 for XBot-L
 };
@@ -279,6 +280,9 @@ __device__ __forceinline__ void stack_row(const float* __restrict__ s, float* __
 }
 __global__ void __launch_bounds__(256) hx_stack_kernel(StackArgs a) {
   const int e = blockIdx.x;
+  // a consumer's background work (the learner's critic on its half of the chip) sleeps while word 0 is up; word 1 tells the consumer's
+  // next launch that this one raised it
+  if (a.pause != nullptr && e == 0 && threadIdx.x == 0) { atomicAdd(a.pause, 1); a.pause[1] = 1; }
   const bool rst = a.reset[e] != 0;
   stack_row(a.obs_src + (size_t)e * a.obs_ld, a.obs_dst + (size_t)e * a.obs_ld, a.obs_frame, e, a.n, a.obs_f, a.obs_ld, (HX_FRAME_STACK - 1) * a.obs_f,
             rst, a.clip, (int)threadIdx.x, (int)blockDim.x);
@@ -309,7 +313,7 @@ void hx_set_error(const std::string& s) { g_err = s; }
 extern char** environ;
 int hx_knobs_check(void) {
   // library knobs, then the names the Python host / tools / tests of this repository read themselves
-  static const char* known[] = {"HX_CRITIC_CHUNK", "HX_BG_PERSIST", "HX_BG_TILE", "HX_BG_WAVES", "HX_CRITIC_LATE", "HX_CRITIC_CU_WORD", "HX_ACTOR_WAVES", "HX_ACTOR_ROWS", "HX_ACTOR_DEPTH", "HX_FWD_IN_TILE",
+  static const char* known[] = {"HX_CRITIC_CHUNK", "HX_BG_PERSIST", "HX_BG_TILE", "HX_BG_WAVES", "HX_STACK_PAUSE", "HX_CRITIC_LATE", "HX_CRITIC_CU_WORD", "HX_ACTOR_WAVES", "HX_ACTOR_ROWS", "HX_ACTOR_DEPTH", "HX_FWD_IN_TILE",
                                 "HX_UPDATE_STREAMS", "HX_WGRAD_BLOCKS", "HX_WGRAD_GROUP", "HX_WGRAD_MULTI", "HX_GEMM_SP", "HX_FRAMES_GATHER", "HX_GEMM_PAIR", "HX_HEAD_MFMA", "HX_CRITIC_YIELD", "HX_WGRAD_FLOOR", "HX_BENCH_LD0", "HX_BENCH_NODB", "HX_BENCH_NOKFULL", "HX_SIM_CU_WORD",
                                 "HX_COMM_TIMEOUT_S", "HX_COMM_INIT_TIMEOUT_S",
                                 "HX_DIST_BACKEND", "HX_DP_FORCE_RCCL", "HX_BENCH_CHILD_PROBE", "HX_STEP_PROF", "HX_STEP_PROF_CHILD", "HX_REFERENCE_ROOT"};
@@ -368,6 +372,7 @@ struct hx_sim {
   int* num_reset2[2]; int parity;
   // frame-mode steps (hx_sim_step_frames): the bookkeeping of the last step, owed until its rows' next reader takes it
   hx_step_book book; bool book_owed;
+  int* pause_word = nullptr;     // hx_sim_set_pause_word
   bool rows_stale = false;       // frame-mode steps have run since the row buffers were last written
   unsigned char* timeout_visible;
   long long step_counter;
@@ -639,7 +644,7 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   k.num_reset = s->num_reset2[s->parity]; k.num_reset_next = s->num_reset2[s->parity ^ 1];
   k.stat_sum = s->p.stat_sum; k.stat_last = s->p.stat_last; k.stat_acc = s->p.stat_acc; k.stat_steps = s->p.stat_steps;
   k.rew = s->p.rew; k.rew_out = out ? out->rew : nullptr; k.done_out = out ? out->done : nullptr; k.timeout_out = out ? out->timeout : nullptr;
-  k.n = n; k.clip = s->cfg.clip_observations;
+  k.n = n; k.clip = s->cfg.clip_observations; k.pause = (out && out->obs) ? s->pause_word : nullptr;
   k.obs_f = s->obs_f; k.obs_ld = s->obs_ld; k.priv_f = s->priv_f; k.priv_ld = s->priv_ld; k.priv_stack = s->priv_stack;
   hipLaunchKernelGGL(hx_stack_kernel, dim3(n), dim3(256), 0, s->stream, k);
   s->obs_cur = od; s->priv_cur = pd;
@@ -661,6 +666,12 @@ extern "C" int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack
   if ((((uintptr_t)obs_dst) | ((uintptr_t)priv_dst)) & 15) { hx_set_error("hx_sim_step_ex: obs_dst / priv_dst must be 16-byte aligned (the rows are written with 16-byte stores)"); return -2; }
   StepOut o{obs_dst, priv_dst, rew_dst, done_dst, timeout_dst};
   return launch_step(s, actions, pack, 0, &o);
+}
+
+extern "C" int hx_sim_set_pause_word(hx_sim* s, int32_t* word) {
+  if (!s) { hx_set_error("hx_sim_set_pause_word: null sim"); return -2; }
+  s->pause_word = word;
+  return 0;
 }
 
 // ---- single-frame observation storage (include/hx_sim.h)
