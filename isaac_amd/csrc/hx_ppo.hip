@@ -2985,7 +2985,9 @@ extern "C" int hx_rollout(hx_ppo* p, hx_sim** sims, const int32_t* env0, const i
   // outlive the iteration (the background critic's bounded wait, hx_pause_poll, would otherwise be paid again every flush)
   if (p->pause_flag && p->step == 0) HX_CHECK(hipMemsetAsync(p->pause_flag, 0, 2 * sizeof(int), p->stream));
   // single-shard row rollouts: the critic also sleeps through the stacking launch (HX_STACK_PAUSE)
-  const bool stack_pause = p->pause_flag && p->stack_pause && !p->frames && nshards == 1 && hx_sim_stream(sims[0]) == (void*)p->stream;
+  // (only with the fused rollout actor: it is that kernel's first workgroup that takes the stacking launch's count back)
+  const bool fused_actor = p->L[0].out == 512 && p->L[1].out == 256 && p->L[2].out == 128 && p->cfg.obs_ld == p->L[0].in_ld;
+  const bool stack_pause = p->pause_flag && p->stack_pause && fused_actor && !p->frames && nshards == 1 && hx_sim_stream(sims[0]) == (void*)p->stream;
   struct PauseWordGuard { hx_sim* s; ~PauseWordGuard() { if (s) (void)hx_sim_set_pause_word(s, nullptr); } } pause_guard{nullptr};      // off again on every way out
   if (stack_pause) { const int rc = hx_sim_set_pause_word(sims[0], p->pause_flag); if (rc) return rc; pause_guard.s = sims[0]; }
   if (p->frames) {
