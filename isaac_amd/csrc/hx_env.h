@@ -31,8 +31,8 @@ struct SimPtrs {
   float* torques;     // [ND][N]
   float* contact;     // [(1 + ND) * 3][N]
   float* bodies;      // [52][N]
-  float* obs_frame;   // [OBSF][N]
-  float* priv_frame;  // [PRIVF][N]
+  float* obs_frame;   // [N][OBSF]   (robot-major since round 4: the stacking launch reads a robot's frame as one contiguous run)
+  float* priv_frame;  // [N][PRIVF]
   float* rew;         // [N]
   unsigned char* reset;    // [N]
   unsigned char* age;      // [N] real frames in the robot's observation history (1 .. frame_stack)
@@ -600,7 +600,7 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
     auto put_priv = [&](int k0, int k1) {
       if (!writer) return;
       if (A.frames) { float* d = A.fs.priv + (size_t)e * A.fs.priv_env_stride; for (int k = k0; k < k1; ++k) d[k] = fminf(fmaxf(f[k], -A.clip), A.clip); }
-      else for (int k = k0; k < k1; ++k) p.priv_frame[(size_t)k * n + e] = f[k];
+      else for (int k = k0; k < k1; ++k) p.priv_frame[(size_t)e * PRIVF + k] = f[k];
     };
     // obs41 = [cmd5, q10, dq10, a10, ang_vel3, euler3]
     float o[OBSF];
@@ -618,7 +618,7 @@ HXD void env_glue(const SimPtrs& p, const hx_sim_cfg& cfg, const StepArgs& A, co
     }
     if (writer) {
       if (A.frames) { float* d = A.fs.obs + (size_t)e * A.fs.obs_env_stride; for (int k = 0; k < OBSF; ++k) d[k] = fminf(fmaxf(o[k], -A.clip), A.clip); }
-      else for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)k * n + e] = o[k];
+      else for (int k = 0; k < OBSF; ++k) p.obs_frame[(size_t)e * OBSF + k] = o[k];
     }
     if constexpr (M::XBOT) {
       // humanoid_env.py:218-236: [cmd 5, q, dq, a, q - ref_dof_pos, lin vel 3, ang vel 3, euler 3, push 2 + 3, friction, mass / 30,

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64 * HX_ENV_WPB) hx_env_step_kernel(SimPtrs p,
 
 // Frame stacking for BOTH observation streams (hector_env.py:246-254 + clip of legged_robot.py:104-107), one
 // workgroup per env, coalesced along the rows:
-//   dst[e][0:(S-1)*F] = reset ? 0 : src[e][F:S*F] ;  dst[e][(S-1)*F : S*F] = clip(frame[:,e]).
+//   dst[e][0:(S-1)*F] = reset ? 0 : src[e][F:S*F] ;  dst[e][(S-1)*F : S*F] = clip(frame[e][:]).
 // dst may be the learner's rollout storage (zero-copy hand-over, hx_sim_step_ex); the same launch refreshes
 // extras["time_outs"], hands reward / done / time-out to the learner's slot and recycles the reset counter.
 struct StackArgs {
@@ -236,7 +236,7 @@ struct StackArgs {
   int obs_f, obs_ld, priv_f, priv_ld;      // frame widths (41 / 70, 65 / 94 with arms, 47 / 73 for XBot-L) and row strides
   int priv_stack;                          // frames in a privileged row: 15, or c_frame_stack = 3 for XBot-L
 };
-// one row:  d[0 : keep) = rst ? 0 : s[F : F + keep),  d[keep : keep + F) = clip(frame[:, e]),  d[keep + F : ld) = 0.
+// one row:  d[0 : keep) = rst ? 0 : s[F : F + keep),  d[keep : keep + F) = clip(frame[e][:]),  d[keep + F : ld) = 0.
 // Rows start 16-byte aligned and ld is a multiple of 4: every store is 16 bytes wide; the shifted source is misaligned by F % 4
 // floats, so a store's four values come from two aligned 16-byte loads (the second one hits the line the first one fetched).
 // Only the few 16-byte groups that touch the new frame or the padding are assembled element by element.
@@ -266,7 +266,7 @@ __device__ __forceinline__ void stack_row(const float* __restrict__ s, float* __
       for (int c = 0; c < 4; ++c) {
         const int k = k0 + c;
         fs[c] = s[min(k + F, ld - 1)];
-        ff[c] = frame[(size_t)min(max(k - keep, 0), F - 1) * n + e];
+        ff[c] = frame[(size_t)e * F + min(max(k - keep, 0), F - 1)];
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {

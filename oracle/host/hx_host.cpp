@@ -191,7 +191,7 @@ static void stack_frames(hxh_env* s) {
       for (int k = 0; k < ld; ++k) {
         float v = 0.f;
         if (k < keep) v = rst ? 0.f : src[k + F];
-        else if (k < keep + F) v = fminf(fmaxf(fr[(size_t)(k - keep) * n + e], -clip), clip);
+        else if (k < keep + F) v = fminf(fmaxf(fr[(size_t)e * F + (k - keep)], -clip), clip);
         dst[k] = v;
       }
     }
