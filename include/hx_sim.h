@@ -190,7 +190,9 @@ int hx_sim_step(hx_sim* s, const float* actions /*[N][10] row-major*/, const flo
 /* hx_sim_step with zero-copy hand-over: the new observation rows ([N][HX_OBS_LD] / [N][HX_PRIV_LD]) and, if rew_dst is
  * not NULL, reward / done / extras["time_outs"] of the step are written straight into the caller's buffers (the
  * learner's rollout storage, what RolloutStorage.add_transitions copies in the reference, rollout_storage.py:87-100).
- * HX_BUF_OBS / HX_BUF_PRIV then point at obs_dst / priv_dst until the next step. */
+ * HX_BUF_OBS / HX_BUF_PRIV then point at obs_dst / priv_dst until the next step.  obs_dst / priv_dst must be 16-byte aligned (rows are
+ * HX_OBS_LD / HX_PRIV_LD floats, multiples of 4, written with 16-byte stores) and must not be the buffers the previous step wrote
+ * (the new rows are built from those, one frame down); both are checked and refused with a message. */
 int hx_sim_step_ex(hx_sim* s, const float* actions, const float* pack, float* obs_dst, float* priv_dst,
                    float* rew_dst, uint8_t* done_dst, uint8_t* timeout_dst);
 /* Scheduling hint for a consumer that runs background work beside the rollout (the learner's deferred critic): while `word` (device

@@ -636,7 +636,11 @@ static int launch_step(hx_sim* s, const float* actions, const float* pack, int m
   // destination of the new observation rows: the caller's (learner storage) or the other internal buffer
   float* od = s->obs[s->cur ^ 1]; float* pd = s->priv[s->cur ^ 1];
   if (s->obs_cur == od) { od = s->obs[s->cur]; pd = s->priv[s->cur]; }
-  if (out && out->obs) { od = out->obs; pd = out->priv; } else s->cur ^= 1;
+  if (out && out->obs) {
+    od = out->obs; pd = out->priv;
+    // the new rows are built from the previous step's (one frame down): in place is a race between the launch's workgroups
+    if (od == s->obs_cur || pd == s->priv_cur) { hx_set_error("hx_sim_step_ex: obs_dst / priv_dst are the rows of the previous step (HX_BUF_OBS / HX_BUF_PRIV): the new rows need a buffer of their own"); return -2; }
+  } else s->cur ^= 1;
   StackArgs k{};
   k.obs_src = s->obs_cur; k.obs_dst = od; k.obs_frame = s->p.obs_frame;
   k.priv_src = s->priv_cur; k.priv_dst = pd; k.priv_frame = s->p.priv_frame;

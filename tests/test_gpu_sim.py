@@ -320,3 +320,43 @@ def test_curriculum_with_device_rng(hxlib):
     info, cnt = env.episode_stats()
     assert info["terrain_level"] == pytest.approx(float(np.mean(env.terrain_levels)))
     env.close()
+
+
+def test_zero_copy_step_writes_the_callers_rows_and_refuses_misaligned_ones(hxlib):
+    """hx_sim_step_ex (include/hx_sim.h): the stacking launch writes observation t+1 and reward / done / time-out of step t straight
+    into the caller's buffers with 16-byte stores -- the same values hx_sim_step leaves in the simulator's own buffers -- and a
+    destination that is not 16-byte aligned is refused with a message instead of being written to."""
+    from isaac_amd import capi
+    from isaac_amd.envs.configs import HectorCfg
+    from isaac_amd.envs.hector_env import HectorFreeEnv
+    from isaac_amd.utils.helpers import set_seed
+    N = 40                                   # five waves; not a multiple of anything else
+    outs = []
+    for zero_copy in (False, True):
+        cfg = HectorCfg(); cfg.env.num_envs = N; cfg.seed = set_seed(3)
+        env = HectorFreeEnv(cfg)
+        act = capi.DeviceBuffer.from_host((0.2 * np.random.default_rng(1).standard_normal((N, 10))).astype(np.float32))
+        L = env._L
+        if zero_copy:
+            ods = [capi.DeviceBuffer(N * env.obs_ld * 4 + 64) for _ in range(2)]
+            pds = [capi.DeviceBuffer(N * env.priv_ld * 4 + 64) for _ in range(2)]
+            rw, dn, to = capi.DeviceBuffer(N * 4), capi.DeviceBuffer(N), capi.DeviceBuffer(N)
+            rc = L.hx_sim_step_ex(env._h, act.ptr, None, ods[0].ptr + 4, pds[0].ptr, rw.ptr, dn.ptr, to.ptr)
+            assert rc != 0 and b"16-byte aligned" in L.hx_last_error()
+            for t in range(3):                   # the rollout storage's pattern: slot t + 1 is written from slot t
+                capi.check(L.hx_sim_step_ex(env._h, act.ptr, None, ods[t & 1].ptr, pds[t & 1].ptr, rw.ptr, dn.ptr, to.ptr), "step_ex")
+            rc = L.hx_sim_step_ex(env._h, act.ptr, None, ods[0].ptr, pds[0].ptr, rw.ptr, dn.ptr, to.ptr)      # in place: the rows of the step before
+            assert rc != 0 and b"buffer of their own" in L.hx_last_error()
+            od, pd = ods[0], pds[0]
+            env.sync()
+            outs.append((od.download(np.float32, (N, env.obs_ld)), pd.download(np.float32, (N, env.priv_ld)), rw.download(np.float32, (N,)), dn.download(np.uint8, (N,))))
+        else:
+            for _ in range(3):
+                capi.check(L.hx_sim_step(env._h, act.ptr, None), "step")
+            env.sync()
+            outs.append((env._buf(capi.BUF_OBS, (N, env.obs_ld)).numpy().copy(), env._buf(capi.BUF_PRIV, (N, env.priv_ld)).numpy().copy(),
+                         env._buf(capi.BUF_REW, (N,)).numpy().copy(), env._buf(capi.BUF_RESET, (N,), np.uint8).numpy().copy()))
+        env.close()
+    for a, b, name in zip(outs[0], outs[1], ("obs rows", "privileged rows", "rewards", "dones")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert np.abs(outs[0][0]).sum() > 0
