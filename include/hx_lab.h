@@ -54,6 +54,8 @@ int hx_sim_prof(hx_sim* s, int which, long long* out_h /*[18]: 9 phase timers, s
 /* phase stamps of the fused rollout actor's last launch, [blocks][8] 100 MHz ticks (start, rows staged, after layer 1, 2, 3, head, log-prob);
  * only in a library built with HX_EXTRA_FLAGS_HX_PPO="-DHX_ACTOR_PROF" (tools/actor_prof.py) */
 int hx_ppo_actor_stamps(hx_ppo* p, long long* out_h, int blocks);
+/* the learner's two pause words (hx_sim_set_pause_word): 0, 0 whenever no rollout launch is in flight */
+int hx_ppo_pause_words(hx_ppo* p, int32_t* out_h);
 /* lifetimes of the first n env-step waves (wave w = robots 8w .. 8w+7), 100 MHz ticks summed over the launches since hx_sim_prof(s, 1, ..);
  * -DHX_STEP_PROF builds (tools/env_clock.py: which waves make a launch as long as it is) */
 int hx_sim_prof_waves(hx_sim* s, long long* out_h, int n);

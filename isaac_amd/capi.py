@@ -181,6 +181,7 @@ def lib():
     L.hx_wgrad_plan_describe.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_int,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.hx_ppo_actor_stamps.argtypes = [vp, vp, C.c_int]
+    L.hx_ppo_pause_words.argtypes = [vp, vp]
     L.hx_sim_prof_waves.argtypes = [vp, vp, C.c_int]
     L.hx_sim_prof_last.argtypes = [vp, vp, C.c_int]
     L.hx_ppo_gemm_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]

@@ -1677,6 +1677,17 @@ extern "C" int hx_ppo_gemm_test(int mode, int M, int N, int K, const float* A, i
   return 0;
 }
 
+// the two words the background critic's sleep hangs on (count of launches it yields to; "a stacking launch raised it"): both are 0
+// whenever no rollout launch is in flight -- what tests/test_gpu_runner.py asserts after rollouts of every kind
+extern "C" int hx_ppo_pause_words(hx_ppo* s, int32_t* out_h /*[2]*/) {
+  if (!s || !out_h) { hx_set_error("hx_ppo_pause_words: null argument"); return -2; }
+  out_h[0] = out_h[1] = 0;
+  if (!s->pause_flag) return 0;
+  HX_CHECK(hipStreamSynchronize(s->stream));
+  if (s->stream2) HX_CHECK(hipStreamSynchronize(s->stream2));
+  HX_CHECK(hipMemcpy(out_h, s->pause_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
 // phase stamps of the fused actor's last launch (-DHX_ACTOR_PROF builds, tools/actor_prof.py): [blocks][8] 100 MHz ticks
 extern "C" int hx_ppo_actor_stamps(hx_ppo* s, long long* out_h, int blocks) {
 #ifdef HX_ACTOR_PROF

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(libpath):
 def test_lab_hooks_are_not_in_the_product_headers():
     """Measurement / unit-test hooks live in include/hx_lab.h; the boundary headers and INTEGRATION.md do not cite them."""
     product, lab = _declared(("hx_sim.h", "hx_ppo.h")), _declared(("hx_lab.h",))
-    for name in ("hx_ppo_gemm_test", "hx_ppo_wgrad_multi_test", "hx_wgrad_plan_describe", "hx_ppo_actor_stamps", "hx_ppo_gemm_bench", "hx_mfma_probe", "hx_sim_prof", "hx_sim_prof_waves", "hx_sim_prof_last", "hx_sim_time", "hx_ppo_prof_begin", "hx_ppo_prof_end"):
+    for name in ("hx_ppo_gemm_test", "hx_ppo_wgrad_multi_test", "hx_wgrad_plan_describe", "hx_ppo_actor_stamps", "hx_ppo_pause_words", "hx_ppo_gemm_bench", "hx_mfma_probe", "hx_sim_prof", "hx_sim_prof_waves", "hx_sim_prof_last", "hx_sim_time", "hx_ppo_prof_begin", "hx_ppo_prof_end"):
         assert name in lab and name not in product, name
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert not (lab - product) & set(re.findall(r"\b(hx_[a-z0-9_]+)\b", integ))

@@ -297,3 +297,41 @@ def test_humanoid_ppo_trains_through_the_registry(hxlib, tmp_path):
     root, q, qd = env.get_state()
     assert q.shape == (128, 12) and np.all(np.isfinite(q)) and 0.6 < np.median(root[:, 2] - env.env_origins[:, 2]) < 1.1   # standing height
     env.close()
+
+
+@pytest.mark.parametrize("task", ["hector", "humanoid_ppo"])
+def test_pause_words_are_zero_after_every_rollout(hxlib, task):
+    """The background critic sleeps while a device count is up: the fused actor raises it per workgroup and lowers it again, and the
+    simulator's stacking launch raises it once for itself with the NEXT fused-actor launch taking that 1 back (hx_sim_set_pause_word).
+    A count that is left up costs every critic workgroup its whole sleep budget (round 4: with the layer-by-layer rollout actor of
+    humanoid_ppo / hector_full nobody took the stacking launch's 1 back, and their iterations were 8 % slower until the hand-over was
+    restricted to the fused actor).  After a rollout -- whole, in pieces, followed by an update -- both words must read 0."""
+    import ctypes
+    from isaac_amd.envs.configs import HectorCfg, XBotLCfg
+    from isaac_amd.envs.hector_env import HectorFreeEnv, XBotLFreeEnv
+    from isaac_amd.algo.ppo import PPO, ActorCritic
+    from isaac_amd.utils.helpers import set_seed
+    N, T = 128, 8
+    cfg_cls, env_cls = (HectorCfg, HectorFreeEnv) if task == "hector" else (XBotLCfg, XBotLFreeEnv)
+    cfg = cfg_cls(); cfg.env.num_envs = N; cfg.seed = set_seed(2)
+    if task != "hector":
+        cfg.terrain.mesh_type = "plane"
+    env = env_cls(cfg)
+    dims = ([512, 256, 128], [768, 256, 128]) if task == "hector" else ([256, 128, 64], [256, 128, 64])
+    alg = PPO(ActorCritic(env.num_obs, env.num_privileged_obs, env.num_actions, *dims), num_learning_epochs=1, num_mini_batches=2, stream=env.stream)
+    alg.init_storage(N, T, [env.num_obs], [env.num_privileged_obs], [env.num_actions], obs_ld=env.obs_ld, priv_ld=env.priv_ld)
+    words = (ctypes.c_int32 * 2)()
+
+    def check(when):
+        rc = alg._L.hx_ppo_pause_words(alg._h, words)
+        assert rc == 0 and (words[0], words[1]) == (0, 0), f"{when}: pause words {words[0]}, {words[1]}"
+
+    check("before any rollout")
+    for pieces in ((T,), (3, T - 3), (1,) * T):
+        for n in pieces:
+            alg.rollout([env], n)
+            check(f"after a rollout piece of {n} steps")
+        alg.compute_returns(env.get_privileged_observations())
+        alg.update()
+        check("after the update")
+    alg.close(); env.close()
