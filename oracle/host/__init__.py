@@ -15,9 +15,10 @@ _libs = {}
 
 
 def build(asan=False):
-    """Serialised across processes (flock): every rank of a job started by a launcher may call this at the same time."""
+    """Serialised across processes (flock): every rank of a job started by a launcher may call this at the same time.
+    asan: False (the optimised build), True (AddressSanitizer + UBSan), "nogap2" (optimised, -DHX_NO_GAP2)."""
     import fcntl
-    target = "asan" if asan else "all"
+    target = "nogap2" if asan == "nogap2" else "asan" if asan else "all"
     os.makedirs(OUT_DIR, exist_ok=True)
     with open(os.path.join(OUT_DIR, ".build.lock"), "w") as lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
@@ -25,14 +26,18 @@ def build(asan=False):
             subprocess.check_call(["make", "-s", "-C", _HERE, target])
         finally:
             fcntl.flock(lk, fcntl.LOCK_UN)
-    return os.path.join(OUT_DIR, "libhx_host_asan.so" if asan else "libhx_host.so")
+    return os.path.join(OUT_DIR, _so_name(asan))
+
+
+def _so_name(asan):
+    return "libhx_host_nogap2.so" if asan == "nogap2" else "libhx_host_asan.so" if asan else "libhx_host.so"
 
 
 def lib(asan=False, build_if_missing=True):
-    key = bool(asan)
+    key = asan if asan == "nogap2" else bool(asan)
     if key in _libs:
         return _libs[key]
-    path = os.path.join(OUT_DIR, "libhx_host_asan.so" if asan else "libhx_host.so")
+    path = os.path.join(OUT_DIR, _so_name(asan))
     if build_if_missing and os.path.exists(os.path.join(_HERE, "Makefile")):
         build(asan)          # make is a no-op when the binary is current; a failed build is never masked by a stale binary
     L = C.CDLL(path)

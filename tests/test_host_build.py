@@ -131,3 +131,40 @@ def test_host_build_under_address_and_ub_sanitizers():
     r = subprocess.run([sys.executable, "-c", code.replace("\\n", "\n")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "sanitized replay ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("task", ["hector", "hector_full"])
+def test_second_stage_of_the_bounding_test_changes_nothing(task):
+    """hx_dyn.h shape_gap_points (round 4): a shape that the bounding-sphere test flags is tested again, exactly, before it is put on
+    the contact loop's visit list.  It may only skip visits that would have found no contact.  The host build with and without it
+    (-DHX_NO_GAP2), free-running 128 robots on the default tile map from a drop (falls, wall contacts, resets included), must agree
+    bit for bit in everything the step returns."""
+    from isaac_amd.envs.configs import HectorCfg, HectorFullCfg
+    from isaac_amd.utils.helpers import set_seed
+    from oracle.host import HostEnv
+    n, steps = 128, 70
+    outs = []
+    for variant in (False, "nogap2"):
+        cfg = (HectorCfg if task == "hector" else HectorFullCfg)(); cfg.env.num_envs = n; cfg.seed = set_seed(11)
+        np.random.seed(11)
+        env = HostEnv(cfg, task=task, asan=variant)
+        nd = env.nd
+        rng = np.random.default_rng(5)
+        rec = []
+        for t in range(steps):
+            obs, priv, rew, reset = env.step((1.0 * rng.standard_normal((n, nd))).astype(np.float32))
+            rec.append((obs, priv, rew, reset.copy(), env.contact_forces, env.torques))
+        outs.append(rec)
+        env.close()
+    resets = sum(int(r[3].sum()) for r in outs[0])
+    nl = outs[0][0][5].shape[1] // 2
+    feet = [nl, 2 * nl]                                  # body index (1 + joint) of the two feet: the last body of each leg chain (hector) ...
+    if task != "hector":
+        feet = [5, 5 + nl]                               # ... the fifth of each side for hector_full (arms follow the leg)
+    other = [b for b in range(outs[0][0][4].shape[1]) if b not in feet]
+    nonfoot = sum(int((np.abs(r[4][:, other, :]).sum(axis=2) > 0).sum()) for r in outs[0])
+    print(f"{task}: {resets} resets, {nonfoot} (step, robot, body) contacts of bodies other than the feet")
+    assert nonfoot > 20 and (resets >= 1 or task != "hector"), (resets, nonfoot)        # robots did touch with more than their feet (and hector fell)
+    for t, (a, b) in enumerate(zip(*outs)):
+        for x, y, name in zip(a, b, ("obs", "priv", "rewards", "resets", "contact forces", "torques")):
+            np.testing.assert_array_equal(x, y, err_msg=f"step {t}: {name}")
