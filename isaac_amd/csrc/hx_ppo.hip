@@ -2576,8 +2576,10 @@ extern "C" int hx_ppo_process_step_range(hx_ppo* s, const float* rew, const uint
 // bootstrap values V(s_T) for env rows [env0, env0+count)  (first half of PPO.compute_returns, ppo.py:116)
 extern "C" int hx_ppo_last_values_range(hx_ppo* s, const float* last_priv, int env0, int count, void* stream) {
   hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  // activations in the backward pass's scratch (idle until the update): the deferred critic's last batch, which owns act_c, may still
+  // be running on the second stream while this runs (hx_ppo_compute_returns)
   float* ac[3];
-  for (int l = 0; l < 3; ++l) ac[l] = s->act_c[l] + (size_t)env0 * s->cfg.critic_hidden[l];
+  for (int l = 0; l < 3; ++l) ac[l] = s->dz_c[l] + (size_t)env0 * s->cfg.critic_hidden[l];
   mlp_hidden_fwd(s, 1, last_priv, s->cfg.priv_ld, count, ac, st);
   hipLaunchKernelGGL(hx_value_head_kernel, dim3((count + 15) / 16), dim3(256), 0, st, ac[2], s->cfg.critic_hidden[2],
                      s->params + s->L[7].w, s->params + s->L[7].b, count, s->last_values + env0);
@@ -2591,8 +2593,10 @@ extern "C" int hx_ppo_compute_returns(hx_ppo* s, const float* last_priv) {
   // finish the deferred critic for every stored slot, then make the main stream wait for it
   // (whatever the background critic did not get to -- it yields to the actor -- runs here on the whole chip, not on its half-chip grid)
   if (s->crit_done < s->step) { HX_CHECK(hipEventRecord(s->ev_priv, s->stream)); const int rc = critic_flush(s, s->step, true); if (rc) return rc; }
-  HX_CHECK(hipStreamWaitEvent(s->stream, s->ev_crit, 0));
+  // the bootstrap values need nothing of the deferred critic: they run while its last batch finishes on the second stream (130 us of
+  // the ~300 us between the rollout's last launch and GAE, profiles/r04_ba_critic_tiles.txt)
   if (last_priv) { const int rc = hx_ppo_last_values_range(s, last_priv, 0, N, s->stream); if (rc) return rc; }
+  HX_CHECK(hipStreamWaitEvent(s->stream, s->ev_crit, 0));
   HX_CHECK(hipMemsetAsync(s->moments, 0, 3 * sizeof(double), s->stream));
   hipLaunchKernelGGL(hx_gae_kernel, dim3((N + 255) / 256), dim3(256), 0, s->stream, s->s_rewards, s->s_dones, s->s_timeouts, s->s_values, s->last_values,
                      T, N, s->cfg.gamma, s->cfg.lam, s->s_returns, s->s_adv_raw, s->moments);
